@@ -1,0 +1,11 @@
+"""3bz_amd — MI355X-native inflate engine behind 3bz's octet-vector API.
+
+`import 3bz_amd` is not valid Python syntax (the name starts with a digit); load it with
+    importlib.import_module("3bz_amd")
+The package holds only what the hot path needs: csrc/ (HIP kernels + host engine + C ABI),
+the ctypes binding and the host-side mirror of the reference's API.
+"""
+from .api import (Engine, EngineError, ThreeBzError, decompress, decompress_vector, default_engine,  # noqa: F401
+                  finished, input_underrun, make_deflate_state, make_gzip_state, make_octet_vector_context,
+                  make_zlib_state, output_overflow, replace_output_buffer, set_default_engine)
+from ._lib import FORMATS, Result, Timings  # noqa: F401

@@ -1,0 +1,83 @@
+"""ctypes binding of lib3bz_amd.so (the C ABI of include/tbz_amd.h).
+
+The product path is the HIP library and nothing else: if it is missing or cannot be loaded this
+module raises — there is no CPU fallback of any kind.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "lib3bz_amd.so"
+
+FORMATS = {"deflate": 0, "zlib": 1, "gzip": 2}
+FINISHED, INPUT_UNDERRUN, OUTPUT_OVERFLOW = 0, 1, 2
+
+
+class Result(C.Structure):
+    """struct tbz_result"""
+    _fields_ = [("status", C.c_int32), ("segments", C.c_uint32), ("out_len", C.c_uint64),
+                ("out_total", C.c_uint64), ("in_consumed", C.c_uint64), ("adler32", C.c_uint32),
+                ("crc32", C.c_uint32), ("trailer_check", C.c_uint32), ("trailer_isize", C.c_uint32),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
+class Timings(C.Structure):
+    """struct tbz_timings"""
+    _fields_ = [("scan_ms", C.c_float), ("huff_ms", C.c_float), ("lz_ms", C.c_float), ("cksum_ms", C.c_float),
+                ("total_ms", C.c_float), ("huff_launches", C.c_uint32), ("fixup_rounds", C.c_uint32),
+                ("token_words", C.c_uint64), ("n_segments", C.c_uint64), ("n_groups", C.c_uint64)]
+
+
+assert C.sizeof(Result) == 64
+
+# every symbol include/tbz_amd.h declares
+SYMBOLS = [
+    "tbz_ctx_create", "tbz_ctx_destroy", "tbz_abi_version", "tbz_strerror", "tbz_last_error",
+    "tbz_device_count", "tbz_inflate", "tbz_inflate_size", "tbz_inflate_batch", "tbz_inflate_device",
+    "tbz_inflate_batch_device", "tbz_adler32_device", "tbz_crc32_device", "tbz_device_malloc",
+    "tbz_device_free", "tbz_memcpy_h2d", "tbz_memcpy_d2h", "tbz_last_timings",
+]
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+def default_path():
+    return os.path.join(_HERE, LIB_NAME)
+
+
+def load(path=None):
+    """Load the library and declare prototypes.  `path` is only ever passed by tests (the CPU
+    lane-emulation build of the same sources); the product always loads lib3bz_amd.so."""
+    path = path or default_path()
+    if not os.path.exists(path):
+        raise LibraryMissing(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % path)
+    L = C.CDLL(path)
+    vp, sz, u64p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)
+    L.tbz_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.tbz_ctx_destroy.argtypes = [vp]
+    L.tbz_ctx_destroy.restype = None
+    L.tbz_strerror.restype = C.c_char_p
+    L.tbz_strerror.argtypes = [C.c_int]
+    L.tbz_last_error.restype = C.c_char_p
+    L.tbz_last_error.argtypes = [vp]
+    L.tbz_inflate.argtypes = [vp, C.c_int, vp, sz, vp, sz, C.POINTER(Result)]
+    L.tbz_inflate_size.argtypes = [vp, C.c_int, vp, sz, C.POINTER(Result)]
+    L.tbz_inflate_batch.argtypes = [vp, C.c_int, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz),
+                                    C.POINTER(Result)]
+    L.tbz_inflate_device.argtypes = [vp, C.c_int, vp, sz, vp, sz, C.POINTER(Result)]
+    L.tbz_inflate_batch_device.argtypes = [vp, C.c_int, sz, vp, u64p, u64p, vp, u64p, u64p, C.POINTER(Result)]
+    L.tbz_adler32_device.argtypes = [vp, vp, sz, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32),
+                                     C.POINTER(C.c_uint32)]
+    L.tbz_crc32_device.argtypes = [vp, vp, sz, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.tbz_device_malloc.argtypes = [vp, sz, C.POINTER(vp)]
+    L.tbz_device_free.argtypes = [vp, vp]
+    L.tbz_memcpy_h2d.argtypes = [vp, vp, vp, sz]
+    L.tbz_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+    L.tbz_last_timings.argtypes = [vp, C.POINTER(Timings)]
+    for s in SYMBOLS:
+        getattr(L, s)  # AttributeError if the ABI is incomplete
+    return L

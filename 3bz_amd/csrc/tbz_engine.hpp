@@ -1,0 +1,764 @@
+// tbz_engine.hpp — host orchestration behind the C ABI of include/tbz_amd.h.
+//
+// One call = one pipeline over a batch of streams, all device-resident:
+//
+//   K0 scan markers ──> host: items ──> K1 huff_decode (one wave per item)
+//        ──> host: follow the landing chain, repair overshoots (K1 fix-up rounds), prefix-sum the
+//            segment sizes, form LZ77 groups, decide per-stream status
+//        ──> K2 lz77 (one wave per group) ──> K4/K5 checksum partials + combine ──> results
+//
+// The host part between K1 and K2 is control flow over a few records per segment (it reads no
+// stream octets and decodes nothing).  Correctness argument for the speculative markers: item 0 of
+// a stream starts at a true block boundary; an item is on the chain iff its predecessor on the
+// chain ENDED A BLOCK exactly at its start, so by induction every chained item starts at a true
+// block boundary and the concatenation of their tokens is exactly what a sequential decoder
+// (3bz's :block-end -> :start-of-block loop, deflate.lisp:719-722) would produce.  Markers that are
+// not on the chain are never used; an item that runs into a false marker mid-block is re-decoded
+// from that block's start by a fix-up item that ignores markers it crosses.
+#pragma once
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/tbz_amd.h"
+#include "tbz_kernels.hpp"
+
+namespace tbz {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace tbz
+
+struct tbz_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[10] = {};
+  std::string err;
+  tbz_timings tim{};
+  // device pools (grow-only)
+  tbz::DevBuf d_str_off, d_str_len, d_tile_first, d_tile_counts, d_tile_offsets, d_markers, d_items, d_res,
+      d_tok, d_segs, d_groups, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
+      d_out_stage;
+};
+
+namespace tbz {
+
+#define TBZ_HIP(call)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                         \
+      return TBZ_E_HIP;                                                                     \
+    }                                                                                       \
+  } while (0)
+
+static int ensure(tbz_ctx* ctx, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap && b.p) return 0;
+  if (b.p) TBZ_HIP(hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = bytes + bytes / 8 + 256;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    ctx->err = std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e);
+    b.p = nullptr;
+    return TBZ_E_NOMEM;
+  }
+  b.cap = want;
+  return 0;
+}
+template <class T>
+static int upload(tbz_ctx* ctx, DevBuf& b, const std::vector<T>& v) {
+  int r = ensure(ctx, b, std::max<size_t>(v.size() * sizeof(T), 16));
+  if (r) return r;
+  if (!v.empty()) TBZ_HIP(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  return 0;
+}
+
+// ---- CRC constant tables (host side of K5) ---------------------------------------------------
+static uint32_t h_mulmod(uint32_t a, uint32_t b) {
+  uint32_t p = 0;
+  for (int i = 0; i < 32; i++) {
+    if (a & (0x80000000u >> i)) p ^= b;
+    b = (b & 1) ? ((b >> 1) ^ 0xedb88320u) : (b >> 1);
+  }
+  return p;
+}
+static void build_crc_tables(std::vector<uint32_t>& t) {
+  t.assign(CRC_WORDS, 0);
+  for (uint32_t n = 0; n < 256; n++) {  // checksums.lisp:177-193
+    uint32_t c = n;
+    for (int k = 0; k < 8; k++) c = (c & 1) ? (0xedb88320u ^ (c >> 1)) : (c >> 1);
+    t[CRC_T + n] = c;
+  }
+  // x^(2^k)
+  uint32_t p = 0x40000000u;  // x^1
+  for (int k = 0; k < 64; k++) {
+    t[CRC_X2N + k] = p;
+    p = h_mulmod(p, p);
+  }
+  auto pow_x8 = [&](uint64_t nbytes) {
+    uint32_t r = 0x80000000u;
+    uint32_t k = 3;
+    while (nbytes) {
+      if (nbytes & 1) r = h_mulmod(t[CRC_X2N + (k & 63)], r);
+      nbytes >>= 1;
+      k++;
+    }
+    return r;
+  };
+  // advance-by-256-octets operator applied to each state byte
+  uint32_t z256 = pow_x8(256);
+  for (uint32_t b = 0; b < 4; b++)
+    for (uint32_t v = 0; v < 256; v++) t[CRC_K + b * 256 + v] = h_mulmod(z256, v << (8 * b));
+  for (uint32_t j = 0; j < 64; j++) t[CRC_LANE + j] = pow_x8(256 - 4 * j);
+}
+
+struct StreamPlan {
+  uint64_t in_off, in_len, out_off, out_cap;
+  uint32_t first_item, n_items;   // round-0 items of this stream: head + one per marker
+  uint32_t first_marker;          // index of the stream's first marker in the global list
+  // chain walk state
+  uint32_t cur_item;              // next item to consume (index into round-0 items) or fix-up slot
+  bool pending_fixup = false, done = false, next_continues = false;
+  uint64_t fix_start_bit = 0;
+  int32_t status = 0;             // final per-stream status once done
+  uint64_t total_out = 0;
+  uint64_t in_end_bit = 0;
+  uint32_t trailer0 = 0, trailer1 = 0, trailer_have = 0;
+  bool saw_final = false;
+  uint32_t seg_first = 0, seg_count = 0;
+};
+
+struct SegHost {
+  Seg seg;
+  uint32_t stream;
+  uint32_t deficit;
+  bool continues;  // must share the window with the previous segment (fix-up continuation)
+};
+
+static int record(tbz_ctx* ctx, int i) {
+  TBZ_HIP(hipEventRecord(ctx->ev[i], ctx->stream));
+  return 0;
+}
+static float elapsed(tbz_ctx* ctx, int a, int b) {
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, ctx->ev[a], ctx->ev[b]) != hipSuccess) return 0;
+  return ms;
+}
+
+// checksum of out[out_off .. +len) per stream on the device; kind 1 = adler32, 2 = crc32
+static int run_checksums(tbz_ctx* ctx, int kind, const void* d_out, const std::vector<uint64_t>& offs,
+                         const std::vector<uint64_t>& lens, const std::vector<uint32_t>& init,
+                         std::vector<uint32_t>& out) {
+  size_t n = offs.size();
+  std::vector<CkChunk> chunks;
+  std::vector<CkStream> cs(n);
+  for (size_t s = 0; s < n; s++) {
+    cs[s].first = (uint32_t)chunks.size();
+    for (uint64_t o = 0; o < lens[s]; o += CK_CHUNK) {
+      CkChunk c;
+      c.out_abs = offs[s] + o;
+      c.len = (uint32_t)std::min<uint64_t>(CK_CHUNK, lens[s] - o);
+      c.stream = (uint32_t)s;
+      chunks.push_back(c);
+    }
+    cs[s].count = (uint32_t)chunks.size() - cs[s].first;
+    cs[s].init0 = init[s];
+    cs[s].pad = 0;
+  }
+  int r;
+  if ((r = upload(ctx, ctx->d_ck_chunks, chunks))) return r;
+  if ((r = upload(ctx, ctx->d_ck_streams, cs))) return r;
+  if ((r = ensure(ctx, ctx->d_ck_parts, std::max<size_t>(chunks.size(), 1) * sizeof(CkPartial)))) return r;
+  if ((r = ensure(ctx, ctx->d_ck_out, std::max<size_t>(n, 1) * sizeof(uint32_t)))) return r;
+  if (kind == 1) {
+    if (!chunks.empty()) {
+      K4Params p{(const u8*)d_out, (const CkChunk*)ctx->d_ck_chunks.p, (CkPartial*)ctx->d_ck_parts.p,
+                 (u32)chunks.size()};
+      TBZ_LAUNCH(tbz_k4_adler_partial, chunks.size(), ctx->stream, p);
+    }
+    K4cParams c{(const CkChunk*)ctx->d_ck_chunks.p, (const CkPartial*)ctx->d_ck_parts.p,
+                (const CkStream*)ctx->d_ck_streams.p, (u32*)ctx->d_ck_out.p, (u32)n};
+    TBZ_LAUNCH(tbz_k4_adler_combine, n, ctx->stream, c);
+  } else {
+    if (!chunks.empty()) {
+      K5Params p{(const u8*)d_out, (const CkChunk*)ctx->d_ck_chunks.p, (CkPartial*)ctx->d_ck_parts.p,
+                 (const u32*)ctx->d_crc_tab.p, (u32)chunks.size()};
+      TBZ_LAUNCH(tbz_k5_crc_partial, chunks.size(), ctx->stream, p);
+    }
+    K5cParams c{(const CkChunk*)ctx->d_ck_chunks.p, (const CkPartial*)ctx->d_ck_parts.p,
+                (const CkStream*)ctx->d_ck_streams.p, (const u32*)ctx->d_crc_tab.p, (u32*)ctx->d_ck_out.p,
+                (u32)n};
+    TBZ_LAUNCH(tbz_k5_crc_combine, n, ctx->stream, c);
+  }
+  TBZ_HIP(hipGetLastError());
+  out.resize(n);
+  TBZ_HIP(hipMemcpyAsync(out.data(), ctx->d_ck_out.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  TBZ_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// the whole pipeline on device-resident buffers
+static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, const uint64_t* in_offs,
+                        const uint64_t* in_lens, void* d_out, const uint64_t* out_offs, const uint64_t* out_caps,
+                        tbz_result* results, bool size_only) {
+  if (!ctx || !results || (n && (!in_offs || !in_lens))) return TBZ_E_ARG;
+  if (format < 0 || format > 2) return TBZ_E_ARG;
+  if (!size_only && n && (!out_offs || !out_caps)) return TBZ_E_ARG;
+  TBZ_HIP(hipSetDevice(ctx->device));
+  ctx->tim = tbz_timings{};
+  for (size_t i = 0; i < n; i++) memset(&results[i], 0, sizeof(tbz_result));
+  if (n == 0) return 0;
+  if (n > 0x7fffffffu) return TBZ_E_ARG;
+  int r;
+
+  // ---------------------------------------------------------------- stream table + tiles
+  std::vector<StreamPlan> sp(n);
+  std::vector<uint64_t> h_off(n), h_len(n);
+  std::vector<uint32_t> tile_first(n + 1);
+  uint64_t in_extent = 0, tiles = 0;
+  for (size_t s = 0; s < n; s++) {
+    sp[s].in_off = in_offs[s];
+    sp[s].in_len = in_lens[s];
+    sp[s].out_off = size_only ? 0 : out_offs[s];
+    sp[s].out_cap = size_only ? ~0ull : out_caps[s];
+    h_off[s] = in_offs[s];
+    h_len[s] = in_lens[s];
+    in_extent = std::max(in_extent, in_offs[s] + in_lens[s]);
+    tile_first[s] = (uint32_t)tiles;
+    tiles += (in_lens[s] + SCAN_TILE - 1) / SCAN_TILE;
+    if (tiles > 0x7fffffffu) return TBZ_E_ARG;
+  }
+  tile_first[n] = (uint32_t)tiles;
+  if (in_extent && !d_in) return TBZ_E_ARG;
+
+  if ((r = record(ctx, 0))) return r;
+  // ---------------------------------------------------------------- K0: markers
+  std::vector<uint64_t> markers;
+  if (tiles) {
+    if ((r = upload(ctx, ctx->d_str_off, h_off))) return r;
+    if ((r = upload(ctx, ctx->d_str_len, h_len))) return r;
+    if ((r = upload(ctx, ctx->d_tile_first, tile_first))) return r;
+    if ((r = ensure(ctx, ctx->d_tile_counts, tiles * 4))) return r;
+    if ((r = ensure(ctx, ctx->d_tile_offsets, (tiles + 1) * 4))) return r;
+    K0Params k0{(const u8*)d_in, (const u64*)ctx->d_str_off.p, (const u64*)ctx->d_str_len.p,
+                (const u32*)ctx->d_tile_first.p, (u32)n, (u32)tiles, (u32*)ctx->d_tile_counts.p,
+                (u32*)ctx->d_tile_offsets.p, nullptr};
+    TBZ_LAUNCH(tbz_k0_scan_count, tiles, ctx->stream, k0);
+    TBZ_LAUNCH(tbz_k0_scan_offsets, 1, ctx->stream, k0);
+    uint32_t n_mark = 0;
+    TBZ_HIP(hipMemcpyAsync(&n_mark, (const uint32_t*)ctx->d_tile_offsets.p + tiles, 4, hipMemcpyDeviceToHost,
+                           ctx->stream));
+    TBZ_HIP(hipStreamSynchronize(ctx->stream));
+    if ((r = ensure(ctx, ctx->d_markers, std::max<size_t>((size_t)n_mark * 8, 16)))) return r;
+    if (n_mark) {
+      k0.markers = (u64*)ctx->d_markers.p;
+      TBZ_LAUNCH(tbz_k0_scan_emit, tiles, ctx->stream, k0);
+      markers.resize(n_mark);
+      TBZ_HIP(hipMemcpyAsync(markers.data(), ctx->d_markers.p, (size_t)n_mark * 8, hipMemcpyDeviceToHost,
+                             ctx->stream));
+      TBZ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    TBZ_HIP(hipGetLastError());
+  } else {
+    if ((r = ensure(ctx, ctx->d_markers, 16))) return r;
+  }
+  if ((r = record(ctx, 1))) return r;
+
+  // ---------------------------------------------------------------- items
+  // markers are globally sorted; streams may be given in any order, so bucket by binary search
+  std::vector<Item> items;
+  items.reserve(n + markers.size());
+  std::vector<uint32_t> item_marker;  // for round-0 items: index of the marker that is its limit (or ~0)
+  for (size_t s = 0; s < n; s++) {
+    StreamPlan& S = sp[s];
+    uint64_t b = S.in_off, e = S.in_off + S.in_len;
+    size_t m0 = std::upper_bound(markers.begin(), markers.end(), b) - markers.begin();
+    size_t m1 = std::lower_bound(markers.begin(), markers.end(), e) - markers.begin();
+    if (m1 < m0) m1 = m0;
+    S.first_item = (uint32_t)items.size();
+    S.first_marker = (uint32_t)m0;
+    S.n_items = (uint32_t)(1 + (m1 - m0));
+    for (size_t k = 0; k <= m1 - m0; k++) {
+      Item it;
+      it.start_bit = (k == 0 ? b : markers[m0 + k - 1]) * 8;
+      it.limit_bit = (m0 + k < m1) ? markers[m0 + k] * 8 : ~0ull;
+      it.end_byte = e;
+      it.stream = (uint32_t)s;
+      it.flags = ((uint32_t)format << ITEM_FMT_SHIFT) | (k == 0 ? ITEM_HEAD : 0u);
+      items.push_back(it);
+    }
+    S.cur_item = S.first_item;
+  }
+  // token pool: one u16 per input bit (K1 never writes more words than bits consumed)
+  if ((r = ensure(ctx, ctx->d_tok, (size_t)in_extent * 16 + 64))) return r;
+  if ((r = upload(ctx, ctx->d_items, items))) return r;
+  if ((r = ensure(ctx, ctx->d_res, items.size() * sizeof(SegResult)))) return r;
+  K1Params k1{(const u8*)d_in, (u16*)ctx->d_tok.p, (const Item*)ctx->d_items.p, (SegResult*)ctx->d_res.p,
+              (const u64*)ctx->d_markers.p, (u32)markers.size(), (u32)items.size()};
+  if ((r = record(ctx, 2))) return r;
+  TBZ_LAUNCH(tbz_k1_huff_decode, items.size(), ctx->stream, k1);
+  TBZ_HIP(hipGetLastError());
+  if ((r = record(ctx, 3))) return r;
+  ctx->tim.huff_launches = 1;
+  std::vector<SegResult> res(items.size());
+  TBZ_HIP(hipMemcpyAsync(res.data(), ctx->d_res.p, res.size() * sizeof(SegResult), hipMemcpyDeviceToHost,
+                         ctx->stream));
+  TBZ_HIP(hipStreamSynchronize(ctx->stream));
+  float huff_ms = elapsed(ctx, 2, 3);
+
+  // ---------------------------------------------------------------- chain walk (+ fix-up rounds)
+  std::vector<SegHost> segs;
+  segs.reserve(items.size());
+  std::vector<std::vector<SegHost>> per_stream(n);
+  auto consume = [&](StreamPlan& S, size_t s, const Item& it, const SegResult& q, bool is_fixup) {
+    SegHost h;
+    h.seg.tok_index = it.start_bit;
+    h.seg.tok_words = q.tok_words;
+    h.seg.out_bytes = q.out_bytes;
+    h.stream = (uint32_t)s;
+    h.deficit = q.max_deficit;
+    h.continues = S.next_continues;
+    S.next_continues = false;
+    if (q.tok_words || q.out_bytes) per_stream[s].push_back(h);
+    else if (h.continues) S.next_continues = true;  // nothing emitted: carry the flag forward
+    S.total_out += q.out_bytes;
+    ctx->tim.token_words += q.tok_words;
+    if (q.status == SEG_LANDED) {
+      uint32_t mk = is_fixup ? q.land_marker : 0;
+      if (is_fixup) S.cur_item = S.first_item + 1 + (mk - S.first_marker);
+      else S.cur_item += 1;
+      return;
+    }
+    if (q.status == SEG_FINAL) {
+      S.saw_final = true;
+      S.trailer0 = q.trailer0;
+      S.trailer1 = q.trailer1;
+      S.trailer_have = q.trailer_have;
+      S.in_end_bit = q.end_bit;
+      S.status = TBZ_FINISHED;
+      S.done = true;
+      return;
+    }
+    if (q.status == SEG_OVERSHOOT) {
+      S.pending_fixup = true;
+      S.fix_start_bit = q.end_bit;
+      S.next_continues = true;
+      return;
+    }
+    if (q.status == SEG_UNDERRUN) {
+      S.status = TBZ_INPUT_UNDERRUN;
+      S.in_end_bit = q.end_bit;
+      S.done = true;
+      return;
+    }
+    S.status = q.status < 0 ? q.status : TBZ_E_INTERNAL;
+    S.done = true;
+  };
+  for (size_t s = 0; s < n; s++) {
+    StreamPlan& S = sp[s];
+    while (!S.done && !S.pending_fixup) {
+      if (S.cur_item >= S.first_item + S.n_items) {  // cannot happen: the last item has no limit
+        S.status = TBZ_E_INTERNAL;
+        S.done = true;
+        break;
+      }
+      consume(S, s, items[S.cur_item], res[S.cur_item], false);
+    }
+  }
+  for (;;) {
+    std::vector<Item> fix;
+    std::vector<size_t> fix_stream;
+    for (size_t s = 0; s < n; s++)
+      if (sp[s].pending_fixup && !sp[s].done) {
+        Item it;
+        it.start_bit = sp[s].fix_start_bit;
+        it.limit_bit = ~0ull;
+        it.end_byte = sp[s].in_off + sp[s].in_len;
+        it.stream = (uint32_t)s;
+        it.flags = ((uint32_t)format << ITEM_FMT_SHIFT) | ITEM_FIXUP;
+        fix.push_back(it);
+        fix_stream.push_back(s);
+      }
+    if (fix.empty()) break;
+    ctx->tim.fixup_rounds++;
+    if ((r = upload(ctx, ctx->d_items, fix))) return r;
+    if ((r = ensure(ctx, ctx->d_res, fix.size() * sizeof(SegResult)))) return r;
+    K1Params kf = k1;
+    kf.items = (const Item*)ctx->d_items.p;
+    kf.res = (SegResult*)ctx->d_res.p;
+    kf.n_items = (u32)fix.size();
+    if ((r = record(ctx, 2))) return r;
+    TBZ_LAUNCH(tbz_k1_huff_decode, fix.size(), ctx->stream, kf);
+    TBZ_HIP(hipGetLastError());
+    if ((r = record(ctx, 3))) return r;
+    ctx->tim.huff_launches++;
+    std::vector<SegResult> fr(fix.size());
+    TBZ_HIP(hipMemcpyAsync(fr.data(), ctx->d_res.p, fr.size() * sizeof(SegResult), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    TBZ_HIP(hipStreamSynchronize(ctx->stream));
+    huff_ms += elapsed(ctx, 2, 3);
+    for (size_t k = 0; k < fix.size(); k++) {
+      size_t s = fix_stream[k];
+      StreamPlan& S = sp[s];
+      S.pending_fixup = false;
+      consume(S, s, fix[k], fr[k], true);
+      while (!S.done && !S.pending_fixup) {
+        if (S.cur_item >= S.first_item + S.n_items) {
+          S.status = TBZ_E_INTERNAL;
+          S.done = true;
+          break;
+        }
+        consume(S, s, items[S.cur_item], res[S.cur_item], false);
+      }
+    }
+  }
+  ctx->tim.huff_ms = huff_ms;
+
+  // ---------------------------------------------------------------- per-stream layout, groups, status
+  std::vector<Seg> h_segs;
+  std::vector<Group> h_groups;
+  for (size_t s = 0; s < n; s++) {
+    StreamPlan& S = sp[s];
+    tbz_result& R = results[s];
+    auto& v = per_stream[s];
+    uint64_t produced = 0;
+    int32_t status = S.status;
+    // history check (deflate.lisp:343-345): a match may not reach before the stream's first octet
+    for (auto& h : v) {
+      if (h.deficit && (uint64_t)h.deficit > produced && status >= 0) status = TBZ_E_DISTANCE;
+      produced += h.seg.out_bytes;
+    }
+    // 3bz decodes front to back: it reports overflow as soon as a token does not fit, before it
+    // could meet a later error / underrun
+    uint64_t cap = S.out_cap;
+    bool overflow = S.total_out > cap;
+    if (overflow) status = TBZ_OUTPUT_OVERFLOW;
+    R.status = status;
+    R.segments = (uint32_t)v.size();
+    R.out_total = S.total_out;
+    R.out_len = overflow ? cap : S.total_out;
+    R.in_consumed = S.saw_final ? (S.in_end_bit / 8 - S.in_off) : 0;
+    R.trailer_check = S.trailer0;
+    R.trailer_isize = S.trailer1;
+    if (S.saw_final) R.flags |= 2;
+    if (status < 0) {
+      R.out_len = 0;
+      continue;  // reference signals an error: no partial-result contract
+    }
+    if (size_only) continue;
+    // groups: a segment that needs history (or continues a repaired block) joins its predecessor
+    uint64_t o = 0;
+    S.seg_first = (uint32_t)h_segs.size();
+    for (size_t i = 0; i < v.size(); i++) {
+      if (o >= R.out_len) break;
+      bool join = i > 0 && (v[i].continues || v[i].deficit > 0);
+      if (!join) {
+        Group g;
+        g.out_abs = S.out_off + o;
+        g.out_end = S.out_off + R.out_len;
+        g.seg_first = (uint32_t)h_segs.size();
+        g.seg_count = 0;
+        h_groups.push_back(g);
+      }
+      h_groups.back().seg_count++;
+      h_segs.push_back(v[i].seg);
+      o += v[i].seg.out_bytes;
+    }
+    S.seg_count = (uint32_t)h_segs.size() - S.seg_first;
+  }
+  ctx->tim.n_segments = h_segs.size();
+  ctx->tim.n_groups = h_groups.size();
+
+  // ---------------------------------------------------------------- K2
+  if ((r = record(ctx, 4))) return r;
+  if (!size_only && !h_groups.empty()) {
+    if (!d_out) return TBZ_E_ARG;
+    if ((r = upload(ctx, ctx->d_segs, h_segs))) return r;
+    if ((r = upload(ctx, ctx->d_groups, h_groups))) return r;
+    K2Params k2{(const u16*)ctx->d_tok.p, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, (u8*)d_out,
+                (u32)h_groups.size()};
+    TBZ_LAUNCH(tbz_k2_lz77, h_groups.size(), ctx->stream, k2);
+    TBZ_HIP(hipGetLastError());
+  }
+  if ((r = record(ctx, 5))) return r;
+
+  // ---------------------------------------------------------------- K4 / K5 + trailer compare
+  if (!size_only && format != TBZ_FORMAT_DEFLATE) {
+    std::vector<uint64_t> co(n), cl(n);
+    std::vector<uint32_t> init(n), sums;
+    for (size_t s = 0; s < n; s++) {
+      co[s] = sp[s].out_off;
+      // update-checksum runs when finished or output-overflow (zlib.lisp:136-137, gzip.lisp:268-269)
+      bool want = results[s].status == TBZ_FINISHED || results[s].status == TBZ_OUTPUT_OVERFLOW;
+      cl[s] = want ? results[s].out_len : 0;
+      init[s] = format == TBZ_FORMAT_ZLIB ? 1u : 0u;  // s1=1,s2=0 (zlib.lisp:11-12) / crc 0 (gzip.lisp:28)
+    }
+    if ((r = run_checksums(ctx, format == TBZ_FORMAT_ZLIB ? 1 : 2, d_out, co, cl, init, sums))) return r;
+    for (size_t s = 0; s < n; s++) {
+      tbz_result& R = results[s];
+      if (format == TBZ_FORMAT_ZLIB) R.adler32 = sums[s];
+      else R.crc32 = sums[s];
+    }
+  } else {
+    TBZ_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  if ((r = record(ctx, 6))) return r;
+  TBZ_HIP(hipStreamSynchronize(ctx->stream));
+  for (size_t s = 0; s < n; s++) {
+    tbz_result& R = results[s];
+    StreamPlan& S = sp[s];
+    if (R.status != TBZ_FINISHED || format == TBZ_FORMAT_DEFLATE) continue;
+    if (format == TBZ_FORMAT_ZLIB) {
+      if (S.trailer_have < 2) R.status = TBZ_INPUT_UNDERRUN;  // zlib.lisp:81-86
+      else if (size_only) R.flags |= 0;
+      else if (S.trailer0 != R.adler32) { R.status = TBZ_E_ADLER32; R.out_len = 0; }
+      else R.flags |= 1;
+    } else {
+      if (S.trailer_have < 1) R.status = TBZ_INPUT_UNDERRUN;  // gzip.lisp:83-86
+      else if (!size_only && S.trailer0 != R.crc32) { R.status = TBZ_E_CRC32; R.out_len = 0; }
+      else if (S.trailer_have < 2) R.status = TBZ_INPUT_UNDERRUN;  // gzip.lisp:96-99
+      else if (!size_only) R.flags |= 1;
+    }
+  }
+  ctx->tim.scan_ms = elapsed(ctx, 0, 1);
+  ctx->tim.lz_ms = elapsed(ctx, 4, 5);
+  ctx->tim.cksum_ms = elapsed(ctx, 5, 6);
+  ctx->tim.total_ms = elapsed(ctx, 0, 6);
+  return 0;
+}
+
+}  // namespace tbz
+
+// ====================================================================================================
+// C ABI
+// ====================================================================================================
+extern "C" {
+
+int tbz_abi_version(void) { return TBZ_ABI_VERSION; }
+
+const char* tbz_strerror(int code) {
+  switch (code) {
+    case TBZ_FINISHED: return "finished";
+    case TBZ_INPUT_UNDERRUN: return "input underrun";
+    case TBZ_OUTPUT_OVERFLOW: return "output overflow";
+    case TBZ_E_BTYPE: return "reserved block type 3";
+    case TBZ_E_STORED_LEN: return "stored block LEN/NLEN mismatch";
+    case TBZ_E_OVERSUBSCRIBED: return "too many entries in huffman table";
+    case TBZ_E_INCOMPLETE: return "incomplete huffman table";
+    case TBZ_E_REPEAT_NO_PREV: return "tried to repeat length without previous length";
+    case TBZ_E_REPEAT_OVERRUN: return "code-length repeat runs past HLIT+HDIST";
+    case TBZ_E_INVALID_CODE: return "invalid huffman code";
+    case TBZ_E_DISTANCE: return "distance reaches before start of output (no window)";
+    case TBZ_E_ZLIB_HEADER: return "invalid zlib header";
+    case TBZ_E_ZLIB_DICT: return "preset dictionary not supported yet";
+    case TBZ_E_ADLER32: return "adler32 mismatch";
+    case TBZ_E_GZIP_MAGIC: return "bad gzip magic";
+    case TBZ_E_GZIP_METHOD: return "unknown gzip compression method";
+    case TBZ_E_GZIP_FLAGS: return "reserved gzip flag bits set";
+    case TBZ_E_GZIP_HCRC: return "gzip header crc mismatch";
+    case TBZ_E_CRC32: return "crc32 mismatch";
+    case TBZ_E_ARG: return "bad argument";
+    case TBZ_E_HIP: return "HIP runtime error";
+    case TBZ_E_NOMEM: return "out of device memory";
+    case TBZ_E_NO_DEVICE: return "no HIP device";
+    case TBZ_E_UNSUPPORTED: return "unsupported on the device path";
+    case TBZ_E_INTERNAL: return "internal error";
+  }
+  return "unknown";
+}
+
+int tbz_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int tbz_ctx_create(int device_id, tbz_ctx** out_ctx) {
+  if (!out_ctx) return TBZ_E_ARG;
+  *out_ctx = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return TBZ_E_NO_DEVICE;
+  if (device_id < 0 || device_id >= n) return TBZ_E_ARG;
+  tbz_ctx* ctx = new tbz_ctx();
+  ctx->device = device_id;
+  auto fail = [&](hipError_t e, const char* what) {
+    fprintf(stderr, "tbz_ctx_create: %s: %s\n", what, hipGetErrorString(e));
+    delete ctx;
+    return TBZ_E_HIP;
+  };
+  hipError_t e;
+  if ((e = hipSetDevice(device_id)) != hipSuccess) return fail(e, "hipSetDevice");
+  if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess) return fail(e, "hipStreamCreate");
+  for (auto& ev : ctx->ev)
+    if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
+  std::vector<uint32_t> t;
+  tbz::build_crc_tables(t);
+  if (tbz::ensure(ctx, ctx->d_crc_tab, t.size() * 4)) {
+    delete ctx;
+    return TBZ_E_NOMEM;
+  }
+  if ((e = hipMemcpy(ctx->d_crc_tab.p, t.data(), t.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
+    return fail(e, "hipMemcpy");
+  *out_ctx = ctx;
+  return 0;
+}
+
+void tbz_ctx_destroy(tbz_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  tbz::DevBuf* bufs[] = {&ctx->d_str_off, &ctx->d_str_len, &ctx->d_tile_first, &ctx->d_tile_counts,
+                         &ctx->d_tile_offsets, &ctx->d_markers, &ctx->d_items, &ctx->d_res, &ctx->d_tok,
+                         &ctx->d_segs, &ctx->d_groups, &ctx->d_ck_chunks, &ctx->d_ck_parts, &ctx->d_ck_streams,
+                         &ctx->d_ck_out, &ctx->d_crc_tab, &ctx->d_in_stage, &ctx->d_out_stage};
+  for (auto* b : bufs)
+    if (b->p) hipFree(b->p);
+  for (auto& ev : ctx->ev)
+    if (ev) hipEventDestroy(ev);
+  if (ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* tbz_last_error(const tbz_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+int tbz_last_timings(const tbz_ctx* ctx, tbz_timings* out) {
+  if (!ctx || !out) return TBZ_E_ARG;
+  *out = ctx->tim;
+  return 0;
+}
+
+int tbz_inflate_batch_device(tbz_ctx* ctx, int format, size_t n, const void* d_in_base, const uint64_t* in_offs,
+                             const uint64_t* in_lens, void* d_out_base, const uint64_t* out_offs,
+                             const uint64_t* out_caps, tbz_result* results) {
+  if (!ctx) return TBZ_E_ARG;
+  return tbz::inflate_core(ctx, format, n, d_in_base, in_offs, in_lens, d_out_base, out_offs, out_caps, results,
+                           false);
+}
+
+int tbz_inflate_device(tbz_ctx* ctx, int format, const void* d_in, size_t in_len, void* d_out, size_t out_cap,
+                       tbz_result* res) {
+  uint64_t io = 0, il = in_len, oo = 0, oc = out_cap;
+  return tbz_inflate_batch_device(ctx, format, 1, d_in, &io, &il, d_out, &oo, &oc, res);
+}
+
+static int stage_batch(tbz_ctx* ctx, int format, size_t n, const uint8_t* const* ins, const size_t* in_lens,
+                       uint8_t* const* outs, const size_t* out_caps, tbz_result* results, bool size_only) {
+  using namespace tbz;
+  if (!ctx || !results || (n && (!ins || !in_lens))) return TBZ_E_ARG;
+  if (!size_only && n && (!outs || !out_caps)) return TBZ_E_ARG;
+  TBZ_HIP(hipSetDevice(ctx->device));
+  std::vector<uint64_t> io(n), il(n), oo(n), oc(n);
+  uint64_t it = 0, ot = 0;
+  for (size_t i = 0; i < n; i++) {
+    io[i] = it;
+    il[i] = in_lens[i];
+    it += (in_lens[i] + 15) & ~15ull;
+    oo[i] = ot;
+    oc[i] = size_only ? 0 : out_caps[i];
+    ot += ((size_only ? 0 : out_caps[i]) + 15) & ~15ull;
+  }
+  int r;
+  if ((r = ensure(ctx, ctx->d_in_stage, it + 64))) return r;
+  if (!size_only && (r = ensure(ctx, ctx->d_out_stage, ot + 64))) return r;
+  for (size_t i = 0; i < n; i++)
+    if (in_lens[i]) {
+      if (!ins[i]) return TBZ_E_ARG;
+      TBZ_HIP(hipMemcpyAsync((uint8_t*)ctx->d_in_stage.p + io[i], ins[i], in_lens[i], hipMemcpyHostToDevice,
+                             ctx->stream));
+    }
+  r = inflate_core(ctx, format, n, ctx->d_in_stage.p, io.data(), il.data(), size_only ? nullptr : ctx->d_out_stage.p,
+                   oo.data(), oc.data(), results, size_only);
+  if (r) return r;
+  if (!size_only) {
+    for (size_t i = 0; i < n; i++)
+      if (results[i].status >= 0 && results[i].out_len) {
+        if (!outs[i]) return TBZ_E_ARG;
+        TBZ_HIP(hipMemcpyAsync(outs[i], (const uint8_t*)ctx->d_out_stage.p + oo[i], results[i].out_len,
+                               hipMemcpyDeviceToHost, ctx->stream));
+      }
+    TBZ_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return 0;
+}
+
+int tbz_inflate_batch(tbz_ctx* ctx, int format, size_t n, const uint8_t* const* ins, const size_t* in_lens,
+                      uint8_t* const* outs, const size_t* out_caps, tbz_result* results) {
+  return stage_batch(ctx, format, n, ins, in_lens, outs, out_caps, results, false);
+}
+
+int tbz_inflate(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap,
+                tbz_result* res) {
+  return stage_batch(ctx, format, 1, &in, &in_len, &out, &out_cap, res, false);
+}
+
+int tbz_inflate_size(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len, tbz_result* res) {
+  return stage_batch(ctx, format, 1, &in, &in_len, nullptr, nullptr, res, true);
+}
+
+int tbz_adler32_device(tbz_ctx* ctx, const void* d_buf, size_t len, uint32_t s1, uint32_t s2, uint32_t* out_s1,
+                       uint32_t* out_s2) {
+  using namespace tbz;
+  if (!ctx || !out_s1 || !out_s2 || (len && !d_buf)) return TBZ_E_ARG;
+  TBZ_HIP(hipSetDevice(ctx->device));
+  std::vector<uint64_t> o{0}, l{len};
+  std::vector<uint32_t> init{(s1 & 0xffff) | (s2 << 16)}, sums;
+  int r = run_checksums(ctx, 1, d_buf, o, l, init, sums);
+  if (r) return r;
+  *out_s1 = sums[0] & 0xffff;
+  *out_s2 = sums[0] >> 16;
+  return 0;
+}
+
+int tbz_crc32_device(tbz_ctx* ctx, const void* d_buf, size_t len, uint32_t crc, uint32_t* out_crc) {
+  using namespace tbz;
+  if (!ctx || !out_crc || (len && !d_buf)) return TBZ_E_ARG;
+  TBZ_HIP(hipSetDevice(ctx->device));
+  std::vector<uint64_t> o{0}, l{len};
+  std::vector<uint32_t> init{crc}, sums;
+  int r = run_checksums(ctx, 2, d_buf, o, l, init, sums);
+  if (r) return r;
+  *out_crc = sums[0];
+  return 0;
+}
+
+int tbz_device_malloc(tbz_ctx* ctx, size_t bytes, void** d_ptr) {
+  using namespace tbz;
+  if (!ctx || !d_ptr) return TBZ_E_ARG;
+  TBZ_HIP(hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 16);
+  if (e != hipSuccess) {
+    ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+    return TBZ_E_NOMEM;
+  }
+  return 0;
+}
+int tbz_device_free(tbz_ctx* ctx, void* d_ptr) {
+  using namespace tbz;
+  if (!ctx) return TBZ_E_ARG;
+  TBZ_HIP(hipSetDevice(ctx->device));
+  TBZ_HIP(hipFree(d_ptr));
+  return 0;
+}
+int tbz_memcpy_h2d(tbz_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+  using namespace tbz;
+  if (!ctx) return TBZ_E_ARG;
+  TBZ_HIP(hipSetDevice(ctx->device));
+  if (bytes) TBZ_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+int tbz_memcpy_d2h(tbz_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+  using namespace tbz;
+  if (!ctx) return TBZ_E_ARG;
+  TBZ_HIP(hipSetDevice(ctx->device));
+  if (bytes) TBZ_HIP(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // extern "C"

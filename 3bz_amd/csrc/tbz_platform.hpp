@@ -1,0 +1,66 @@
+// tbz_platform.hpp — the gfx950 flavour of the few primitives the kernels are written against.
+//
+// Every kernel in this engine is launched with 64-thread workgroups: one workgroup == one
+// CDNA4 wavefront.  That makes `__syncthreads()` a single-wave s_barrier (an LDS ordering
+// point, essentially free) and lets the cross-lane helpers below be plain wave intrinsics.
+//
+// tests/emu/ holds a second header of the same name that runs the identical kernel source on
+// the CPU (64 host threads per workgroup) under AddressSanitizer — GPU ASan is not available
+// on this pool.  That header is test infrastructure; the product is built from THIS file only.
+#ifndef TBZ_PLATFORM_HPP_INCLUDED
+#define TBZ_PLATFORM_HPP_INCLUDED
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#define TBZ_WAVE 64
+#define TBZ_DEV __device__ __forceinline__
+#define TBZ_DEV_NOINLINE __device__ __noinline__
+#define TBZ_KERNEL extern "C" __global__ __launch_bounds__(64)
+#define TBZ_SHARED __shared__
+#define TBZ_CONSTANT __constant__
+#define TBZ_RESTRICT __restrict__
+
+using u8 = uint8_t;
+using u16 = uint16_t;
+using u32 = uint32_t;
+using u64 = uint64_t;
+using i32 = int32_t;
+using i64 = int64_t;
+
+TBZ_DEV u32 tbz_lane() { return threadIdx.x; }
+TBZ_DEV u32 tbz_block() { return blockIdx.x; }
+TBZ_DEV u32 tbz_nblocks() { return gridDim.x; }
+TBZ_DEV void tbz_sync() { __syncthreads(); }
+TBZ_DEV u64 tbz_ballot(bool p) { return __ballot(p); }
+TBZ_DEV u32 tbz_shfl(u32 v, int src) { return (u32)__shfl((int)v, src, 64); }
+TBZ_DEV u32 tbz_shfl_up(u32 v, unsigned d) { return (u32)__shfl_up((int)v, d, 64); }
+TBZ_DEV u32 tbz_shfl_down(u32 v, unsigned d) { return (u32)__shfl_down((int)v, d, 64); }
+TBZ_DEV u32 tbz_shfl_xor(u32 v, int m) { return (u32)__shfl_xor((int)v, m, 64); }
+TBZ_DEV u64 tbz_shfl64(u64 v, int src) {
+  u32 lo = tbz_shfl((u32)v, src), hi = tbz_shfl((u32)(v >> 32), src);
+  return ((u64)hi << 32) | lo;
+}
+TBZ_DEV u64 tbz_shfl_up64(u64 v, unsigned d) {
+  u32 lo = tbz_shfl_up((u32)v, d), hi = tbz_shfl_up((u32)(v >> 32), d);
+  return ((u64)hi << 32) | lo;
+}
+TBZ_DEV u64 tbz_shfl_xor64(u64 v, int m) {
+  u32 lo = tbz_shfl_xor((u32)v, m), hi = tbz_shfl_xor((u32)(v >> 32), m);
+  return ((u64)hi << 32) | lo;
+}
+// value of the first active lane, as a wave-uniform (SGPR) value: lets the compiler keep the
+// sequential part of the decoders on the scalar unit
+TBZ_DEV u32 tbz_uniform(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+TBZ_DEV u64 tbz_uniform64(u64 v) {
+  return ((u64)tbz_uniform((u32)(v >> 32)) << 32) | tbz_uniform((u32)v);
+}
+TBZ_DEV u32 tbz_popc64(u64 v) { return (u32)__popcll(v); }
+TBZ_DEV u32 tbz_ffs64(u64 v) { return (u32)__ffsll((long long)v); }  // 1-based, 0 if none
+TBZ_DEV u32 tbz_brev32(u32 v) { return __brev(v); }
+TBZ_DEV u32 tbz_clz32(u32 v) { return (u32)__clz((int)v); }
+TBZ_DEV u32 tbz_atomic_add_lds(u32* p, u32 v) { return atomicAdd(p, v); }
+
+#define TBZ_LAUNCH(kernel, grid, stream, ...) \
+  hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3(64), 0, (stream), __VA_ARGS__)
+#endif  // TBZ_PLATFORM_HPP_INCLUDED

@@ -1,0 +1,98 @@
+// tbz_structs.hpp — plain records shared by host orchestration and kernels.
+//
+// Vocabulary (follows the reference's domain, not ML's):
+//   stream   one deflate/zlib/gzip stream = one (decompress-vector …) call of 3bz
+//   marker   a byte position p+4 where input[p..p+4) = 00 00 FF FF, i.e. the byte after an empty
+//            stored block (Z_SYNC_FLUSH / Z_FULL_FLUSH).  Speculative: the pattern may also occur
+//            inside compressed data; only a decode that ENDS a block exactly there proves it.
+//   item     one unit of K1 work: "decode blocks starting at this bit until you land on the next
+//            marker / hit the final block / fail"
+//   segment  a proven item: contiguous run of blocks between two proven block boundaries
+//   group    consecutive segments of one stream that must share one LZ77 window (the first needs no
+//            history; the rest reach back into their predecessors)
+//   token    u16 word: literal (0x00bb), or match head (0x8000 | len-3) followed by (dist-1)
+#pragma once
+#include <cstdint>
+
+namespace tbz {
+
+// ---- K1 item flags
+enum : uint32_t {
+  ITEM_HEAD = 1u,    // starts at the stream's first byte: parse the zlib/gzip container header first
+  ITEM_FIXUP = 2u,   // chain repair: ignore `limit_bit`, land on ANY marker (binary search)
+  ITEM_FMT_SHIFT = 8 // format in bits 8..9
+};
+
+// ---- K1 segment status (internal; mapped to tbz_result.status by the host)
+enum : int32_t {
+  SEG_LANDED = 1,     // ended a block exactly on a marker (index in land_marker)
+  SEG_FINAL = 2,      // decoded the BFINAL block (trailer fields valid)
+  SEG_OVERSHOOT = 3,  // crossed limit_bit mid-block: resume from end_bit (= start of that block)
+  SEG_UNDERRUN = 4    // input ended (deflate.lisp:114-120); out_bytes/tok_words cover complete tokens
+  // <0: TBZ_E_* error codes of include/tbz_amd.h
+};
+
+struct Item {
+  uint64_t start_bit;  // bit position relative to in_base
+  uint64_t limit_bit;  // first bit this item must not decode past without landing (next marker*8)
+  uint64_t end_byte;   // end of the stream (relative to in_base)
+  uint32_t stream;
+  uint32_t flags;
+};
+
+struct SegResult {
+  uint64_t end_bit;      // LANDED/FINAL: bit after the last block (FINAL: after the trailer);
+                         // OVERSHOOT: start of the block that crossed; UNDERRUN: start of the token/field
+  uint64_t out_bytes;    // octets the decoded tokens produce
+  uint64_t tok_words;    // u16 token words written at tok[start_bit ...]
+  int32_t status;
+  uint32_t max_deficit;  // max over matches of (distance - octets produced before it in THIS item), 0 if none
+  uint32_t trailer0;     // zlib: adler32 (already byte-swapped to host order); gzip: crc32
+  uint32_t trailer1;     // gzip: ISIZE
+  uint32_t trailer_have; // 0 none, 1 first word only (gzip crc without isize), 2 complete
+  uint32_t land_marker;  // LANDED: index of the marker landed on
+  uint64_t reserved;
+};
+
+struct Seg {
+  uint64_t tok_index;  // first token word (index into the u16 pool)
+  uint64_t tok_words;
+  uint64_t out_bytes;
+};
+
+struct Group {
+  uint64_t out_abs;    // byte offset in out_base of the group's first octet
+  uint64_t out_end;    // byte offset in out_base one past the last octet this group may store (clip)
+  uint32_t seg_first;
+  uint32_t seg_count;
+};
+
+// checksum chunk: `len` octets at out_base[out_abs..)
+struct CkChunk {
+  uint64_t out_abs;
+  uint32_t len;
+  uint32_t stream;
+};
+// per stream: chunks [first, first+count)
+struct CkStream {
+  uint32_t first;
+  uint32_t count;
+  uint32_t init0;  // adler: s1 | s2<<16 ; crc: finalised crc to chain from
+  uint32_t pad;
+};
+struct CkPartial {
+  uint32_t a;  // adler: sum of octets mod 65521        crc: raw (init 0) crc of the chunk
+  uint32_t b;  // adler: sum of (len-i)*octet mod 65521 crc: unused
+};
+
+constexpr uint32_t CK_CHUNK = 64u << 10;   // octets per checksum workgroup
+constexpr uint32_t SCAN_TILE = 16u << 10;  // octets per marker-scan workgroup
+
+// crc constants table layout (u32 words), filled by the host at context creation
+constexpr uint32_t CRC_T = 0;         // 256: classic reflected table (checksums.lisp:177-193)
+constexpr uint32_t CRC_K = 256;       // 4*256: advance-by-256-octets operator, split by state byte
+constexpr uint32_t CRC_X2N = 1280;    // 64: x^(2^k) mod P, k = 0..63 (reflected)
+constexpr uint32_t CRC_LANE = 1344;   // 64: x^(8*(256-4*lane)) mod P
+constexpr uint32_t CRC_WORDS = 1408;
+
+}  // namespace tbz

@@ -1,0 +1,160 @@
+/* tbz_amd.h — C ABI of the MI355X-native inflate engine that drops in behind 3bz's
+ * octet-vector path.
+ *
+ * The reference (3bz, Common Lisp) has NO plugin / FFI interface on this path: decode is
+ * plain Lisp functions and the only FFI it uses is cffi:mem-ref for pointer-context input
+ * (io-mmap.lisp:71,:84,:95,:108).  The drop-in boundary is therefore 3bz's exported Lisp
+ * API (package.lisp:13-27); this header is the C ABI a CFFI shim binds underneath it
+ * (lisp/3bz-amd.lisp).  Every entry point cites the reference interface it
+ * serves.
+ *
+ * Conventions
+ *   - plain pointers and sizes; no C++/torch types; no exceptions cross the boundary
+ *   - all buffers are BORROWED for the duration of the call, never retained
+ *     (3bz: caller owns input and output vectors, io-common.lisp:3-4, deflate.lisp:47-48)
+ *   - return value: 0 = call executed (look at tbz_result.status per stream),
+ *                   <0 = engine failure (HIP error, bad argument); tbz_strerror(code)
+ *   - tbz_result.status: TBZ_FINISHED / TBZ_INPUT_UNDERRUN / TBZ_OUTPUT_OVERFLOW are 3bz's
+ *     three status flags (api.lisp:67-72; they are flags, not conditions); <0 is a Lisp
+ *     `error`/`assert`/`ecase` failure of the reference (SURVEY §8a contract list)
+ *   - a context is not thread-safe (one in-flight call); several contexts may coexist
+ *     (3bz: one state must not be used concurrently)
+ */
+#ifndef TBZ_AMD_H
+#define TBZ_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TBZ_ABI_VERSION 1
+
+/* decompress-vector's :format keyword (api.lisp:31-34) */
+enum { TBZ_FORMAT_DEFLATE = 0, TBZ_FORMAT_ZLIB = 1, TBZ_FORMAT_GZIP = 2 };
+
+/* per-stream status */
+enum {
+  TBZ_FINISHED = 0,        /* (finished state)        api.lisp:67-68 */
+  TBZ_INPUT_UNDERRUN = 1,  /* (input-underrun state)  api.lisp:69-70, deflate.lisp:114-120 */
+  TBZ_OUTPUT_OVERFLOW = 2, /* (output-overflow state) api.lisp:71-72, deflate.lisp:121-137 */
+  /* reference errors (Lisp conditions) */
+  TBZ_E_BTYPE = -1,          /* deflate.lisp:521 */
+  TBZ_E_STORED_LEN = -2,     /* deflate.lisp:535 */
+  TBZ_E_OVERSUBSCRIBED = -3, /* huffman-tree.lisp:116-117 */
+  TBZ_E_INCOMPLETE = -4,     /* huffman-tree.lisp:119-122 */
+  TBZ_E_REPEAT_NO_PREV = -5, /* deflate.lisp:642-643 */
+  TBZ_E_REPEAT_OVERRUN = -6, /* deflate.lisp:645,:656 */
+  TBZ_E_INVALID_CODE = -7,   /* invalid node reached: deflate.lisp:438,:481 */
+  TBZ_E_DISTANCE = -8,       /* distance before start of output, no window: deflate.lisp:345 */
+  TBZ_E_ZLIB_HEADER = -9,    /* zlib.lisp:20-32 */
+  TBZ_E_ZLIB_DICT = -10,     /* zlib.lisp:33-35 */
+  TBZ_E_ADLER32 = -11,       /* zlib.lisp:95 */
+  TBZ_E_GZIP_MAGIC = -12,    /* gzip.lisp:120-121 */
+  TBZ_E_GZIP_METHOD = -13,   /* gzip.lisp:130-132 */
+  TBZ_E_GZIP_FLAGS = -14,    /* gzip.lisp:133-134 */
+  TBZ_E_GZIP_HCRC = -15,     /* gzip.lisp:255 */
+  TBZ_E_CRC32 = -16,         /* gzip.lisp:93 */
+  /* engine failures (also used as function return codes) */
+  TBZ_E_ARG = -100,
+  TBZ_E_HIP = -101,     /* a HIP runtime call failed; tbz_last_error(ctx) has the text */
+  TBZ_E_NOMEM = -102,
+  TBZ_E_NO_DEVICE = -103,
+  TBZ_E_UNSUPPORTED = -104, /* e.g. resuming a stream mid-way on the device path */
+  TBZ_E_INTERNAL = -105
+};
+
+/* what one call reports per stream: 64 bytes, also the record exchanged between ranks in
+ * the batched multi-GPU case */
+typedef struct tbz_result {
+  int32_t status;        /* TBZ_FINISHED / _INPUT_UNDERRUN / _OUTPUT_OVERFLOW or <0 */
+  uint32_t segments;     /* independent segments the stream was split into */
+  uint64_t out_len;      /* octets valid in the output = what `decompress` returns
+                            (deflate.lisp:730); for gzip/zlib early returns see api notes */
+  uint64_t out_total;    /* full decompressed size when known (== out_len when finished) */
+  uint64_t in_consumed;  /* input octets consumed including header and trailer */
+  uint32_t adler32;      /* computed over the output (zlib.lisp:97-102), s1 | s2<<16 */
+  uint32_t crc32;        /* computed over the output (gzip.lisp:80-81) */
+  uint32_t trailer_check;/* checksum stored in the stream trailer (0 if not reached) */
+  uint32_t trailer_isize;/* gzip ISIZE (read, never compared: gzip.lisp:95-106,:278) */
+  uint32_t flags;        /* bit0: checksum verified against trailer; bit1: BFINAL block decoded */
+  uint32_t reserved[3];
+} tbz_result;
+
+/* durations of the device stages of the LAST call, from HIP events recorded on the
+ * context's stream (ms).  bench.py builds roofline.achieved from these. */
+typedef struct tbz_timings {
+  float scan_ms;     /* K0 scan_markers (count + scan + emit) */
+  float huff_ms;     /* K1 huff_decode (all rounds) */
+  float lz_ms;       /* K2 lz77_resolve */
+  float cksum_ms;    /* K4/K5 checksum partials + combine */
+  float total_ms;    /* first kernel start .. last kernel end (device time, includes host chain gaps) */
+  uint32_t huff_launches;
+  uint32_t fixup_rounds;
+  uint64_t token_words; /* u16 token words written by K1 (traffic accounting) */
+  uint64_t n_segments;
+  uint64_t n_groups;
+} tbz_timings;
+
+typedef struct tbz_ctx tbz_ctx;
+
+/* ---- context ------------------------------------------------------------------------
+ * An engine handle bound to one HIP device: stream, scratch pools, constant tables.
+ * Replaces nothing in 3bz (a deflate-state is self-contained, deflate.lisp:4-62); it is
+ * the opaque handle the Lisp shim keeps in a special variable. */
+int tbz_ctx_create(int device_id, tbz_ctx** out_ctx);
+void tbz_ctx_destroy(tbz_ctx* ctx);
+int tbz_abi_version(void);
+const char* tbz_strerror(int code);
+const char* tbz_last_error(const tbz_ctx* ctx);
+int tbz_device_count(void);
+
+/* ---- one-shot decode, host buffers ---------------------------------------------------
+ * (decompress-vector compressed :format f :start s :end e :output out), api.lisp:23-47.
+ * `in`/`out` are host memory (pinned Lisp vectors via cffi:with-pointer-to-vector-data,
+ * the pattern of bench.lisp:61).  Status and count land in *res.  With a too-small `out`
+ * the buffer is filled with the correct prefix and status is TBZ_OUTPUT_OVERFLOW, exactly
+ * what the reference leaves behind (deflate.lisp:254-269,:693-697). */
+int tbz_inflate(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap,
+                tbz_result* res);
+
+/* Size query so the shim allocates exactly once instead of 3bz's 32 KiB-then-double loop
+ * (api.lisp:48-65).  out_total/status as tbz_inflate would report with unlimited space. */
+int tbz_inflate_size(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len, tbz_result* res);
+
+/* n independent streams in one call (BASELINE configs 3 and 4): stream i is
+ * (decompress-vector ins[i] :format f :output outs[i]). */
+int tbz_inflate_batch(tbz_ctx* ctx, int format, size_t n, const uint8_t* const* ins, const size_t* in_lens,
+                      uint8_t* const* outs, const size_t* out_caps, tbz_result* results);
+
+/* ---- one-shot decode, device-resident buffers ------------------------------------------
+ * Same contract with input and output already in HBM (what bench.py times; also the
+ * pointer-context analogue of with-octet-pointer, io-mmap.lisp:26-54).  Stream i reads
+ * d_in_base[in_offs[i] .. +in_lens[i]) and writes d_out_base[out_offs[i] .. +out_caps[i]). */
+int tbz_inflate_device(tbz_ctx* ctx, int format, const void* d_in, size_t in_len, void* d_out, size_t out_cap,
+                       tbz_result* res);
+int tbz_inflate_batch_device(tbz_ctx* ctx, int format, size_t n, const void* d_in_base, const uint64_t* in_offs,
+                             const uint64_t* in_lens, void* d_out_base, const uint64_t* out_offs,
+                             const uint64_t* out_caps, tbz_result* results);
+
+/* ---- checksums over device memory -------------------------------------------------------
+ * (adler32 buf end s1 s2) checksums.lisp:167-174 and (crc32/table buf end crc) :196-210,
+ * same chaining convention: pass the previous (s1,s2) / finalised crc back in. */
+int tbz_adler32_device(tbz_ctx* ctx, const void* d_buf, size_t len, uint32_t s1, uint32_t s2, uint32_t* out_s1,
+                       uint32_t* out_s2);
+int tbz_crc32_device(tbz_ctx* ctx, const void* d_buf, size_t len, uint32_t crc, uint32_t* out_crc);
+
+/* ---- device memory helpers for hosts without a HIP binding (the Lisp shim) --------------- */
+int tbz_device_malloc(tbz_ctx* ctx, size_t bytes, void** d_ptr);
+int tbz_device_free(tbz_ctx* ctx, void* d_ptr);
+int tbz_memcpy_h2d(tbz_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int tbz_memcpy_d2h(tbz_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+int tbz_last_timings(const tbz_ctx* ctx, tbz_timings* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,299 @@
+// tests/emu/tbz_platform.hpp — TEST INFRASTRUCTURE.  CPU emulation of the primitives in
+// 3bz_amd/csrc/tbz_platform.hpp so the UNCHANGED kernel + engine source can run under
+// AddressSanitizer/UBSan on the build host (GPU ASan is not available on this pool).
+//
+// A 64-thread workgroup is emulated by 64 cooperative fibers that hand over to each other at every
+// collective (ballot / shuffle / barrier); `__shared__` becomes function-local static storage (workgroups run
+// one after another); the HIP runtime calls the engine makes are mapped to malloc/memcpy.
+// Nothing here is linked into lib3bz_amd.so; the emulation library is only ever loaded by tests.
+#ifndef TBZ_PLATFORM_HPP_INCLUDED
+#define TBZ_PLATFORM_HPP_INCLUDED
+#include <pthread.h>
+#include <ucontext.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define TBZ_EMU 1
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/common_interface_defs.h>
+#endif
+#define TBZ_WAVE 64
+#define TBZ_DEV static inline
+#define TBZ_DEV_NOINLINE static
+#define TBZ_KERNEL static
+#define TBZ_SHARED static
+#define TBZ_CONSTANT static const
+#define TBZ_RESTRICT
+
+using u8 = uint8_t;
+using u16 = uint16_t;
+using u32 = uint32_t;
+using u64 = uint64_t;
+using i32 = int32_t;
+using i64 = int64_t;
+
+struct uint4 {
+  u32 x, y, z, w;
+};
+
+namespace tbz_emu {
+// 64 lanes = 64 cooperative fibers on ONE OS thread.  Every collective (barrier / ballot / shuffle)
+// is "yield to the next lane"; because convergent code makes every lane execute the same sequence
+// of collectives, one trip round the ring is exactly one barrier.  Deterministic, and ~100x faster
+// than 64 OS threads on a std::barrier.
+constexpr size_t kStack = 512 << 10;
+struct State {
+  ucontext_t main_ctx;
+  ucontext_t fib[64];
+  char* stacks[64] = {};
+  bool done[64];
+  u64 nbar[64];
+  int cur = 0;
+  int ndone = 0;
+  u32 block = 0, nblocks = 0;
+  const std::function<void()>* fn = nullptr;
+  volatile u64 slot[64];
+#if defined(__SANITIZE_ADDRESS__)
+  void* fake[65] = {};  // [64] = main
+  const void* main_bottom = nullptr;
+  size_t main_size = 0;
+#endif
+};
+inline State& st() {
+  static State s;
+  return s;
+}
+inline bool strict() {
+  static int s = -1;
+  if (s < 0) s = getenv("TBZ_EMU_STRICT") ? 1 : 0;
+  return s == 1;
+}
+#if defined(__SANITIZE_ADDRESS__)
+inline void san_start(int from, int to) {
+  State& s = st();
+  const void* bottom = to == 64 ? s.main_bottom : (const void*)s.stacks[to];
+  size_t size = to == 64 ? s.main_size : kStack;
+  __sanitizer_start_switch_fiber(&s.fake[from], bottom, size);
+}
+inline void san_finish(int me) {
+  State& s = st();
+  const void* ob;
+  size_t os;
+  __sanitizer_finish_switch_fiber(s.fake[me], &ob, &os);
+  if (me != 64 && !s.main_bottom) { /* learned lazily below */ }
+}
+#else
+inline void san_start(int, int) {}
+inline void san_finish(int) {}
+#endif
+inline void switch_to(int me, int nx) {  // me/nx in 0..63, or 64 for the launcher
+  State& s = st();
+  if (nx != 64) s.cur = nx;
+  san_start(me, nx);
+  swapcontext(me == 64 ? &s.main_ctx : &s.fib[me], nx == 64 ? &s.main_ctx : &s.fib[nx]);
+  san_finish(me);
+}
+inline int next_alive(int me) {
+  State& s = st();
+  for (int k = 1; k <= 64; k++) {
+    int c = (me + k) & 63;
+    if (!s.done[c]) return c;
+  }
+  return -1;
+}
+inline void barrier() {
+  State& s = st();
+  int me = s.cur;
+  s.nbar[me]++;
+  int nx = next_alive(me);
+  if (nx < 0 || nx == me) return;
+  switch_to(me, nx);
+}
+inline void trampoline() {
+  State& s = st();
+  san_finish(s.cur);
+  int me = s.cur;
+  (*s.fn)();
+  s.done[me] = true;
+  s.ndone++;
+  for (int i = 0; i < 64; i++)
+    if (s.done[i] && s.nbar[i] != s.nbar[me]) {
+      fprintf(stderr, "tbz_emu: lanes %d and %d executed a different number of collectives (%llu vs %llu): "
+              "divergent barrier / ballot / shuffle\n", i, me, (unsigned long long)s.nbar[i],
+              (unsigned long long)s.nbar[me]);
+      abort();
+    }
+  int nx = next_alive(me);
+  if (nx < 0) nx = 64;
+  else s.cur = nx;
+#if defined(__SANITIZE_ADDRESS__)
+  {
+    const void* bottom = nx == 64 ? s.main_bottom : (const void*)s.stacks[nx];
+    size_t size = nx == 64 ? s.main_size : kStack;
+    __sanitizer_start_switch_fiber(nullptr, bottom, size);  // this fiber is finished
+  }
+#endif
+  setcontext(nx == 64 ? &s.main_ctx : &s.fib[nx]);
+}
+// run kernel body `fn` for `grid` workgroups of 64 lanes, one workgroup after another
+inline void launch(u32 grid, const std::function<void()>& fn) {
+  if (grid == 0) return;
+  State& s = st();
+  for (int l = 0; l < 64; l++)
+    if (!s.stacks[l]) s.stacks[l] = (char*)malloc(kStack);
+#if defined(__SANITIZE_ADDRESS__)
+  if (!s.main_bottom) {
+    pthread_attr_t at;
+    pthread_getattr_np(pthread_self(), &at);
+    void* addr;
+    size_t sz;
+    pthread_attr_getstack(&at, &addr, &sz);
+    pthread_attr_destroy(&at);
+    s.main_bottom = addr;
+    s.main_size = sz;
+  }
+#endif
+  s.fn = &fn;
+  s.nblocks = grid;
+  for (u32 b = 0; b < grid; b++) {
+    s.block = b;
+    s.ndone = 0;
+    for (int l = 0; l < 64; l++) {
+      s.done[l] = false;
+      s.nbar[l] = 0;
+      getcontext(&s.fib[l]);
+      s.fib[l].uc_stack.ss_sp = s.stacks[l];
+      s.fib[l].uc_stack.ss_size = kStack;
+      s.fib[l].uc_link = nullptr;
+      makecontext(&s.fib[l], (void (*)())trampoline, 0);
+    }
+    switch_to(64, 0);
+  }
+  s.fn = nullptr;
+}
+inline u64 xchg(u64 v, u32 src) {
+  State& s = st();
+  s.slot[s.cur] = v;
+  barrier();
+  u64 r = s.slot[src & 63];
+  barrier();
+  return r;
+}
+}  // namespace tbz_emu
+
+TBZ_DEV u32 tbz_lane() { return (u32)tbz_emu::st().cur; }
+TBZ_DEV u32 tbz_block() { return tbz_emu::st().block; }
+TBZ_DEV u32 tbz_nblocks() { return tbz_emu::st().nblocks; }
+TBZ_DEV void tbz_sync() { tbz_emu::barrier(); }
+TBZ_DEV u64 tbz_ballot(bool p) {
+  tbz_emu::State& s = tbz_emu::st();
+  s.slot[s.cur] = p ? 1 : 0;
+  tbz_emu::barrier();
+  u64 m = 0;
+  for (int i = 0; i < 64; i++) m |= (u64)(s.slot[i] & 1) << i;
+  tbz_emu::barrier();
+  return m;
+}
+TBZ_DEV u64 tbz_shfl64(u64 v, int src) { return tbz_emu::xchg(v, (u32)src); }
+TBZ_DEV u64 tbz_shfl_up64(u64 v, unsigned d) {
+  u32 l = (u32)tbz_emu::st().cur;
+  return tbz_emu::xchg(v, l >= d ? l - d : l);
+}
+TBZ_DEV u64 tbz_shfl_xor64(u64 v, int m) { return tbz_emu::xchg(v, (u32)tbz_emu::st().cur ^ (u32)m); }
+TBZ_DEV u32 tbz_shfl(u32 v, int src) { return (u32)tbz_emu::xchg(v, (u32)src); }
+TBZ_DEV u32 tbz_shfl_up(u32 v, unsigned d) { return (u32)tbz_shfl_up64(v, d); }
+TBZ_DEV u32 tbz_shfl_down(u32 v, unsigned d) {
+  u32 l = (u32)tbz_emu::st().cur;
+  return (u32)tbz_emu::xchg(v, l + d < 64 ? l + d : l);
+}
+TBZ_DEV u32 tbz_shfl_xor(u32 v, int m) { return (u32)tbz_shfl_xor64(v, m); }
+// readfirstlane: on the GPU every lane gets lane 0's value.  In strict mode verify that the value
+// really is wave-uniform (costs two barriers per call, so off by default).
+TBZ_DEV u32 tbz_uniform(u32 v) {
+  if (tbz_emu::strict()) {
+    u32 r = (u32)tbz_emu::xchg(v, 0);
+    if (r != v) {
+      fprintf(stderr, "tbz_emu: non-uniform value passed to tbz_uniform (lane %u: %u vs lane 0: %u)\n",
+              (u32)tbz_emu::st().cur, v, r);
+      abort();
+    }
+    return r;
+  }
+  return v;
+}
+TBZ_DEV u64 tbz_uniform64(u64 v) { return v; }
+TBZ_DEV u32 tbz_popc64(u64 v) { return (u32)__builtin_popcountll(v); }
+TBZ_DEV u32 tbz_ffs64(u64 v) { return (u32)__builtin_ffsll((long long)v); }
+TBZ_DEV u32 tbz_brev32(u32 v) {
+  v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+  v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+  v = ((v >> 4) & 0x0f0f0f0fu) | ((v & 0x0f0f0f0fu) << 4);
+  return __builtin_bswap32(v);
+}
+TBZ_DEV u32 tbz_clz32(u32 v) { return v ? (u32)__builtin_clz(v) : 32; }
+TBZ_DEV u32 tbz_atomic_add_lds(u32* p, u32 v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+
+#define TBZ_LAUNCH(kernel, grid, stream, ...) \
+  tbz_emu::launch((u32)(grid), [&] { kernel(__VA_ARGS__); })
+
+// ---- the sliver of the HIP runtime the engine uses ----------------------------------------------
+typedef int hipError_t;
+typedef void* hipStream_t;
+struct tbz_emu_event {
+  std::chrono::steady_clock::time_point t;
+};
+typedef tbz_emu_event* hipEvent_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+static inline const char* hipGetErrorString(hipError_t) { return "emulated HIP error"; }
+static inline hipError_t hipGetDeviceCount(int* n) {
+  *n = 1;
+  return hipSuccess;
+}
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t n) {
+  *p = malloc(n ? n : 1);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+static inline hipError_t hipFree(void* p) {
+  free(p);
+  return hipSuccess;
+}
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
+  memcpy(d, s, n);
+  return hipSuccess;
+}
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
+  memcpy(d, s, n);
+  return hipSuccess;
+}
+static inline hipError_t hipStreamCreate(hipStream_t* s) {
+  *s = nullptr;
+  return hipSuccess;
+}
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) {
+  *e = new tbz_emu_event();
+  return hipSuccess;
+}
+static inline hipError_t hipEventDestroy(hipEvent_t e) {
+  delete e;
+  return hipSuccess;
+}
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+  e->t = std::chrono::steady_clock::now();
+  return hipSuccess;
+}
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+  return hipSuccess;
+}
+#endif  // TBZ_PLATFORM_HPP_INCLUDED

@@ -1,0 +1,341 @@
+"""Parity cases shared by the CPU (lane-emulator) and GPU (lib3bz_amd.so) test modules.
+
+Every case drives the product through the 3bz-shaped API (3bz_amd.api) and checks it against the
+oracle (oracle/tbz_oracle.c, itself pinned to the reference's vectors) on the same inputs:
+bit-exact octets, identical status flag, identical count, identical error class.
+"""
+import gzip as pygzip
+import hashlib
+import importlib
+import json
+import os
+import random
+import struct
+import zlib
+
+from oracle import oracle as O
+from tools import corpus as K
+
+T = importlib.import_module("3bz_amd")
+A = T.api
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FMT = {"deflate": 0, "zlib": 1, "gzip": 2}
+
+
+# ---------------------------------------------------------------------------------- helpers
+def oracle_oneshot(data, fmt, cap, start=0, end=None):
+    """what 3bz's (decompress ctx state) does on a fresh state with a `cap`-octet buffer"""
+    out = bytearray(cap)
+    st = O.State(FMT[fmt], out)
+    ctx = O.make_octet_vector_context(data, start=start, end=end)
+    try:
+        n = O.decompress(ctx, st)
+    except O.OracleError as e:
+        return {"flag": "error", "code": e.code, "ret": None, "bytes": b"", "offset": None}
+    flag = ("finished" if O.finished(st) else "underrun" if O.input_underrun(st)
+            else "overflow" if O.output_overflow(st) else "none")
+    return {"flag": flag, "code": 0, "ret": n, "bytes": bytes(out[:st.output_offset]), "offset": st.output_offset}
+
+
+def engine_oneshot(eng, data, fmt, cap, start=0, end=None):
+    out = bytearray(cap)
+    mk = {"deflate": A.make_deflate_state, "zlib": A.make_zlib_state, "gzip": A.make_gzip_state}[fmt]
+    st = mk(out)
+    ctx = A.make_octet_vector_context(data, start=start, end=end)
+    try:
+        n = A.decompress(ctx, st, engine=eng)
+    except A.ThreeBzError as e:
+        return {"flag": "error", "code": e.code, "ret": None, "bytes": b"", "offset": None}
+    flag = ("finished" if A.finished(st) else "underrun" if A.input_underrun(st)
+            else "overflow" if A.output_overflow(st) else "none")
+    return {"flag": flag, "code": 0, "ret": n, "bytes": bytes(out[:st.output_offset]), "offset": st.output_offset}
+
+
+def assert_same(eng, data, fmt, cap, start=0, end=None, what=""):
+    want = oracle_oneshot(data, fmt, cap, start, end)
+    got = engine_oneshot(eng, data, fmt, cap, start, end)
+    assert got["flag"] == want["flag"], (what, got["flag"], want["flag"], got["code"], want["code"])
+    if want["flag"] == "error":
+        assert got["code"] == want["code"], (what, got["code"], want["code"])
+        return want
+    assert got["offset"] == want["offset"], (what, got["offset"], want["offset"])
+    assert got["ret"] == want["ret"], (what, got["ret"], want["ret"])
+    assert got["bytes"] == want["bytes"], (what, "octets differ",
+                                           next((i for i, (a, b) in enumerate(zip(got["bytes"], want["bytes"]))
+                                                 if a != b), None))
+    return want
+
+
+# ---------------------------------------------------------------------------------- cases
+def case_known_answer_vectors(eng):
+    """deflate-test.lisp:69-302 through the state API; the device path must behave exactly like the
+    oracle on all 37 (which is stronger than the reference harness, deflate-test.lisp:66)."""
+    vs = json.load(open(os.path.join(GOLDEN, "deflate_vectors.json")))["vectors"]
+    assert len(vs) == 37
+    for v in vs:
+        data = bytes.fromhex(v["input_hex"])
+        w = assert_same(eng, data, "deflate", 1024, what="vector@%d" % v["line"])
+        if v["class"] == "ok":
+            assert w["flag"] == "finished" and w["bytes"].hex() == v["expected_hex"]
+        elif v["class"] == "eof":
+            assert w["flag"] == "underrun"
+        else:
+            assert w["flag"] in ("error", "underrun")
+
+
+def case_test_deflated(eng):
+    raw = open(os.path.join(GOLDEN, "test_deflated.bin"), "rb").read()
+    meta = json.load(open(os.path.join(GOLDEN, "test_deflated.json")))
+    buf, n = A.decompress_vector(raw, format="deflate", start=8, engine=eng)
+    assert n == meta["plain_len"] == int.from_bytes(raw[:8], "little")
+    assert hashlib.sha256(bytes(buf[:n])).hexdigest() == meta["sha256"]
+    out = bytearray(n)
+    _, n2 = A.decompress_vector(raw[8:], format="deflate", output=out, engine=eng)
+    assert n2 == n and hashlib.sha256(bytes(out)).hexdigest() == meta["sha256"]
+
+
+def _mixed_plain(n, seed):
+    rng = random.Random(seed)
+    parts = [K.enwik_like(n // 2, seed=seed), K.xorshift64star_bytes(n // 8, seed + 1), b"\x00" * (n // 8),
+             bytes(rng.choice(b"abc") for _ in range(n // 8)), K.enwik_like(n // 8, seed=seed + 2)]
+    return b"".join(parts)
+
+
+def case_containers_and_levels(eng, n=48_000):
+    for level in (0, 1, 6, 9):
+        plain = _mixed_plain(n, level + 10)
+        z = zlib.compress(plain, level)
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        raw = c.compress(plain) + c.flush()
+        g = pygzip.compress(plain, level, mtime=0)
+        for fmt, blob in (("zlib", z), ("deflate", raw), ("gzip", g)):
+            w = assert_same(eng, blob, fmt, len(plain), what="%s L%d" % (fmt, level))
+            assert w["flag"] == "finished" and w["bytes"] == plain
+            buf, cnt = A.decompress_vector(blob, format=fmt, engine=eng)
+            assert cnt == len(plain) and bytes(buf) == plain
+    # zlib strategies that change the block mix: fixed-Huffman only, Huffman-only, RLE
+    plain = _mixed_plain(n // 2, 77)
+    for strat in (zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+        c = zlib.compressobj(6, zlib.DEFLATED, 15, 8, strat)
+        z = c.compress(plain) + c.flush()
+        w = assert_same(eng, z, "zlib", len(plain), what="strategy %d" % strat)
+        assert w["bytes"] == plain
+    # gzip with every optional header field incl. header crc16 (gzip.lisp:180-255)
+    hdr = bytearray(b"\x1f\x8b\x08\x1e\x00\x00\x00\x00\x00\x03")
+    hdr += struct.pack("<H", 5) + b"extra" + b"name\x00" + b"comment\x00"
+    hdr += struct.pack("<H", zlib.crc32(bytes(hdr)) & 0xFFFF)
+    small = plain[:5000]
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    blob = bytes(hdr) + c.compress(small) + c.flush() + struct.pack("<II", zlib.crc32(small), len(small))
+    w = assert_same(eng, blob, "gzip", len(small), what="gzip optional fields")
+    assert w["bytes"] == small
+    bad = bytearray(blob)
+    bad[len(hdr) - 1] ^= 0x40
+    assert_same(eng, bytes(bad), "gzip", len(small), what="gzip bad header crc")
+    # :start / :end (api.lisp:23)
+    pad = b"\xAA" * 7 + z + b"\xBB" * 9
+    buf, cnt = A.decompress_vector(pad, format="zlib", start=7, end=7 + len(z), engine=eng)
+    assert bytes(buf[:cnt]) == plain
+
+
+def case_flush_streams(eng, n=96 << 10):
+    """config 2 shape: Z_FULL_FLUSH every 16 KiB -> independent segments found by the marker scan"""
+    s, p, a = K.zlib_flush_stream(n)
+    out = bytearray(n)
+    res = eng.inflate(s, 1, out)
+    assert res.status == 0 and res.out_len == n and bytes(out) == p
+    assert res.segments == n // 16384, res.segments
+    assert res.adler32 == a == res.trailer_check and (res.flags & 1)
+    assert res.in_consumed == len(s)
+    assert_same(eng, s, "zlib", n, what="full-flush stream")
+    # config 2b: Z_SYNC_FLUSH — history crosses segments, so they must share one window
+    s, p, a = K.zlib_flush_stream(n // 2, flush=zlib.Z_SYNC_FLUSH)
+    out = bytearray(len(p))
+    res = eng.inflate(s, 1, out)
+    assert res.status == 0 and bytes(out) == p
+    assert eng.timings().n_groups < eng.timings().n_segments
+    # small blocks: a flush every 1000 octets
+    s, p, a = K.zlib_flush_stream(40_000, block=1000)
+    assert_same(eng, s, "zlib", len(p), what="1000-octet flush blocks")
+
+
+def case_configs_1_3_5(eng, adv_total=160 << 10):
+    for two in (False, True):  # config 1: one / two stored blocks
+        s, p = K.config1_stream(two)
+        w = assert_same(eng, s, "deflate", len(p), what="config1")
+        assert w["bytes"] == p
+    # config 3: per-member parity through the batch entry point
+    blob, offs, plains = K.gzip_members(5, 24 << 10)
+    ends = offs[1:] + [len(blob)]
+    outs = [bytearray(len(p)) for p in plains]
+    res = eng.inflate_batch([blob[o:e] for o, e in zip(offs, ends)], 2, outs)
+    for r, o, p in zip(res, outs, plains):
+        assert r.status == 0 and bytes(o) == p and r.crc32 == zlib.crc32(p) and r.trailer_isize == len(p)
+    # 3bz decodes exactly ONE member and ignores what follows (gzip.lisp:277-286)
+    w = assert_same(eng, blob, "gzip", len(plains[0]), what="multi-member: first member only")
+    assert w["bytes"] == plains[0]
+    w = assert_same(eng, blob, "gzip", len(plains[2]), start=offs[2], what="member 2 via :start")
+    assert w["bytes"] == plains[2]
+    # config 5: adversarial LZ77, one sequential segment and with flush points
+    for ff in (0, 64 << 10):
+        s, p = K.adversarial_stream(total=adv_total, full_flush_every=ff)
+        w = assert_same(eng, s, "zlib", len(p), what="config5 ff=%d" % ff)
+        assert w["bytes"] == p
+
+
+def case_overflow_and_underrun(eng):
+    plain = K.enwik_like(60_000, seed=5)
+    s, p, a = K.zlib_flush_stream(48 << 10)
+    blobs = [("zlib", zlib.compress(plain, 6), plain), ("gzip", pygzip.compress(plain, 6, mtime=0), plain),
+             ("zlib", s, p), ("deflate", K.config1_stream(True)[0], K.config1_stream(True)[1])]
+    rng = random.Random(8)
+    for fmt, blob, pl in blobs:
+        # output too small: flag, count == cap, buffer holds the correct prefix (deflate.lisp:254-269,:693-697)
+        for cap in (0, 1, 2, 257, 258, 259, 4095, 16384, 16385, len(pl) - 1, len(pl)):
+            w = assert_same(eng, blob, fmt, cap, what="%s cap %d" % (fmt, cap))
+            assert w["flag"] == ("finished" if cap >= len(pl) else "overflow")
+        # truncated input at interesting cut points: header, mid-block, trailer
+        cuts = {0, 1, 2, 3, 5, 9, 10, 11, 17, len(blob) - 9, len(blob) - 8, len(blob) - 5, len(blob) - 4,
+                len(blob) - 3, len(blob) - 1}
+        cuts |= {rng.randrange(len(blob)) for _ in range(6)}
+        for c in sorted(x for x in cuts if 0 <= x < len(blob)):
+            w = assert_same(eng, blob, fmt, len(pl) + 10, end=c, what="%s cut %d" % (fmt, c))
+            assert w["flag"] in ("underrun", "error"), (fmt, c, w["flag"])
+    # decompress-vector's own errors (api.lisp:41-47,:55)
+    z = zlib.compress(plain)
+    for kw, code in (({"output": bytearray(10)}, -21), ({"end": len(z) - 3, "output": bytearray(len(plain))}, -20),
+                     ({"end": len(z) - 3}, -20)):
+        try:
+            A.decompress_vector(z, format="zlib", engine=eng, **kw)
+            raise AssertionError("expected an error")
+        except A.ThreeBzError as e:
+            assert e.code == code, (e.code, code)
+
+
+def case_errors(eng):
+    plain = K.enwik_like(20_000, seed=3)
+    z = zlib.compress(plain, 6)
+    g = pygzip.compress(plain, 6, mtime=0)
+    mut = []
+    mut.append(("zlib", z[:-1] + bytes([z[-1] ^ 1])))          # adler mismatch (zlib.lisp:95)
+    mut.append(("zlib", b"\x78\x9d" + z[2:]))                  # header check (zlib.lisp:20-24)
+    mut.append(("zlib", b"\x79\x9c" + z[2:]))                  # CM != 8
+    mut.append(("zlib", b"\x88\x1c" + z[2:]))                  # CINFO > 7
+    mut.append(("zlib", b"\x78\xbb" + z[2:]))                  # FDICT
+    mut.append(("gzip", b"\x1f\x8c" + g[2:]))                  # magic
+    mut.append(("gzip", g[:2] + b"\x09" + g[3:]))              # CM
+    mut.append(("gzip", g[:3] + b"\x20" + g[4:]))              # reserved flag
+    mut.append(("gzip", g[:-8] + bytes([g[-8] ^ 1]) + g[-7:]))  # crc mismatch (gzip.lisp:93)
+    mut.append(("gzip", g[:-1] + bytes([g[-1] ^ 1])))          # ISIZE is NOT checked (gzip.lisp:278)
+    mut.append(("deflate", b"\x07"))                           # BTYPE 3
+    mut.append(("deflate", bytes.fromhex("0104089fac")))       # LEN/NLEN
+    # distance before start of output, no window (deflate.lisp:345)
+    w = K.FixedHuffmanWriter()
+    w.begin_block(True)
+    w.literal(65)
+    w.match(3, 2)
+    w.end_block()
+    w.align()
+    mut.append(("deflate", w.getvalue()))
+    # bit flips inside compressed data: whatever 3bz does (error, underrun, garbage+adler error), we do
+    rng = random.Random(11)
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    raw = c.compress(plain) + c.flush()
+    for _ in range(12):
+        b = bytearray(raw)
+        i = rng.randrange(len(b))
+        b[i] ^= 1 << rng.randrange(8)
+        mut.append(("deflate", bytes(b)))
+    for fmt, blob in mut:
+        assert_same(eng, blob, fmt, len(plain) + 300, what="mutation %s %s" % (fmt, blob[:6].hex()))
+
+
+def case_false_markers(eng):
+    """00 00 FF FF inside payload bytes: every hit is a speculative marker the chain must reject"""
+    pat = b"\x00\x00\xff\xff"
+    payload = (pat * 50 + b"ABCD" + pat + b"x" * 100 + b"\x00" + pat + b"\xff\xff" + pat * 3) * 20
+    s = K.stored_stream(payload, max_block=1000)  # stored blocks: the pattern survives verbatim
+    w = assert_same(eng, s, "deflate", len(payload), what="false markers in stored blocks")
+    assert w["bytes"] == payload
+    res = eng.inflate(s, 0, bytearray(len(payload)))
+    assert res.status == 0 and eng.timings().fixup_rounds >= 1
+    # a real flush stream whose plaintext is full of the pattern, level 0 (stored) and level 6
+    plain = (pat * 10 + K.enwik_like(3000, 9)) * 12
+    for level in (0, 6):
+        c = zlib.compressobj(level, zlib.DEFLATED, 15)
+        blob = b""
+        for i in range(0, len(plain), 5000):
+            blob += c.compress(plain[i:i + 5000]) + c.flush(zlib.Z_FULL_FLUSH)
+        blob += c.flush()
+        w = assert_same(eng, blob, "zlib", len(plain), what="pattern-rich flush stream L%d" % level)
+        assert w["bytes"] == plain
+    # pattern straddling the end of input / right at the end
+    for tail in (pat, pat[:3], b"\x00" + pat):
+        blob = K.stored_stream(b"hello" + tail)
+        assert_same(eng, blob, "deflate", 64, what="marker at the very end")
+
+
+def case_device_buffers(eng, n=64 << 10):
+    """device-resident entry points with unaligned bases and a multi-stream batch"""
+    s, p, a = K.zlib_flush_stream(n)
+    for mis_in, mis_out in ((0, 0), (1, 3), (3, 1), (2, 15), (5, 16)):
+        d_in = eng.malloc(len(s) + 64)
+        d_out = eng.malloc(n + 64)
+        eng.h2d(d_in + mis_in, s)
+        res = eng.inflate_device(d_in + mis_in, len(s), d_out + mis_out, n, 1)
+        got = bytearray(n)
+        eng.d2h(got, d_out + mis_out)
+        eng.free(d_in)
+        eng.free(d_out)
+        assert res.status == 0 and res.out_len == n and bytes(got) == p, (mis_in, mis_out, res.status)
+        assert res.adler32 == a
+    # batch: three streams of different formats' worth of data at odd offsets in one buffer
+    plains = [K.enwik_like(20_000, 21), K.enwik_like(7_777, 22), b"", K.enwik_like(33_333, 23)]
+    blobs = [zlib.compress(x, 6) for x in plains]
+    in_offs, pos = [], 3
+    for b in blobs:
+        in_offs.append(pos)
+        pos += len(b) + 5
+    out_offs, opos = [], 1
+    for x in plains:
+        out_offs.append(opos)
+        opos += len(x) + 7
+    d_in = eng.malloc(pos + 64)
+    d_out = eng.malloc(opos + 64)
+    for o, b in zip(in_offs, blobs):
+        eng.h2d(d_in + o, b)
+    res = eng.inflate_batch_device(d_in, in_offs, [len(b) for b in blobs], d_out, out_offs,
+                                   [len(x) for x in plains], 1)
+    whole = bytearray(opos)
+    eng.d2h(whole, d_out)
+    eng.free(d_in)
+    eng.free(d_out)
+    for r, o, x in zip(res, out_offs, plains):
+        assert r.status == 0 and r.out_len == len(x) and bytes(whole[o:o + len(x)]) == x
+        assert r.adler32 == zlib.adler32(x)
+
+
+def case_checksum_kernels(eng):
+    """K4/K5 against the oracle's adler32/ub64 and crc32/table incl. the chaining convention"""
+    rng = random.Random(5)
+    base = bytes(rng.getrandbits(8) for _ in range(70_000)) + b"\xff" * 70_000
+    for n in (0, 1, 3, 4, 255, 256, 257, 1023, 65535, 65536, 65537, 131072 + 5, len(base)):
+        for mis in (0, 1, 7):
+            if n + mis > len(base):
+                continue
+            d = eng.malloc(n + 64)
+            buf = base[mis:mis + n]
+            eng.h2d(d + mis, buf)
+            s1, s2 = eng.adler32_device(d + mis, n)
+            assert (s1, s2) == O.adler32(buf), (n, mis)
+            assert eng.crc32_device(d + mis, n) == O.crc32(buf), (n, mis)
+            # chaining (zlib.lisp:97-102, gzip.lisp:80-81)
+            c1, c2 = eng.adler32_device(d + mis, n, 12345, 54321)
+            assert (c1, c2) == O.adler32(buf, 12345, 54321)
+            assert eng.crc32_device(d + mis, n, 0xDEADBEEF) == O.crc32(buf, 0xDEADBEEF)
+            eng.free(d)
+
+
+ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,
+             case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_device_buffers,
+             case_checksum_kernels]

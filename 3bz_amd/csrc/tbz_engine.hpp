@@ -42,7 +42,7 @@ struct tbz_ctx {
   tbz_timings tim{};
   // device pools (grow-only)
   tbz::DevBuf d_str_off, d_str_len, d_tile_first, d_tile_counts, d_tile_offsets, d_markers, d_items, d_res,
-      d_tok, d_segs, d_groups, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
+      d_tok, d_scratch, d_segs, d_groups, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
       d_out_stage;
 };
 
@@ -300,10 +300,18 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   if ((r = ensure(ctx, ctx->d_tok, (size_t)in_extent * 16 + 64))) return r;
   if ((r = upload(ctx, ctx->d_items, items))) return r;
   if ((r = ensure(ctx, ctx->d_res, items.size() * sizeof(SegResult)))) return r;
+  // one lane per item; with few items use fewer lanes per workgroup so that every CU gets work
+  auto items_per_wg = [](size_t n_it) {
+    u32 ipw = 64;
+    while (ipw > 1 && n_it / ipw < 512) ipw >>= 1;
+    return ipw;
+  };
+  if ((r = ensure(ctx, ctx->d_scratch, items.size() * (size_t)K1_SCRATCH))) return r;
   K1Params k1{(const u8*)d_in, (u16*)ctx->d_tok.p, (const Item*)ctx->d_items.p, (SegResult*)ctx->d_res.p,
-              (const u64*)ctx->d_markers.p, (u32)markers.size(), (u32)items.size()};
+              (const u64*)ctx->d_markers.p, (u8*)ctx->d_scratch.p, (u32)markers.size(), (u32)items.size(),
+              items_per_wg(items.size())};
   if ((r = record(ctx, 2))) return r;
-  TBZ_LAUNCH(tbz_k1_huff_decode, items.size(), ctx->stream, k1);
+  TBZ_LAUNCH(tbz_k1_huff_decode, (items.size() + k1.items_per_wg - 1) / k1.items_per_wg, ctx->stream, k1);
   TBZ_HIP(hipGetLastError());
   if ((r = record(ctx, 3))) return r;
   ctx->tim.huff_launches = 1;
@@ -394,8 +402,9 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     kf.items = (const Item*)ctx->d_items.p;
     kf.res = (SegResult*)ctx->d_res.p;
     kf.n_items = (u32)fix.size();
+    kf.items_per_wg = items_per_wg(fix.size());
     if ((r = record(ctx, 2))) return r;
-    TBZ_LAUNCH(tbz_k1_huff_decode, fix.size(), ctx->stream, kf);
+    TBZ_LAUNCH(tbz_k1_huff_decode, (fix.size() + kf.items_per_wg - 1) / kf.items_per_wg, ctx->stream, kf);
     TBZ_HIP(hipGetLastError());
     if ((r = record(ctx, 3))) return r;
     ctx->tim.huff_launches++;
@@ -482,8 +491,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if (!d_out) return TBZ_E_ARG;
     if ((r = upload(ctx, ctx->d_segs, h_segs))) return r;
     if ((r = upload(ctx, ctx->d_groups, h_groups))) return r;
-    K2Params k2{(const u16*)ctx->d_tok.p, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, (u8*)d_out,
-                (u32)h_groups.size()};
+    K2Params k2{(const u16*)ctx->d_tok.p, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p,
+                (const u8*)d_in, (u8*)d_out, (u32)h_groups.size()};
     TBZ_LAUNCH(tbz_k2_lz77, h_groups.size(), ctx->stream, k2);
     TBZ_HIP(hipGetLastError());
   }
@@ -615,7 +624,7 @@ void tbz_ctx_destroy(tbz_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   tbz::DevBuf* bufs[] = {&ctx->d_str_off, &ctx->d_str_len, &ctx->d_tile_first, &ctx->d_tile_counts,
-                         &ctx->d_tile_offsets, &ctx->d_markers, &ctx->d_items, &ctx->d_res, &ctx->d_tok,
+                         &ctx->d_tile_offsets, &ctx->d_markers, &ctx->d_items, &ctx->d_res, &ctx->d_tok, &ctx->d_scratch,
                          &ctx->d_segs, &ctx->d_groups, &ctx->d_ck_chunks, &ctx->d_ck_parts, &ctx->d_ck_streams,
                          &ctx->d_ck_out, &ctx->d_crc_tab, &ctx->d_in_stage, &ctx->d_out_stage};
   for (auto* b : bufs)

@@ -8,12 +8,14 @@
 //         find 00 00 FF FF flush markers (candidate independent-segment starts), coalesced reads,
 //         wave prefix-sums for an ordered compaction.
 //   K1  tbz_k1_huff_decode
-//         one wave per item: bit reader + dynamic-header parse + LDS-resident lookup tables
-//         (replaces deflate.lisp:518-702 and huffman-tree.lisp:99-218).  Emits u16 tokens, counts
-//         output octets, reports where it landed.  Needs no history, so every item is independent.
+//         one LANE per item (64 independent decoders per wave): bit reader + dynamic-header parse +
+//         lane-interleaved LDS lookup tables (replaces deflate.lisp:518-702 and
+//         huffman-tree.lisp:99-218).  Emits u16 tokens, counts output octets, reports where it
+//         landed.  Needs no history, so every item is independent.
 //   K2  tbz_k2_lz77
-//         one wave per group: token stream -> 36 KiB LDS ring (32 KiB history + one batch span) ->
-//         16-byte coalesced HBM stores (replaces copy-history / out-byte, deflate.lisp:233-359).
+//         one wave per group: token stream -> 36 KiB LDS ring (32 KiB history + one batch span),
+//         matches resolved lane-parallel in rounds -> 16-byte coalesced HBM stores (replaces
+//         copy-history / out-byte / :copy-block, deflate.lisp:233-359,:538-573).
 //   K4  tbz_k4_adler_partial / tbz_k4_adler_combine   (checksums.lisp:18-62)
 //   K5  tbz_k5_crc_partial / tbz_k5_crc_combine       (checksums.lisp:177-210)
 #pragma once
@@ -32,15 +34,7 @@ constexpr i32 E_BTYPE = -1, E_STORED_LEN = -2, E_OVERSUB = -3, E_INCOMPLETE = -4
 // ------------------------------------------------------------------------------------------------
 // small wave helpers
 // ------------------------------------------------------------------------------------------------
-TBZ_DEV u32 wave_incl_scan_u32(u32 v) {
-  const u32 lane = tbz_lane();
-#pragma unroll
-  for (u32 d = 1; d < 64; d <<= 1) {
-    u32 t = tbz_shfl_up(v, d);
-    if (lane >= d) v += t;
-  }
-  return v;
-}
+TBZ_DEV u32 wave_incl_scan_u32(u32 v) { return tbz_wave_incl_scan_u32(v); }
 TBZ_DEV u64 wave_incl_scan_u64(u64 v) {
   const u32 lane = tbz_lane();
 #pragma unroll
@@ -187,166 +181,66 @@ TBZ_KERNEL void tbz_k0_scan_emit(K0Params P) {
 }
 
 // ================================================================================================
-// K1 — Huffman decode to tokens
+// K1 — Huffman decode to tokens, ONE LANE PER ITEM (64 independent decoders per wavefront).
+//
+// Why lane-per-item: symbol decode is a serial dependent chain (lookup -> shift -> lookup), so one
+// decoder can use one lane.  A first version ran one decoder per WAVE; the compiler (correctly)
+// scalarised it onto the CU's single scalar ALU and the kernel became SALU-bound at ~1700 cycles
+// per token (profiles/r01_v1_*).  Here every lane of the 4 SIMDs' VALUs decodes its own item:
+//   - fast lookup tables live in LDS, LANE-INTERLEAVED: entry i of lane l is element [i][l], so the
+//     bank is a function of the lane only and 64 random lookups never conflict by index
+//   - lit/len: 9-bit root (512 x u16 per lane), distance: 6-bit root (64 x u16 per lane);
+//     longer codes take the canonical path (limits held in registers, sorted symbols in a per-item
+//     global scratch that stays in L2)
+//   - the compressed bitstream is read through a 96-bit register window per lane, one aligned
+//     32-bit word fetched a full window ahead of use
+//   - tokens are stored straight to the item's token region (consecutive u16 per lane; L2 merges)
+// Replaces deflate.lisp:518-702 + huffman-tree.lisp:99-218 (same acceptance rules and errors).
 // ================================================================================================
 
-// RFC 1951 tables (restated natively; the reference keeps them merged in constants.lisp:41-61)
-TBZ_CONSTANT u16 c_len_base[32] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59,
-                                   67, 83, 99, 115, 131, 163, 195, 227, 258, 0, 0, 0};
-TBZ_CONSTANT u8 c_len_extra[32] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3,
-                                   4, 4, 4, 4, 5, 5, 5, 5, 0, 0, 0, 0};
-TBZ_CONSTANT u16 c_dist_base[32] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769,
-                                    1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577, 0, 0};
-TBZ_CONSTANT u8 c_dist_extra[32] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8,
-                                    9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 0, 0};
 TBZ_CONSTANT u8 c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-// lookup-table entry (u32), one flat root table per alphabet + canonical fallback for long codes:
-//   [3:0]  code length L          [7:4]  extra-bit count X      [9:8] kind
-//   [12]   "long code" flag (kind = SPECIAL): the code is longer than the root index
-//   [31:16] value: literal octet / length base / distance base / code-length symbol
-constexpr u32 K_LIT = 0, K_BASE = 1, K_EOB = 2, K_SPECIAL = 3;
-constexpr u32 ENTRY_INVALID = K_SPECIAL << 8;                 // unassigned bit pattern (hole in an incomplete code)
-constexpr u32 ENTRY_LONG = (K_SPECIAL << 8) | (1u << 12);     // code longer than the root index
-constexpr u32 ENTRY_BADSYM = (K_SPECIAL << 8) | (1u << 13);   // | L: a coded symbol that may not be used
-constexpr int ROOT_LIT = 10, ROOT_DIST = 8, ROOT_CL = 7;
-enum { ALPHA_LITLEN = 0, ALPHA_DIST = 1, ALPHA_CL = 2 };
+constexpr int FAST_LIT = 9, FAST_DIST = 6, FAST_CL = 7;
+// u16 fast-table entry: [3:0] code length L (0 = special), [15:4] symbol.
+//   L = 0, symbol 0 : unassigned pattern (hole of an incomplete code)      -> invalid
+//   L = 0, symbol 1 : code longer than the root index                       -> canonical path
+constexpr u32 FE_HOLE = 0x0000, FE_LONG = 0x0010;
 
-struct CanonMeta {  // per alphabet, for the long-code fallback
-  u16 first[16];    // first canonical code of each length
-  u16 count[16];
-  u16 offs[16];     // index of the first symbol of each length in `sorted`
-  u32 min_len;      // shortest code length = width of the reference's root table (huffman-tree.lisp:144)
+// token words (u16):
+//   0x00bb                      literal octet
+//   0x8000 | (len-3)            match head, followed by  (dist-1)            (bit 15 clear)
+//   0xC000 | (n & 0x3fff)       stored-run head: n octets copied verbatim from the input, followed by
+//                               (n>>14) | (src&0x1fff)<<2 , (src>>13)&0x7fff , (src>>28)&0x7fff
+// payload words always have bit 15 clear, so a word with bit 15 set is always a head.
+constexpr u32 TOK_MATCH = 0x8000u, TOK_STORED = 0xC000u;
+
+constexpr u32 K1_SCRATCH = 1024;  // octets of global scratch per item: lens[320] | sorted_lit u16[288] | sorted_dist u16[32] | spare
+constexpr u32 K1_SC_LENS = 0, K1_SC_SLIT = 320, K1_SC_SDIST = 896, K1_SC_SCL = 960;
+
+struct K1Lds {
+  u16 lit[1 << FAST_LIT][64];    // 64 KiB (also hosts the 7-bit code-length-code table while a header is parsed)
+  u16 dist[1 << FAST_DIST][64];  // 8 KiB
+  u16 tmp[32][64];               // 4 KiB: per-lane counters while a table is built
 };
 
-TBZ_DEV u32 make_entry(int alpha, u32 sym, u32 len) {
-  if (alpha == ALPHA_LITLEN) {
-    if (sym < 256) return (sym << 16) | (K_LIT << 8) | len;
-    if (sym == 256) return (K_EOB << 8) | len;
-    if (sym <= 285) {
-      u32 k = sym - 257;
-      return ((u32)c_len_base[k] << 16) | (K_BASE << 8) | ((u32)c_len_extra[k] << 4) | len;
-    }
-    return ENTRY_BADSYM | len;  // 286/287 take part in the code but may not be used (huffman-tree.lisp:176-177)
-  }
-  if (alpha == ALPHA_DIST) {
-    if (sym <= 29) return ((u32)c_dist_base[sym] << 16) | (K_BASE << 8) | ((u32)c_dist_extra[sym] << 4) | len;
-    return ENTRY_BADSYM | len;  // 30/31 (huffman-tree.lisp:172-175)
-  }
-  return (sym << 16) | (K_BASE << 8) | len;
-}
+struct K1Params {
+  const u8* in_base;
+  u16* tok;       // token pool: item tokens start at tok[item.start_bit]; words written never exceed bits consumed
+  const Item* items;
+  SegResult* res;
+  const u64* markers;
+  u8* scratch;    // n_items * K1_SCRATCH octets
+  u32 n_markers;
+  u32 n_items;
+  u32 items_per_wg;  // 1..64: lanes >= items_per_wg idle (used to spread few large items over all CUs)
+};
 
-// Wave-parallel canonical-Huffman table build.  `lens` (LDS) holds n code lengths 0..15.
-// Same acceptance rules as build-tree-part (huffman-tree.lisp:112-122): over-subscribed -> error;
-// incomplete -> error unless at most one symbol is coded; all-zero -> table of INVALID entries.
-// All lanes must call this together; the return value is wave-uniform.
-template <int ROOT>
-TBZ_DEV i32 build_table(const u8* lens, u32 n, int alpha, u32* tbl, u16* sorted, CanonMeta* meta, u32* cnt) {
-  const u32 lane = tbz_lane();
-  tbz_sync();
-  if (lane < 16) cnt[lane] = 0;
-  tbz_sync();
-  for (u32 i = lane; i < n; i += 64) {
-    u32 l = lens[i];
-    if (l) tbz_atomic_add_lds(&cnt[l], 1);
-  }
-  tbz_sync();
-  u32 c[16], first[16], offs[16];
-  u32 used = 0, code = 0, off = 0, min_len = 0;
-  i32 left = 1;
-  i32 err = 0;
-  c[0] = 0;
-  first[0] = 0;
-  offs[0] = 0;
-#pragma unroll
-  for (int L = 1; L < 16; L++) {
-    c[L] = tbz_uniform(cnt[L]);
-    left <<= 1;
-    if ((i32)c[L] > left && !err) err = E_OVERSUB;
-    left -= (i32)c[L];
-    used += c[L];
-    if (c[L] && !min_len) min_len = L;
-    code = (code + c[L - 1]) << 1;
-    first[L] = code;
-    offs[L] = off;
-    off += c[L];
-  }
-  if (!err && left > 0 && used > 1) err = E_INCOMPLETE;
-  if (err) return err;
-  for (u32 i = lane; i < (1u << ROOT); i += 64) tbl[i] = ENTRY_INVALID;
-  if (lane < 16) {
-    meta->first[lane] = (u16)first[lane];
-    meta->count[lane] = (u16)c[lane];
-    meta->offs[lane] = (u16)offs[lane];
-  }
-  if (lane == 0) meta->min_len = min_len;
-  tbz_sync();
-  if (used == 0) return 0;
-  u32 run[16];
-#pragma unroll
-  for (int L = 0; L < 16; L++) run[L] = 0;
-  const u64 lt = (1ull << lane) - 1;
-  for (u32 base = 0; base < n; base += 64) {
-    u32 i = base + lane;
-    u32 l = i < n ? lens[i] : 0;
-    u32 rank = 0, fc = 0, so = 0;
-#pragma unroll
-    for (int L = 1; L < 16; L++) {
-      if (c[L]) {  // wave-uniform
-        u64 m = tbz_ballot(l == (u32)L);
-        if (l == (u32)L) {
-          rank = run[L] + tbz_popc64(m & lt);
-          fc = first[L];
-          so = offs[L];
-        }
-        run[L] += tbz_popc64(m);
-      }
-    }
-    if (l) {
-      u32 cd = fc + rank;
-      sorted[so + rank] = (u16)i;
-      u32 rev = tbz_brev32(cd) >> (32 - l);
-      if (l <= (u32)ROOT) {
-        u32 ent = make_entry(alpha, i, l);
-        for (u32 k = rev; k < (1u << ROOT); k += (1u << l)) tbl[k] = ent;
-      } else {
-        tbl[rev & ((1u << ROOT) - 1)] = ENTRY_LONG;
-      }
-    }
-  }
-  tbz_sync();
-  return 0;
-}
-
-// canonical decode of a code longer than the root index (rare path)
-template <int ROOT>
-TBZ_DEV u32 decode_long(u32 peek, int alpha, const u16* sorted, const CanonMeta* meta) {
-  u32 r = tbz_brev32(peek);
-  for (u32 L = ROOT + 1; L <= 15; L++) {
-    u32 cd = r >> (32 - L);
-    u32 rel = cd - (u32)meta->first[L];
-    if (rel < (u32)meta->count[L]) {
-      u32 sym = sorted[(u32)meta->offs[L] + rel];
-      return tbz_uniform(make_entry(alpha, sym, L));
-    }
-  }
-  return ENTRY_INVALID;
-}
-
-// How many bits the reference has to see before it reaches the invalid node an entry stands for:
-// a coded-but-forbidden symbol needs its whole code; a hole in an incomplete (single-code) tree is
-// found in the root table, i.e. after `min_len` bits (huffman-tree.lisp:144,:212-217).
-TBZ_DEV u32 special_bits(u32 ent, const CanonMeta* meta) {
-  return (ent & (1u << 13)) ? (ent & 15) : tbz_uniform(meta->min_len);
-}
-
-// LSB-first bit reader over global memory (deflate.lisp:140-231 restated for a wave: the state is
-// wave-uniform so it can live in SGPRs; 32-bit words are fetched one ahead of use).
+// per-lane bit reader (deflate.lisp:140-231 restated): LSB-first, 32-bit words, one word of lookahead
 struct BitReader {
   const u32* w;
-  u64 bias;    // bits between the aligned word base and in_base
   u64 nwords;  // words that contain stream octets
   u32 tail_mask;
+  u32 bias;    // bits between the aligned word base and in_base (0, 8, 16, 24)
   u64 pos;     // bit position relative to in_base
   u64 wi;
   u32 lo, hi, nx, o;
@@ -357,11 +251,11 @@ TBZ_DEV u32 br_word(const BitReader& b, u64 i) {
     v = b.w[i];
     if (i + 1 == b.nwords) v &= b.tail_mask;
   }
-  return tbz_uniform(v);
+  return v;
 }
 TBZ_DEV void br_init(BitReader& b, const u8* in_base, u64 end_byte) {
   uintptr_t base = (uintptr_t)in_base;
-  u64 mis = base & 3;
+  u32 mis = (u32)(base & 3);
   b.w = (const u32*)(base - mis);
   b.bias = mis * 8;
   u64 endb = mis + end_byte;
@@ -392,130 +286,183 @@ TBZ_DEV void br_skip(BitReader& b, u32 n) {  // n <= 32
 }
 TBZ_DEV u32 bfe(u32 v, u32 off, u32 n) { return (v >> off) & ((1u << n) - 1); }
 
-struct K1Params {
-  const u8* in_base;
-  u16* tok;  // token pool: item tokens start at tok[item.start_bit]; words written never exceed bits consumed
-  const Item* items;
-  SegResult* res;
-  const u64* markers;
-  u32 n_markers;
-  u32 n_items;
+// RFC 1951 length / distance bases from the symbol, in ALU (no table lookups in the hot loop).
+// Same values as constants.lisp:41-61.
+TBZ_DEV void len_base_extra(u32 c /* sym-257, 0..28 */, u32& base, u32& extra) {
+  if (c < 8) {
+    base = 3 + c;
+    extra = 0;
+  } else if (c == 28) {
+    base = 258;
+    extra = 0;
+  } else {
+    extra = (c >> 2) - 1;
+    base = 3 + ((4 + (c & 3)) << extra);
+  }
+}
+TBZ_DEV void dist_base_extra(u32 d /* 0..29 */, u32& base, u32& extra) {
+  if (d < 4) {
+    base = 1 + d;
+    extra = 0;
+  } else {
+    extra = (d >> 1) - 1;
+    base = 1 + ((2 + (d & 1)) << extra);
+  }
+}
+
+// canonical-code state of the lengths above the fast root, kept in registers
+template <int FAST>
+struct LongCodes {
+  u32 lim[15 - FAST];  // first[L] + count[L]   (0 when no code has this length)
+  u32 dlt[15 - FAST];  // offs[L] - first[L]    (mod 2^32)
+  u32 min_len;         // shortest code length = width of the reference's root table (huffman-tree.lisp:144)
 };
 
-constexpr u32 K1_STAGE = 1024;  // u16 words staged in LDS between coalesced flushes
+// Per-lane canonical-Huffman table build.  `lens` (global scratch) holds n code lengths 0..15.
+// Acceptance rules of build-tree-part (huffman-tree.lisp:112-122): over-subscribed -> error;
+// incomplete -> error unless at most one symbol is coded; all-zero -> table of holes.
+template <int FAST>
+TBZ_DEV i32 build_table(const u8* lens, u32 n, u16 (*fast)[64], u16 (*tmp)[64], u16* sorted, LongCodes<FAST>& lc) {
+  const u32 lane = tbz_lane();
+#pragma unroll
+  for (int L = 0; L < 16; L++) tmp[L][lane] = 0;
+  for (u32 i = 0; i < n; i++) {
+    u32 l = lens[i];
+    if (l) tmp[l][lane] = (u16)(tmp[l][lane] + 1);
+  }
+  u32 used = 0, code = 0, off = 0, prev = 0;
+  i32 left = 1, err = 0;
+  lc.min_len = 0;
+#pragma unroll
+  for (int L = 1; L < 16; L++) {
+    u32 c = tmp[L][lane];
+    left <<= 1;
+    if ((i32)c > left && !err) err = E_OVERSUB;
+    left -= (i32)c;
+    used += c;
+    if (c && !lc.min_len) lc.min_len = L;
+    code = (code + prev) << 1;  // first canonical code of length L
+    prev = c;
+    tmp[L][lane] = (u16)off;                 // next free slot in `sorted`
+    tmp[16 + L][lane] = (u16)(code - off);   // code = slot + this   (mod 2^16; codes are < 2^15)
+    if (L > FAST) {
+      lc.lim[L - FAST - 1] = c ? code + c : 0;
+      lc.dlt[L - FAST - 1] = off - code;
+    }
+    off += c;
+  }
+  if (!err && left > 0 && used > 1) err = E_INCOMPLETE;
+  if (err) return err;
+  for (u32 i = 0; i < (1u << FAST); i++) fast[i][lane] = (u16)FE_HOLE;
+  for (u32 i = 0; i < n; i++) {
+    u32 l = lens[i];
+    if (!l) continue;
+    u32 slot = tmp[l][lane];
+    tmp[l][lane] = (u16)(slot + 1);
+    u32 cd = (slot + tmp[16 + l][lane]) & 0xffff;
+    sorted[slot] = (u16)i;
+    u32 rev = tbz_brev32(cd) >> (32 - l);
+    if (l <= (u32)FAST) {
+      u16 ent = (u16)((i << 4) | l);
+      for (u32 k = rev; k < (1u << FAST); k += (1u << l)) fast[k][lane] = ent;
+    } else {
+      fast[rev & ((1u << FAST) - 1)][lane] = (u16)FE_LONG;
+    }
+  }
+  return 0;
+}
 
-struct K1Lds {
-  u32 lit[1 << ROOT_LIT];
-  u32 dist[1 << ROOT_DIST];
-  u32 cl[1 << ROOT_CL];
-  u16 stage[K1_STAGE];
-  u16 lit_sorted[288];
-  u16 dist_sorted[32];
-  u16 cl_sorted[32];
-  CanonMeta meta[3];
-  u32 cnt[16];
-  u8 lens[320];
-  u8 cl_lens[32];
-};
+// canonical decode of a code longer than the root index: returns (sym << 4) | L, or FE_HOLE
+template <int FAST>
+TBZ_DEV u32 decode_long(u32 peek, const u16* sorted, const LongCodes<FAST>& lc) {
+  u32 r = tbz_brev32(peek);
+  u32 ent = FE_HOLE;
+#pragma unroll
+  for (int k = 0; k < 15 - FAST; k++) {
+    const u32 L = FAST + 1 + k;
+    u32 cd = r >> (32 - L);
+    if (ent == FE_HOLE && cd < lc.lim[k]) ent = ((u32)sorted[(cd + lc.dlt[k]) & 0xffff] << 4) | L;
+  }
+  return ent;
+}
 
 struct K1State {
   BitReader br;
   u64 end_bit, limit_bit;
-  u64 produced;   // octets the tokens emitted so far produce
-  u64 tok_flushed;  // words already in global memory
-  u32 staged;
+  u64 produced;  // octets the tokens emitted so far produce
+  u64 ntok;      // token words written
+  u64 fail_pos;  // bit position reported on underrun / overshoot
+  u16* tok;      // this item's token region
   u32 deficit;
-  u64 tok_base;   // index of this item's first token word
-  u64 fail_pos;   // bit position reported on underrun / overshoot
 };
-
-TBZ_DEV void k1_flush(K1Lds& S, K1State& st, u16* tok) {
-  tbz_sync();
-  for (u32 i = tbz_lane(); i < st.staged; i += 64) tok[st.tok_base + st.tok_flushed + i] = S.stage[i];
-  tbz_sync();
-  st.tok_flushed += st.staged;
-  st.staged = 0;
-}
-TBZ_DEV void k1_emit(K1Lds& S, K1State& st, u16* tok, u32 v) {
-  S.stage[st.staged++] = (u16)v;
-  if (st.staged >= K1_STAGE - 2) k1_flush(S, st, tok);
-}
 
 // availability / landing-limit test after consuming bits for a token or header field that started
 // at `p0`.  Underrun wins (deflate.lisp:399-427: the whole symbol is pushed back and re-read).
-#define K1_CHECK(p0)                                  \
-  do {                                                \
-    if (st.br.pos > st.end_bit) {                     \
-      st.fail_pos = (p0);                             \
-      return SEG_UNDERRUN;                            \
-    }                                                 \
-    if (st.br.pos > st.limit_bit) {                   \
-      st.fail_pos = (p0);                             \
-      return SEG_OVERSHOOT;                           \
-    }                                                 \
+#define K1_CHECK(p0)                 \
+  do {                               \
+    if (st.br.pos > st.end_bit) {    \
+      st.fail_pos = (p0);            \
+      return SEG_UNDERRUN;           \
+    }                                \
+    if (st.br.pos > st.limit_bit) {  \
+      st.fail_pos = (p0);            \
+      return SEG_OVERSHOOT;          \
+    }                                \
   } while (0)
 
+struct K1Tables {
+  LongCodes<FAST_LIT> ll;
+  LongCodes<FAST_DIST> ld;
+};
+
 // fixed (BTYPE=1) code lengths: huffman-tree.lisp:89-97
-TBZ_DEV i32 k1_build_fixed(K1Lds& S) {
-  const u32 lane = tbz_lane();
-  tbz_sync();
-  for (u32 i = lane; i < 320; i += 64) {
-    u8 l;
-    if (i < 144) l = 8;
-    else if (i < 256) l = 9;
-    else if (i < 280) l = 7;
-    else if (i < 288) l = 8;
-    else l = 5;
-    S.lens[i] = l;
-  }
-  tbz_sync();
-  i32 e = build_table<ROOT_LIT>(S.lens, 288, ALPHA_LITLEN, S.lit, S.lit_sorted, &S.meta[0], S.cnt);
+TBZ_DEV i32 k1_build_fixed(K1Lds& S, K1Tables& T, u8* sc) {
+  u8* lens = sc + K1_SC_LENS;
+  for (u32 i = 0; i < 320; i++) lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5;
+  i32 e = build_table<FAST_LIT>(lens, 288, S.lit, S.tmp, (u16*)(sc + K1_SC_SLIT), T.ll);
   if (e) return e;
-  return build_table<ROOT_DIST>(S.lens + 288, 32, ALPHA_DIST, S.dist, S.dist_sorted, &S.meta[1], S.cnt);
+  return build_table<FAST_DIST>(lens + 288, 32, S.dist, S.tmp, (u16*)(sc + K1_SC_SDIST), T.ld);
 }
 
 // :dynamic-huffman-block … :dht-len-table-data (deflate.lisp:577-669)
-TBZ_DEV i32 k1_dynamic_header(K1Lds& S, K1State& st) {
+TBZ_DEV i32 k1_dynamic_header(K1Lds& S, K1State& st, K1Tables& T, u8* sc) {
+  const u32 lane = tbz_lane();
   const u64 p0 = st.br.pos;
   u32 pk = br_peek(st.br);
   u32 hlit = (pk & 31) + 257, hdist = ((pk >> 5) & 31) + 1, hclen = ((pk >> 10) & 15) + 4;
   br_skip(st.br, 14);
   K1_CHECK(p0);
-  tbz_sync();
-  if (tbz_lane() < 32) S.cl_lens[tbz_lane()] = 0;
-  tbz_sync();
+  u8* lens = sc + K1_SC_LENS;
+  for (u32 i = 0; i < 19; i++) lens[i] = 0;
   for (u32 i = 0; i < hclen; i++) {
     u32 v = br_peek(st.br) & 7;
     br_skip(st.br, 3);
-    S.cl_lens[c_cl_order[i]] = (u8)v;
+    lens[c_cl_order[i]] = (u8)v;
   }
   K1_CHECK(p0);
-  i32 e = build_table<ROOT_CL>(S.cl_lens, 19, ALPHA_CL, S.cl, S.cl_sorted, &S.meta[2], S.cnt);
+  LongCodes<FAST_CL> lcl;  // max code length is 7: never consulted
+  i32 e = build_table<FAST_CL>(lens, 19, S.lit, S.tmp, (u16*)(sc + K1_SC_SCL), lcl);
   if (e) return e;
   const u32 n = hlit + hdist;
   u32 i = 0, last = 0xff;
   while (i < n) {
     const u64 ps = st.br.pos;
     pk = br_peek(st.br);
-    u32 ent = tbz_uniform(S.cl[pk & ((1u << ROOT_CL) - 1)]);
-    u32 L = ent & 15, sym = ent >> 16;
-    bool bad = ((ent >> 8) & 3) == K_SPECIAL;
-    u32 x = 0, xb = 0;
-    if (!bad) {
-      xb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
-      x = bfe(pk, L, xb);
-      br_skip(st.br, L + xb);
-      K1_CHECK(ps);
-    } else {
-      // an unassigned pattern: error unless the input ends inside it
-      if (st.br.pos + special_bits(ent, &S.meta[2]) > st.end_bit) {
+    u32 ent = S.lit[pk & ((1u << FAST_CL) - 1)][lane];
+    u32 L = ent & 15, sym = ent >> 4;
+    if (L == 0) {  // unassigned pattern: error unless the input ends inside the root index
+      if (st.br.pos + lcl.min_len > st.end_bit) {
         st.fail_pos = ps;
         return SEG_UNDERRUN;
       }
       return E_INVALID_CODE;
     }
+    u32 xb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
+    u32 x = bfe(pk, L, xb);
+    br_skip(st.br, L + xb);
+    K1_CHECK(ps);
     if (sym < 16) {
-      S.lens[i++] = (u8)sym;
+      lens[i++] = (u8)sym;
       last = sym;
     } else {
       u32 rep, val;
@@ -529,68 +476,85 @@ TBZ_DEV i32 k1_dynamic_header(K1Lds& S, K1State& st) {
         last = 0;
       }
       if (i + rep > n) return E_REPEAT_OVERRUN;
-      for (u32 k = 0; k < rep; k++) S.lens[i + k] = (u8)val;
+      for (u32 k = 0; k < rep; k++) lens[i + k] = (u8)val;
       i += rep;
     }
   }
-  tbz_sync();
-  e = build_table<ROOT_LIT>(S.lens, hlit, ALPHA_LITLEN, S.lit, S.lit_sorted, &S.meta[0], S.cnt);
+  e = build_table<FAST_LIT>(lens, hlit, S.lit, S.tmp, (u16*)(sc + K1_SC_SLIT), T.ll);
   if (e) return e;
-  return build_table<ROOT_DIST>(S.lens + hlit, hdist, ALPHA_DIST, S.dist, S.dist_sorted, &S.meta[1], S.cnt);
+  return build_table<FAST_DIST>(lens + hlit, hdist, S.dist, S.tmp, (u16*)(sc + K1_SC_SDIST), T.ld);
 }
 
 // :decode-compressed-data (deflate.lisp:673-702): returns 0 at end-of-block
-TBZ_DEV i32 k1_decode_block(K1Lds& S, K1State& st, u16* tok) {
+TBZ_DEV i32 k1_decode_block(K1Lds& S, K1State& st, const K1Tables& T, const u8* sc) {
+  const u32 lane = tbz_lane();
+  const u16* slit = (const u16*)(sc + K1_SC_SLIT);
+  const u16* sdist = (const u16*)(sc + K1_SC_SDIST);
   for (;;) {
     const u64 p0 = st.br.pos;
     u32 pk = br_peek(st.br);
-    u32 ent = tbz_uniform(S.lit[pk & ((1u << ROOT_LIT) - 1)]);
-    if (((ent >> 8) & 3) == K_SPECIAL) {
-      if (ent & (1u << 12)) ent = decode_long<ROOT_LIT>(pk, ALPHA_LITLEN, S.lit_sorted, &S.meta[0]);
-      if (((ent >> 8) & 3) == K_SPECIAL) {
-        if (st.br.pos + special_bits(ent, &S.meta[0]) > st.end_bit) {
+    u32 ent = S.lit[pk & ((1u << FAST_LIT) - 1)][lane];
+    if ((ent & 15) == 0) {
+      if (ent == FE_LONG) ent = decode_long<FAST_LIT>(pk, slit, T.ll);
+      if ((ent & 15) == 0) {
+        if (st.br.pos + T.ll.min_len > st.end_bit) {
           st.fail_pos = p0;
           return SEG_UNDERRUN;
         }
         return E_INVALID_CODE;
       }
     }
-    u32 L = ent & 15, X = (ent >> 4) & 15, kind = (ent >> 8) & 3, val = ent >> 16;
-    if (kind == K_LIT) {
+    u32 L = ent & 15, sym = ent >> 4;
+    if (sym < 256) {
       br_skip(st.br, L);
       K1_CHECK(p0);
-      k1_emit(S, st, tok, val);
+      st.tok[st.ntok++] = (u16)sym;
       st.produced += 1;
-    } else if (kind == K_BASE) {
-      u32 len = val + bfe(pk, L, X);
+    } else if (sym == 256) {  // end of block
+      br_skip(st.br, L);
+      K1_CHECK(p0);
+      return 0;
+    } else {
+      if (sym > 285) {  // 286/287 are coded but may not be used (huffman-tree.lisp:176-177)
+        br_skip(st.br, L);
+        K1_CHECK(p0);
+        return E_INVALID_CODE;
+      }
+      u32 base, X;
+      len_base_extra(sym - 257, base, X);
+      u32 len = base + bfe(pk, L, X);
       br_skip(st.br, L + X);
       u32 pd = br_peek(st.br);
-      u32 de = tbz_uniform(S.dist[pd & ((1u << ROOT_DIST) - 1)]);
-      if (((de >> 8) & 3) == K_SPECIAL) {
-        if (de & (1u << 12)) de = decode_long<ROOT_DIST>(pd, ALPHA_DIST, S.dist_sorted, &S.meta[1]);
-        if (((de >> 8) & 3) == K_SPECIAL) {
-          if (st.br.pos + special_bits(de, &S.meta[1]) > st.end_bit) {
+      u32 de = S.dist[pd & ((1u << FAST_DIST) - 1)][lane];
+      if ((de & 15) == 0) {
+        if (de == FE_LONG) de = decode_long<FAST_DIST>(pd, sdist, T.ld);
+        if ((de & 15) == 0) {
+          if (st.br.pos + T.ld.min_len > st.end_bit) {
             st.fail_pos = p0;
             return SEG_UNDERRUN;
           }
           return E_INVALID_CODE;
         }
       }
-      u32 DL = de & 15, DX = (de >> 4) & 15;
-      u32 dist = (de >> 16) + bfe(pd, DL, DX);
+      u32 DL = de & 15, ds = de >> 4;
+      if (ds > 29) {  // 30/31 (huffman-tree.lisp:172-175)
+        br_skip(st.br, DL);
+        K1_CHECK(p0);
+        return E_INVALID_CODE;
+      }
+      u32 dbase, DX;
+      dist_base_extra(ds, dbase, DX);
+      u32 dist = dbase + bfe(pd, DL, DX);
       br_skip(st.br, DL + DX);
       K1_CHECK(p0);
       if ((u64)dist > st.produced) {
         u32 d = dist - (u32)st.produced;
         if (d > st.deficit) st.deficit = d;
       }
-      k1_emit(S, st, tok, 0x8000u | (len - 3));
-      k1_emit(S, st, tok, dist - 1);
+      st.tok[st.ntok] = (u16)(TOK_MATCH | (len - 3));
+      st.tok[st.ntok + 1] = (u16)(dist - 1);
+      st.ntok += 2;
       st.produced += len;
-    } else {  // end of block
-      br_skip(st.br, L);
-      K1_CHECK(p0);
-      return 0;
     }
   }
 }
@@ -626,22 +590,17 @@ TBZ_DEV i32 k1_container_header(K1State& st, u32 fmt) {
   }
   if (fmt == 2) {
     u32 crc = 0xffffffffu;
-    u32 hdr[10];
-    for (int i = 0; i < 2; i++) {
-      if ((e = k1_byte(st, &hdr[i], p0))) return e;
-      crc = crc_bitwise(crc, hdr[i]);
-    }
-    if (hdr[0] != 0x1f || hdr[1] != 0x8b) return E_GZIP_MAGIC;
-    for (int i = 2; i < 4; i++) {
-      if ((e = k1_byte(st, &hdr[i], p0))) return e;
-      crc = crc_bitwise(crc, hdr[i]);
-    }
-    if (hdr[2] != 8) return E_GZIP_METHOD;
-    u32 flg = hdr[3];
-    if (flg >> 5) return E_GZIP_FLAGS;
-    for (int i = 4; i < 10; i++) {
-      if ((e = k1_byte(st, &hdr[i], p0))) return e;
-      crc = crc_bitwise(crc, hdr[i]);
+    u32 flg = 0;
+    for (int i = 0; i < 10; i++) {
+      if ((e = k1_byte(st, &t, p0))) return e;
+      crc = crc_bitwise(crc, t);
+      if (i == 0 && t != 0x1f) return E_GZIP_MAGIC;
+      if (i == 1 && t != 0x8b) return E_GZIP_MAGIC;
+      if (i == 2 && t != 8) return E_GZIP_METHOD;
+      if (i == 3) {
+        flg = t;
+        if (flg >> 5) return E_GZIP_FLAGS;
+      }
     }
     if (flg & 4) {
       if ((e = k1_byte(st, &b0, p0))) return e;
@@ -653,7 +612,7 @@ TBZ_DEV i32 k1_container_header(K1State& st, u32 fmt) {
         crc = crc_bitwise(crc, t);
       }
     }
-    for (int f = 8; f <= 16; f <<= 1) {  // FNAME, FCOMMENT: zero-terminated
+    for (u32 f = 8; f <= 16; f <<= 1) {  // FNAME, FCOMMENT: zero-terminated
       if (flg & f) {
         for (;;) {
           if ((e = k1_byte(st, &t, p0))) return e;
@@ -674,21 +633,23 @@ TBZ_DEV i32 k1_container_header(K1State& st, u32 fmt) {
 
 TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
   TBZ_SHARED K1Lds S;
-  if (tbz_block() >= P.n_items) return;
   const u32 lane = tbz_lane();
-  const Item it = P.items[tbz_block()];
+  const u32 idx = tbz_block() * P.items_per_wg + lane;
+  if (lane >= P.items_per_wg || idx >= P.n_items) return;  // no collectives below: lanes are independent
+  const Item it = P.items[idx];
   const u32 fmt = (it.flags >> ITEM_FMT_SHIFT) & 3;
   const bool fixup = (it.flags & ITEM_FIXUP) != 0;
+  u8* sc = P.scratch + (u64)idx * K1_SCRATCH;
   K1State st;
+  K1Tables T;
   br_init(st.br, P.in_base, it.end_byte);
   br_seek(st.br, it.start_bit);
   st.end_bit = it.end_byte * 8;
   st.limit_bit = fixup ? ~0ull : it.limit_bit;
   st.produced = 0;
-  st.tok_flushed = 0;
-  st.staged = 0;
+  st.ntok = 0;
   st.deficit = 0;
-  st.tok_base = it.start_bit;
+  st.tok = P.tok + it.start_bit;
   st.fail_pos = it.start_bit;
 
   i32 status = 0;
@@ -701,7 +662,7 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
   while (status == 0) {
     blk_pos = st.br.pos;
     blk_prod = st.produced;
-    blk_tok = st.tok_flushed + st.staged;
+    blk_tok = st.ntok;
     u32 pk = br_peek(st.br);
     br_skip(st.br, 3);
     if (st.br.pos > st.end_bit) { st.fail_pos = blk_pos; status = SEG_UNDERRUN; break; }
@@ -719,10 +680,14 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
       if ((byte0 + LEN) * 8 > st.limit_bit) { status = SEG_OVERSHOOT; break; }
       u64 avail = it.end_byte - byte0;
       u32 ncopy = avail < LEN ? (u32)avail : LEN;
-      k1_flush(S, st, P.tok);
-      for (u32 i = lane; i < ncopy; i += 64) P.tok[st.tok_base + st.tok_flushed + i] = P.in_base[byte0 + i];
-      st.tok_flushed += ncopy;
-      st.produced += ncopy;
+      if (ncopy) {  // one stored-run token: K2 copies the octets straight from the input
+        st.tok[st.ntok] = (u16)(TOK_STORED | (ncopy & 0x3fff));
+        st.tok[st.ntok + 1] = (u16)((ncopy >> 14) | ((u32)(byte0 & 0x1fff) << 2));
+        st.tok[st.ntok + 2] = (u16)((byte0 >> 13) & 0x7fff);
+        st.tok[st.ntok + 3] = (u16)((byte0 >> 28) & 0x7fff);
+        st.ntok += 4;
+        st.produced += ncopy;
+      }
       if (ncopy < LEN) { st.fail_pos = (byte0 + ncopy) * 8; status = SEG_UNDERRUN; break; }
       br_seek(st.br, (byte0 + LEN) * 8);
     } else if (btype == 3) {
@@ -731,15 +696,15 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
     } else {
       if (btype == 1) {
         if (tables != 1) {
-          status = k1_build_fixed(S);
+          status = k1_build_fixed(S, T, sc);
           tables = 1;
         }
       } else {
-        status = k1_dynamic_header(S, st);
+        status = k1_dynamic_header(S, st, T, sc);
         tables = 2;
       }
       if (status) break;
-      status = k1_decode_block(S, st, P.tok);
+      status = k1_decode_block(S, st, T, sc);
       if (status) break;
     }
     // :block-end (deflate.lisp:719-722)
@@ -782,45 +747,49 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
     }
   }
 
-  u64 r_end, r_out, r_tok;
+  SegResult r;
   if (status == SEG_OVERSHOOT) {
-    r_end = blk_pos;
-    r_out = blk_prod;
-    r_tok = blk_tok;
+    r.end_bit = blk_pos;
+    r.out_bytes = blk_prod;
+    r.tok_words = blk_tok;
   } else {
-    r_end = (status == SEG_UNDERRUN) ? st.fail_pos : st.br.pos;
-    r_out = st.produced;
-    r_tok = st.tok_flushed + st.staged;
+    r.end_bit = (status == SEG_UNDERRUN) ? st.fail_pos : st.br.pos;
+    r.out_bytes = st.produced;
+    r.tok_words = st.ntok;
   }
-  k1_flush(S, st, P.tok);
-  if (lane == 0) {
-    SegResult r;
-    r.end_bit = r_end;
-    r.out_bytes = r_out;
-    r.tok_words = r_tok;
-    r.status = status;
-    r.max_deficit = st.deficit;
-    r.trailer0 = tr0;
-    r.trailer1 = tr1;
-    r.trailer_have = tr_have;
-    r.land_marker = land;
-    r.reserved = 0;
-    P.res[tbz_block()] = r;
-  }
+  r.status = status;
+  r.max_deficit = st.deficit;
+  r.trailer0 = tr0;
+  r.trailer1 = tr1;
+  r.trailer_have = tr_have;
+  r.land_marker = land;
+  r.reserved = 0;
+  P.res[idx] = r;
 }
 #undef K1_CHECK
 
 // ================================================================================================
-// K2 — LZ77 resolve: tokens -> LDS ring window -> coalesced stores
+// K2 — LZ77 resolve: tokens -> LDS ring window -> coalesced 16-byte stores.  One wave per group.
+//
+// A batch is up to 64 token words.  Lanes classify their word (literal / match head / payload) with
+// ballots, a DPP prefix sum gives every token its output offset, literals are stored at once, and
+// matches are resolved LANE-PARALLEL in rounds: a match is ready when the part of its source that
+// it does not produce itself lies below the high-water mark (the offset of the first unresolved
+// match; everything below is final).  The first unresolved match is always ready, so every round
+// makes progress; typical text needs 2-4 rounds per batch.  Long matches (> 16 octets) and stored
+// runs are copied cooperatively by all 64 lanes.  Replaces copy-history / out-byte / :copy-block
+// (deflate.lisp:233-359, :538-573).
 // ================================================================================================
 constexpr u32 K2_WIN = 36864;   // 32 KiB history + one batch span + slack; multiple of 16
-constexpr u32 K2_SPAN = 3072;   // max octets one 64-token batch may produce (cut otherwise)
+constexpr u32 K2_SPAN = 3072;   // max octets one batch may produce (cut otherwise)
 constexpr u32 K2_FLUSH = 8192;  // flush the ring to HBM every this many octets
+constexpr u32 K2_SHORT = 16;    // matches up to this length are copied by their own lane
 
 struct K2Params {
   const u16* tok;
   const Seg* segs;
   const Group* groups;
+  const u8* in_base;  // source of stored runs
   u8* out_base;
   u32 n_groups;
 };
@@ -837,9 +806,7 @@ TBZ_DEV void k2_flush(const u8* win, u8* outp, u64 from, u64 to, u64 clip, u32 a
   u64 head_end = ((from + a0 + 15) & ~15ull) - a0;  // first 16-aligned offset >= from
   if (head_end > to) head_end = to;
   u64 body_end = head_end + ((to - head_end) & ~15ull);
-  // head octets
   if (from + lane < head_end) outp[from + lane] = win[(u32)((from + lane + a0) % K2_WIN)];
-  // 16-byte body
   u64 nchunk = (body_end - head_end) >> 4;
   u32 r0 = (u32)((head_end + a0) % K2_WIN);
   for (u32 c = lane; c < (u32)nchunk; c += 64) {  // nchunk*16 < K2_WIN
@@ -847,15 +814,35 @@ TBZ_DEV void k2_flush(const u8* win, u8* outp, u64 from, u64 to, u64 clip, u32 a
     uint4 v = *(const uint4*)(win + ri);
     *(uint4*)(outp + head_end + (u64)c * 16) = v;
   }
-  // tail octets
   if (body_end + lane < to) outp[body_end + lane] = win[(u32)((body_end + lane + a0) % K2_WIN)];
   tbz_sync();
+}
+
+// all 64 lanes copy l octets inside the ring: dst index rd, source rs = rd - dd.  An overlapping
+// copy (dd < l) repeats the dd-octet pattern (the special cases of deflate.lisp:281-334).
+TBZ_DEV void k2_copy_coop(u8* win, u32 rd, u32 dd, u32 l) {
+  const u32 lane = tbz_lane();
+  u32 rs = rd >= dd ? rd - dd : rd + K2_WIN - dd;
+  float inv = 1.0f / (float)dd;
+  for (u32 j = lane; j < l; j += 64) {
+    u32 jj = j;
+    if (dd < l) {
+      u32 q = (u32)((float)j * inv);
+      i32 r = (i32)j - (i32)(q * dd);
+      if (r < 0) r += (i32)dd;
+      if (r >= (i32)dd) r -= (i32)dd;
+      jj = (u32)r;
+    }
+    u8 b = win[ring(rs + jj)];
+    win[ring(rd + j)] = b;
+  }
 }
 
 TBZ_KERNEL void tbz_k2_lz77(K2Params P) {
   TBZ_SHARED __attribute__((aligned(16))) u8 win[K2_WIN];
   if (tbz_block() >= P.n_groups) return;
   const u32 lane = tbz_lane();
+  const u64 lane_bit = 1ull << lane;
   const Group g = P.groups[tbz_block()];
   u8* outp = P.out_base + g.out_abs;
   const u32 a0 = (u32)((uintptr_t)outp & 15);
@@ -870,44 +857,83 @@ TBZ_KERNEL void tbz_k2_lz77(K2Params P) {
       u64 left = sg.tok_words - p;
       u32 n = left < 64 ? (u32)left : 64;
       u32 w = lane < n ? P.tok[sg.tok_index + p + lane] : 0;
-      bool head = lane < n && (w & 0x8000u);
-      bool prev_head = tbz_shfl_up(head ? 1u : 0u, 1) != 0 && lane > 0;
-      bool isdist = lane < n && prev_head;
-      head = head && !isdist;
-      bool islit = lane < n && !head && !isdist;
+      const u64 valid = n == 64 ? ~0ull : ((1ull << n) - 1);
+      u64 hb = tbz_ballot((w & 0x8000u) != 0) & valid;            // heads (payload words have bit 15 clear)
+      u64 sb = tbz_ballot((w & 0xC000u) == 0xC000u) & valid;      // stored-run heads
+      u64 mb = hb & ~sb;                                          // match heads
+      if (sb & 1) {
+        // ---- stored run at the front of the batch: cooperative copy input -> ring, flushing as we go
+        if (n < 4) break;  // malformed (never produced by K1)
+        u32 w1 = tbz_readlane(w, 1), w2 = tbz_readlane(w, 2), w3 = tbz_readlane(w, 3), w0 = tbz_readlane(w, 0);
+        u64 cnt = (w0 & 0x3fff) | ((u64)(w1 & 3) << 14);
+        u64 src = ((u64)(w1 >> 2) & 0x1fff) | ((u64)w2 << 13) | ((u64)w3 << 28);
+        while (cnt) {
+          u32 c = cnt < 4096 ? (u32)cnt : 4096;
+          tbz_sync();
+          for (u32 j = lane; j < c; j += 64) win[ring(rpos + j)] = P.in_base[src + j];
+          tbz_sync();
+          pos += c;
+          rpos = ring(rpos + c);
+          src += c;
+          cnt -= c;
+          if (pos - flushed >= K2_FLUSH || pos >= clip) {
+            u64 upto = pos >= clip ? pos : ((pos + a0) & ~15ull) - a0;
+            if (upto > flushed) {
+              k2_flush(win, outp, flushed, upto, clip, a0);
+              flushed = upto;
+            }
+          }
+          if (pos >= clip) break;
+        }
+        p += 4;
+        continue;
+      }
+      // ---- ordinary batch: everything before the first stored head
+      u32 n_eff = sb ? (u32)tbz_ffs64(sb) - 1 : n;
+      const u64 veff = n_eff == 64 ? ~0ull : ((1ull << n_eff) - 1);
+      mb &= veff;
+      u64 pm = (mb << 1);                       // payload (distance) words
+      u64 lits = veff & ~mb & ~pm;
+      u64 cut_ok = (lits | pm) & veff;          // a batch may end after a literal or after a distance word
+      bool head = (mb & lane_bit) != 0, islit = (lits & lane_bit) != 0;
       u32 len = head ? (w & 0xff) + 3 : (islit ? 1u : 0u);
-      u32 incl = wave_incl_scan_u32(len);
-      // a batch may end after a literal or after a distance word, never between head and distance,
-      // and may not produce more than K2_SPAN octets (ring sizing)
-      u64 ok = tbz_ballot(lane < n && !head && incl <= K2_SPAN);
+      u32 incl = tbz_wave_incl_scan_u32(len);
+      u64 ok = tbz_ballot(incl <= K2_SPAN) & cut_ok;
       if (ok == 0) break;  // malformed token stream (never produced by K1)
       u32 m = 64 - (u32)__builtin_clzll(ok);
-      u32 total = tbz_shfl(incl, (int)m - 1);
-      bool active = lane < m;
+      u32 total = tbz_readlane(incl, m - 1);
+      const u64 act = m == 64 ? ~0ull : ((1ull << m) - 1);
       u32 dofs = incl - len;  // octet offset of this token inside the batch
-      u32 dist = (tbz_shfl_down(w, 1) & 0x7fffu) + 1;
-      if (active && islit) win[ring(rpos + dofs)] = (u8)w;
-      u64 hm = tbz_ballot(active && head);
+      u32 dist = (tbz_wave_shl1(w) & 0x7fffu) + 1;
+      if (islit && (act & lane_bit)) win[ring(rpos + dofs)] = (u8)w;
+      // multi-round resolution
+      u64 pend = mb & act;
+      // the part of the source a match does not write itself ends at dofs - dist + min(len, dist)
+      i32 need = (i32)dofs - (i32)dist + (i32)(len < dist ? len : dist);
+      u32 rd = ring(rpos + dofs);
+      u32 rs = rd >= dist ? rd - dist : rd + K2_WIN - dist;
       tbz_sync();
-      while (hm) {
-        int i = (int)tbz_ffs64(hm) - 1;
-        hm &= hm - 1;
-        u32 l = tbz_shfl(len, i), dd = tbz_shfl(dist, i), o = tbz_shfl(dofs, i);
-        u32 rd = ring(rpos + o);                       // ring index of the match's first octet
-        u32 rs = rd >= dd ? rd - dd : rd + K2_WIN - dd;  // ring index of its source
-        float inv = 1.0f / (float)dd;
-        for (u32 j = lane; j < l; j += 64) {
-          u32 jj = j;
-          if (dd < l) {  // overlapping copy: octet j repeats the dd-octet pattern (deflate.lisp:281-334)
-            u32 q = (u32)((float)j * inv);
-            i32 r = (i32)j - (i32)(q * dd);
-            if (r < 0) r += (i32)dd;
-            if (r >= (i32)dd) r -= (i32)dd;
-            jj = (u32)r;
+      while (pend) {
+        u32 first = (u32)tbz_ffs64(pend) - 1;
+        i32 hwm = (i32)tbz_readlane(dofs, first);
+        bool ready = (pend & lane_bit) && need <= hwm;
+        u64 rdy = tbz_ballot(ready);
+        u64 longs = tbz_ballot(ready && len > K2_SHORT);
+        if (ready && len <= K2_SHORT) {  // own-lane copy; an overlapping match repeats its dist-octet pattern
+          u32 jj = 0;
+          for (u32 j = 0; j < len; j++) {
+            u8 b = win[ring(rs + jj)];
+            win[ring(rd + j)] = b;
+            jj++;
+            if (jj == dist) jj = 0;
           }
-          u8 b = win[ring(rs + jj)];
-          win[ring(rd + j)] = b;
         }
+        while (longs) {
+          u32 i = (u32)tbz_ffs64(longs) - 1;
+          longs &= longs - 1;
+          k2_copy_coop(win, tbz_readlane(rd, i), tbz_readlane(dist, i), tbz_readlane(len, i));
+        }
+        pend &= ~rdy;
         tbz_sync();
       }
       pos += total;

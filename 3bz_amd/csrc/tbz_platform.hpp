@@ -61,6 +61,25 @@ TBZ_DEV u32 tbz_brev32(u32 v) { return __brev(v); }
 TBZ_DEV u32 tbz_clz32(u32 v) { return (u32)__clz((int)v); }
 TBZ_DEV u32 tbz_atomic_add_lds(u32* p, u32 v) { return atomicAdd(p, v); }
 
+// value of lane `i` (i wave-uniform): v_readlane, no LDS round trip
+TBZ_DEV u32 tbz_readlane(u32 v, u32 i) { return (u32)__builtin_amdgcn_readlane((int)v, (int)i); }
+// whole-wave shift by one lane through DPP (no LDS): shr1: lane i <- lane i-1 (lane 0 <- 0);
+// shl1: lane i <- lane i+1 (lane 63 <- 0)
+TBZ_DEV u32 tbz_wave_shr1(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
+TBZ_DEV u32 tbz_wave_shl1(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
+// wave64 inclusive prefix sum in 7 DPP adds (row_shr 1/2/3/4/8, row_bcast 15/31)
+TBZ_DEV u32 tbz_wave_incl_scan_u32(u32 x) {
+  int v0 = (int)x;
+  int v = v0 + __builtin_amdgcn_update_dpp(0, v0, 0x111, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v0, 0x112, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v0, 0x113, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xe, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xc, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return (u32)v;
+}
+
 #define TBZ_LAUNCH(kernel, grid, stream, ...) \
   hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3(64), 0, (stream), __VA_ARGS__)
 #endif  // TBZ_PLATFORM_HPP_INCLUDED

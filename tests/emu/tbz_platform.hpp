@@ -239,6 +239,26 @@ TBZ_DEV u32 tbz_brev32(u32 v) {
 TBZ_DEV u32 tbz_clz32(u32 v) { return v ? (u32)__builtin_clz(v) : 32; }
 TBZ_DEV u32 tbz_atomic_add_lds(u32* p, u32 v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
+TBZ_DEV u32 tbz_readlane(u32 v, u32 i) { return (u32)tbz_emu::xchg(v, i); }
+TBZ_DEV u32 tbz_wave_shr1(u32 v) {
+  u32 l = (u32)tbz_emu::st().cur;
+  u32 r = (u32)tbz_emu::xchg(v, l ? l - 1 : 0);
+  return l ? r : 0;
+}
+TBZ_DEV u32 tbz_wave_shl1(u32 v) {
+  u32 l = (u32)tbz_emu::st().cur;
+  u32 r = (u32)tbz_emu::xchg(v, l < 63 ? l + 1 : 63);
+  return l < 63 ? r : 0;
+}
+TBZ_DEV u32 tbz_wave_incl_scan_u32(u32 v) {
+  u32 l = (u32)tbz_emu::st().cur;
+  for (u32 d = 1; d < 64; d <<= 1) {
+    u32 t = (u32)tbz_emu::xchg(v, l >= d ? l - d : l);
+    if (l >= d) v += t;
+  }
+  return v;
+}
+
 #define TBZ_LAUNCH(kernel, grid, stream, ...) \
   tbz_emu::launch((u32)(grid), [&] { kernel(__VA_ARGS__); })
 

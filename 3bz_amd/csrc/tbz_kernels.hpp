@@ -186,21 +186,26 @@ TBZ_KERNEL void tbz_k0_scan_emit(K0Params P) {
 // Why lane-per-item: symbol decode is a serial dependent chain (lookup -> shift -> lookup), so one
 // decoder can use one lane.  A first version ran one decoder per WAVE; the compiler (correctly)
 // scalarised it onto the CU's single scalar ALU and the kernel became SALU-bound at ~1700 cycles
-// per token (profiles/r01_v1_*).  Here every lane of the 4 SIMDs' VALUs decodes its own item:
-//   - fast lookup tables live in LDS, LANE-INTERLEAVED: entry i of lane l is element [i][l], so the
-//     bank is a function of the lane only and 64 random lookups never conflict by index
-//   - lit/len: 9-bit root (512 x u16 per lane), distance: 6-bit root (64 x u16 per lane);
-//     longer codes take the canonical path (limits held in registers, sorted symbols in a per-item
-//     global scratch that stays in L2)
-//   - the compressed bitstream is read through a 96-bit register window per lane, one aligned
-//     32-bit word fetched a full window ahead of use
-//   - tokens are stored straight to the item's token region (consecutive u16 per lane; L2 merges)
+// per token (profiles/r01_v1_*).  Here every lane of the 4 SIMDs' VALUs decodes its own item.
+//
+// Everything the token loop touches is in registers or LDS — NO global loads inside it, because
+// vmcnt is a per-wave in-order counter: one lane's load makes all 64 lanes wait for every store in
+// flight (measured: a full memory round trip per iteration).
+//   - lookup tables in LDS, LANE-INTERLEAVED: entry i of lane l is element [i][l], so the bank is a
+//     function of the lane only and 64 random lookups never collide by index
+//   - lit/len: 8-bit root (256 x u16 per lane); longer codes: canonical search with the per-length
+//     limits in registers and the long-code symbols in LDS (`slong`)
+//   - distance: 5-bit root (32 x u16 per lane) + the 32 distance symbols in LDS (`sdist`)
+//   - compressed input: a 64-word LDS window per lane, reloaded by all lanes together once per
+//     phase (nested loops make the wave reconverge at the reload)
+//   - tokens are stored straight to the item's token region (consecutive u16 per lane, merged in L2);
+//     stores need no wait
 // Replaces deflate.lisp:518-702 + huffman-tree.lisp:99-218 (same acceptance rules and errors).
 // ================================================================================================
 
 TBZ_CONSTANT u8 c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-constexpr int FAST_LIT = 9, FAST_DIST = 6, FAST_CL = 7;
+constexpr int FAST_LIT = 8, FAST_DIST = 5, FAST_CL = 7;
 // u16 fast-table entry: [3:0] code length L (0 = special), [15:4] symbol.
 //   L = 0, symbol 0 : unassigned pattern (hole of an incomplete code)      -> invalid
 //   L = 0, symbol 1 : code longer than the root index                       -> canonical path
@@ -214,14 +219,20 @@ constexpr u32 FE_HOLE = 0x0000, FE_LONG = 0x0010;
 // payload words always have bit 15 clear, so a word with bit 15 set is always a head.
 constexpr u32 TOK_MATCH = 0x8000u, TOK_STORED = 0xC000u;
 
-constexpr u32 K1_SCRATCH = 1024;  // octets of global scratch per item: lens[320] | sorted_lit u16[288] | sorted_dist u16[32] | spare
-constexpr u32 K1_SC_LENS = 0, K1_SC_SLIT = 320, K1_SC_SDIST = 896, K1_SC_SCL = 960;
+constexpr u32 K1_SCRATCH = 1024;  // octets of global scratch per item: lens[320] | sorted_lit u16[288] | spare
+constexpr u32 K1_SC_LENS = 0, K1_SC_SLIT = 320, K1_SC_SCL = 960;
+constexpr u32 K1_INBUF = 64;      // 32-bit words of compressed input windowed per lane (256 octets)
+constexpr u32 K1_SLONG = 128;     // long-code literal/length symbols held in LDS per lane (the rest: global scratch)
 
 struct K1Lds {
-  u16 lit[1 << FAST_LIT][64];    // 64 KiB (also hosts the 7-bit code-length-code table while a header is parsed)
-  u16 dist[1 << FAST_DIST][64];  // 8 KiB
-  u16 tmp[32][64];               // 4 KiB: per-lane counters while a table is built
+  u16 lit[1 << FAST_LIT][64];    // 32 KiB (also hosts the 7-bit code-length-code table while a header is parsed)
+  u16 slong[K1_SLONG][64];       // 16 KiB: lit/len symbols whose code is longer than the root, canonical order
+  u16 dist[1 << FAST_DIST][64];  // 4 KiB
+  u8 sdist[32][64];              // 2 KiB: distance symbols in canonical order
+  u32 inbuf[K1_INBUF][64];       // 16 KiB: per-lane window of the compressed stream; its first 4 KiB double as the
+                                 //         per-lane counters while a table is built (the window is reloaded after)
 };
+static_assert(sizeof(K1Lds) <= 80 * 1024, "two K1 workgroups must fit one CU's 160 KiB LDS");
 
 struct K1Params {
   const u8* in_base;
@@ -235,17 +246,21 @@ struct K1Params {
   u32 items_per_wg;  // 1..64: lanes >= items_per_wg idle (used to spread few large items over all CUs)
 };
 
-// per-lane bit reader (deflate.lisp:140-231 restated): LSB-first, 32-bit words, one word of lookahead
+// per-lane bit reader (deflate.lisp:140-231 restated): LSB-first, 32-bit words, one word of lookahead.
+// This is the general (64-bit position) form used for headers and block framing; the token loop works
+// on a phase-local 32-bit copy.
 struct BitReader {
   const u32* w;
-  u64 nwords;  // words that contain stream octets
+  u32 (*buf)[64];  // this workgroup's LDS input windows, [word][lane]
+  u64 nwords;      // words that contain stream octets
   u32 tail_mask;
-  u32 bias;    // bits between the aligned word base and in_base (0, 8, 16, 24)
-  u64 pos;     // bit position relative to in_base
+  u32 bias;        // bits between the aligned word base and in_base (0, 8, 16, 24)
+  u64 pos;         // bit position relative to in_base
   u64 wi;
+  u64 bw;          // word index held in buf[0]; 2^62 (never within the window of a real index) when invalid
   u32 lo, hi, nx, o;
 };
-TBZ_DEV u32 br_word(const BitReader& b, u64 i) {
+TBZ_DEV u32 br_word_global(const BitReader& b, u64 i) {
   u32 v = 0;
   if (i < b.nwords) {
     v = b.w[i];
@@ -253,7 +268,37 @@ TBZ_DEV u32 br_word(const BitReader& b, u64 i) {
   }
   return v;
 }
-TBZ_DEV void br_init(BitReader& b, const u8* in_base, u64 end_byte) {
+// words come from the lane's LDS window when it covers them, else straight from memory, so
+// correctness never depends on when the window was loaded
+TBZ_DEV u32 br_word(const BitReader& b, u64 i) {
+  u64 k = i - b.bw;
+  if (k < K1_INBUF) return b.buf[k][tbz_lane()];
+  return br_word_global(b, i);
+}
+struct __attribute__((packed, aligned(4))) U32x4 {
+  u32 a, b, c, d;
+};
+// reload the lane's window so that it starts at the current word (octets past the stream read as 0)
+TBZ_DEV void br_refill(BitReader& b) {
+  const u32 lane = tbz_lane();
+  const u64 w0 = b.wi;
+  if (w0 + K1_INBUF < b.nwords) {  // whole window inside the stream, no tail masking: 16-octet loads
+#pragma unroll
+    for (u32 k = 0; k < K1_INBUF; k += 4) {
+      U32x4 v = *(const U32x4*)(b.w + w0 + k);
+      b.buf[k][lane] = v.a;
+      b.buf[k + 1][lane] = v.b;
+      b.buf[k + 2][lane] = v.c;
+      b.buf[k + 3][lane] = v.d;
+    }
+  } else {
+    for (u32 k = 0; k < K1_INBUF; k++) b.buf[k][lane] = br_word_global(b, w0 + k);
+  }
+  b.bw = w0;
+}
+TBZ_DEV void br_init(BitReader& b, const u8* in_base, u64 end_byte, u32 (*buf)[64]) {
+  b.buf = buf;
+  b.bw = 1ull << 62;
   uintptr_t base = (uintptr_t)in_base;
   u32 mis = (u32)(base & 3);
   b.w = (const u32*)(base - mis);
@@ -272,7 +317,7 @@ TBZ_DEV void br_seek(BitReader& b, u64 pos) {
   b.hi = br_word(b, b.wi + 1);
   b.nx = br_word(b, b.wi + 2);
 }
-TBZ_DEV u32 br_peek(const BitReader& b) { return (u32)(((((u64)b.hi) << 32) | b.lo) >> b.o); }
+TBZ_DEV u32 br_peek(const BitReader& b) { return tbz_alignbit(b.hi, b.lo, b.o); }
 TBZ_DEV void br_skip(BitReader& b, u32 n) {  // n <= 32
   b.o += n;
   b.pos += n;
@@ -284,45 +329,47 @@ TBZ_DEV void br_skip(BitReader& b, u32 n) {  // n <= 32
     b.nx = br_word(b, b.wi + 2);
   }
 }
-TBZ_DEV u32 bfe(u32 v, u32 off, u32 n) { return (v >> off) & ((1u << n) - 1); }
 
 // RFC 1951 length / distance bases from the symbol, in ALU (no table lookups in the hot loop).
 // Same values as constants.lisp:41-61.
 TBZ_DEV void len_base_extra(u32 c /* sym-257, 0..28 */, u32& base, u32& extra) {
-  if (c < 8) {
-    base = 3 + c;
-    extra = 0;
-  } else if (c == 28) {
-    base = 258;
-    extra = 0;
-  } else {
-    extra = (c >> 2) - 1;
-    base = 3 + ((4 + (c & 3)) << extra);
-  }
+  u32 e = (c >> 2) - 1;
+  u32 b = 3 + ((4 + (c & 3)) << (e & 7));
+  bool small = c < 8, top = c == 28;
+  extra = (small || top) ? 0 : e;
+  base = small ? 3 + c : (top ? 258 : b);
 }
 TBZ_DEV void dist_base_extra(u32 d /* 0..29 */, u32& base, u32& extra) {
-  if (d < 4) {
-    base = 1 + d;
-    extra = 0;
-  } else {
-    extra = (d >> 1) - 1;
-    base = 1 + ((2 + (d & 1)) << extra);
-  }
+  u32 e = (d >> 1) - 1;
+  u32 b = 1 + ((2 + (d & 1)) << (e & 15));
+  bool small = d < 4;
+  extra = small ? 0 : e;
+  base = small ? 1 + d : b;
 }
 
 // canonical-code state of the lengths above the fast root, kept in registers
 template <int FAST>
 struct LongCodes {
   u32 lim[15 - FAST];  // first[L] + count[L]   (0 when no code has this length)
-  u32 dlt[15 - FAST];  // offs[L] - first[L]    (mod 2^32)
+  u32 dlt[15 - FAST];  // offs[L] - first[L]    (mod 2^32): symbol slot = code + dlt
   u32 min_len;         // shortest code length = width of the reference's root table (huffman-tree.lisp:144)
+  u32 nshort;          // symbols whose code fits the root (their slots come first in canonical order)
+};
+
+// where the canonical-order symbol list of an alphabet lives
+struct SortedStore {
+  u16* glob;            // global scratch (whole list), or null
+  u16 (*lds16)[64];     // LDS copy of the slots >= nshort (lit/len long codes), or null
+  u8 (*lds8)[64];       // LDS copy of all slots (distance), or null
+  u32 cap16;
 };
 
 // Per-lane canonical-Huffman table build.  `lens` (global scratch) holds n code lengths 0..15.
 // Acceptance rules of build-tree-part (huffman-tree.lisp:112-122): over-subscribed -> error;
 // incomplete -> error unless at most one symbol is coded; all-zero -> table of holes.
 template <int FAST>
-TBZ_DEV i32 build_table(const u8* lens, u32 n, u16 (*fast)[64], u16 (*tmp)[64], u16* sorted, LongCodes<FAST>& lc) {
+TBZ_DEV i32 build_table(const u8* lens, u32 n, u16 (*fast)[64], u16 (*tmp)[64], const SortedStore& ss,
+                        LongCodes<FAST>& lc) {
   const u32 lane = tbz_lane();
 #pragma unroll
   for (int L = 0; L < 16; L++) tmp[L][lane] = 0;
@@ -333,6 +380,7 @@ TBZ_DEV i32 build_table(const u8* lens, u32 n, u16 (*fast)[64], u16 (*tmp)[64], 
   u32 used = 0, code = 0, off = 0, prev = 0;
   i32 left = 1, err = 0;
   lc.min_len = 0;
+  lc.nshort = 0;
 #pragma unroll
   for (int L = 1; L < 16; L++) {
     u32 c = tmp[L][lane];
@@ -343,13 +391,14 @@ TBZ_DEV i32 build_table(const u8* lens, u32 n, u16 (*fast)[64], u16 (*tmp)[64], 
     if (c && !lc.min_len) lc.min_len = L;
     code = (code + prev) << 1;  // first canonical code of length L
     prev = c;
-    tmp[L][lane] = (u16)off;                 // next free slot in `sorted`
-    tmp[16 + L][lane] = (u16)(code - off);   // code = slot + this   (mod 2^16; codes are < 2^15)
+    tmp[L][lane] = (u16)off;                // next free slot in canonical order
+    tmp[16 + L][lane] = (u16)(code - off);  // code = slot + this   (mod 2^16; codes are < 2^15)
     if (L > FAST) {
       lc.lim[L - FAST - 1] = c ? code + c : 0;
       lc.dlt[L - FAST - 1] = off - code;
     }
     off += c;
+    if (L == FAST) lc.nshort = off;
   }
   if (!err && left > 0 && used > 1) err = E_INCOMPLETE;
   if (err) return err;
@@ -360,13 +409,16 @@ TBZ_DEV i32 build_table(const u8* lens, u32 n, u16 (*fast)[64], u16 (*tmp)[64], 
     u32 slot = tmp[l][lane];
     tmp[l][lane] = (u16)(slot + 1);
     u32 cd = (slot + tmp[16 + l][lane]) & 0xffff;
-    sorted[slot] = (u16)i;
+    if (ss.glob) ss.glob[slot] = (u16)i;
+    if (ss.lds8) ss.lds8[slot & 31][lane] = (u8)i;
     u32 rev = tbz_brev32(cd) >> (32 - l);
     if (l <= (u32)FAST) {
       u16 ent = (u16)((i << 4) | l);
       for (u32 k = rev; k < (1u << FAST); k += (1u << l)) fast[k][lane] = ent;
     } else {
       fast[rev & ((1u << FAST) - 1)][lane] = (u16)FE_LONG;
+      u32 ls = slot - lc.nshort;
+      if (ss.lds16 && ls < ss.cap16) ss.lds16[ls][lane] = (u16)i;
     }
   }
   return 0;
@@ -374,25 +426,37 @@ TBZ_DEV i32 build_table(const u8* lens, u32 n, u16 (*fast)[64], u16 (*tmp)[64], 
 
 // canonical decode of a code longer than the root index: returns (sym << 4) | L, or FE_HOLE
 template <int FAST>
-TBZ_DEV u32 decode_long(u32 peek, const u16* sorted, const LongCodes<FAST>& lc) {
+TBZ_DEV u32 decode_long(u32 peek, const SortedStore& ss, const LongCodes<FAST>& lc) {
   u32 r = tbz_brev32(peek);
-  u32 ent = FE_HOLE;
+  u32 slot = 0, len = 0;
 #pragma unroll
-  for (int k = 0; k < 15 - FAST; k++) {
+  for (int k = 15 - FAST - 1; k >= 0; k--) {  // longest first, so the shortest matching length wins
     const u32 L = FAST + 1 + k;
     u32 cd = r >> (32 - L);
-    if (ent == FE_HOLE && cd < lc.lim[k]) ent = ((u32)sorted[(cd + lc.dlt[k]) & 0xffff] << 4) | L;
+    bool hit = cd < lc.lim[k];
+    slot = hit ? cd + lc.dlt[k] : slot;
+    len = hit ? L : len;
   }
-  return ent;
+  if (len == 0) return FE_HOLE;
+  slot &= 0xffff;
+  u32 sym;
+  if (ss.lds8) {
+    sym = ss.lds8[slot & 31][tbz_lane()];
+  } else {
+    u32 ls = slot - lc.nshort;
+    if (ls < ss.cap16) sym = ss.lds16[ls][tbz_lane()];
+    else sym = ss.glob[slot];  // more long codes than the LDS list holds (not seen on text; kept for correctness)
+  }
+  return (sym << 4) | len;
 }
 
 struct K1State {
   BitReader br;
   u64 end_bit, limit_bit;
   u64 produced;  // octets the tokens emitted so far produce
-  u64 ntok;      // token words written
   u64 fail_pos;  // bit position reported on underrun / overshoot
-  u16* tok;      // this item's token region
+  u16* tok;      // next token word of this item
+  u16* tok0;
   u32 deficit;
 };
 
@@ -414,14 +478,18 @@ struct K1Tables {
   LongCodes<FAST_LIT> ll;
   LongCodes<FAST_DIST> ld;
 };
+TBZ_DEV u16 (*k1_tmp(K1Lds& S))[64] { return (u16(*)[64])S.inbuf; }
+TBZ_DEV SortedStore k1_ss_lit(K1Lds& S, u8* sc) { return SortedStore{(u16*)(sc + K1_SC_SLIT), S.slong, nullptr, K1_SLONG}; }
+TBZ_DEV SortedStore k1_ss_dist(K1Lds& S) { return SortedStore{nullptr, nullptr, S.sdist, 0}; }
 
 // fixed (BTYPE=1) code lengths: huffman-tree.lisp:89-97
-TBZ_DEV i32 k1_build_fixed(K1Lds& S, K1Tables& T, u8* sc) {
+TBZ_DEV i32 k1_build_fixed(K1Lds& S, K1State& st, K1Tables& T, u8* sc) {
+  st.br.bw = 1ull << 62;  // the table builders use the window's LDS as scratch
   u8* lens = sc + K1_SC_LENS;
   for (u32 i = 0; i < 320; i++) lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5;
-  i32 e = build_table<FAST_LIT>(lens, 288, S.lit, S.tmp, (u16*)(sc + K1_SC_SLIT), T.ll);
+  i32 e = build_table<FAST_LIT>(lens, 288, S.lit, k1_tmp(S), k1_ss_lit(S, sc), T.ll);
   if (e) return e;
-  return build_table<FAST_DIST>(lens + 288, 32, S.dist, S.tmp, (u16*)(sc + K1_SC_SDIST), T.ld);
+  return build_table<FAST_DIST>(lens + 288, 32, S.dist, k1_tmp(S), k1_ss_dist(S), T.ld);
 }
 
 // :dynamic-huffman-block … :dht-len-table-data (deflate.lisp:577-669)
@@ -440,8 +508,11 @@ TBZ_DEV i32 k1_dynamic_header(K1Lds& S, K1State& st, K1Tables& T, u8* sc) {
     lens[c_cl_order[i]] = (u8)v;
   }
   K1_CHECK(p0);
+  // the window's LDS is scratch for the three table builds below: carry on from registers/memory
+  // (a header is ~60 octets) and let the token loop reload it
+  st.br.bw = 1ull << 62;
   LongCodes<FAST_CL> lcl;  // max code length is 7: never consulted
-  i32 e = build_table<FAST_CL>(lens, 19, S.lit, S.tmp, (u16*)(sc + K1_SC_SCL), lcl);
+  i32 e = build_table<FAST_CL>(lens, 19, S.lit, k1_tmp(S), SortedStore{(u16*)(sc + K1_SC_SCL), nullptr, nullptr, 0}, lcl);
   if (e) return e;
   const u32 n = hlit + hdist;
   u32 i = 0, last = 0xff;
@@ -458,7 +529,7 @@ TBZ_DEV i32 k1_dynamic_header(K1Lds& S, K1State& st, K1Tables& T, u8* sc) {
       return E_INVALID_CODE;
     }
     u32 xb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
-    u32 x = bfe(pk, L, xb);
+    u32 x = tbz_bfe(pk, L, xb);
     br_skip(st.br, L + xb);
     K1_CHECK(ps);
     if (sym < 16) {
@@ -480,82 +551,143 @@ TBZ_DEV i32 k1_dynamic_header(K1Lds& S, K1State& st, K1Tables& T, u8* sc) {
       i += rep;
     }
   }
-  e = build_table<FAST_LIT>(lens, hlit, S.lit, S.tmp, (u16*)(sc + K1_SC_SLIT), T.ll);
+  e = build_table<FAST_LIT>(lens, hlit, S.lit, k1_tmp(S), k1_ss_lit(S, sc), T.ll);
   if (e) return e;
-  return build_table<FAST_DIST>(lens + hlit, hdist, S.dist, S.tmp, (u16*)(sc + K1_SC_SDIST), T.ld);
+  return build_table<FAST_DIST>(lens + hlit, hdist, S.dist, k1_tmp(S), k1_ss_dist(S), T.ld);
 }
 
-// :decode-compressed-data (deflate.lisp:673-702): returns 0 at end-of-block
-TBZ_DEV i32 k1_decode_block(K1Lds& S, K1State& st, const K1Tables& T, const u8* sc) {
+// :decode-compressed-data (deflate.lisp:673-702): returns 0 at end-of-block.
+//
+// Structure: phases.  A phase reloads the lane's 64-word LDS window at the current position and then
+// decodes tokens out of it with 32-bit phase-local state until the window runs low.  The two loops
+// are nested ON PURPOSE: lanes leave the inner loop at different times and the wave reconverges at
+// the reload, so the 64 lanes reload together once per ~100-200 tokens instead of one lane or other
+// stalling the wave every iteration.
+TBZ_DEV i32 k1_decode_block(K1Lds& S, K1State& st, const K1Tables& T, u8* sc) {
   const u32 lane = tbz_lane();
-  const u16* slit = (const u16*)(sc + K1_SC_SLIT);
-  const u16* sdist = (const u16*)(sc + K1_SC_SDIST);
+  const SortedStore ssl = k1_ss_lit(S, sc), ssd = k1_ss_dist(S);
+  enum { RUN = 0, DONE_EOB, FAIL_LIMIT, FAIL_CODE_LIT, FAIL_CODE_DIST, FAIL_SYM };
   for (;;) {
-    const u64 p0 = st.br.pos;
-    u32 pk = br_peek(st.br);
-    u32 ent = S.lit[pk & ((1u << FAST_LIT) - 1)][lane];
-    if ((ent & 15) == 0) {
-      if (ent == FE_LONG) ent = decode_long<FAST_LIT>(pk, slit, T.ll);
+    br_refill(st.br);
+    BitReader& B = st.br;
+    u32 lo = B.lo, hi = B.hi, nx = B.nx, o = B.o;
+    u32 k = 3;  // window slot of the word after nx
+    // bits this item may still consume before underrun / overshoot (saturated; a phase uses < 2^12)
+    u64 lim64 = st.end_bit < st.limit_bit ? st.end_bit : st.limit_bit;
+    i32 rem = lim64 <= B.pos ? 0 : ((lim64 - B.pos) > 0x7fffff00ull ? 0x7fffff00 : (i32)(lim64 - B.pos));
+    const i32 rem_start = rem;
+    i32 rem_tok = rem;  // value of rem when the current token started
+    u32 hist = st.produced > 32768 ? 32768u : (u32)st.produced;  // history available inside this item (saturated)
+    u32 prod = 0;       // octets produced in this phase
+    u32 deficit = st.deficit;
+    u16* tp = st.tok;
+    u32 why = RUN, bad_bits = 0;
+
+#define K1_SKIP(n)          \
+  do {                      \
+    o += (n);               \
+    rem -= (i32)(n);        \
+    if (o >= 32) {          \
+      o -= 32;              \
+      lo = hi;              \
+      hi = nx;              \
+      nx = B.buf[k][lane];  \
+      k++;                  \
+    }                       \
+  } while (0)
+
+    while (k < K1_INBUF - 3) {  // a token takes at most 3 window words
+      rem_tok = rem;
+      u32 pk = tbz_alignbit(hi, lo, o);
+      u32 ent = S.lit[pk & ((1u << FAST_LIT) - 1)][lane];
       if ((ent & 15) == 0) {
-        if (st.br.pos + T.ll.min_len > st.end_bit) {
-          st.fail_pos = p0;
-          return SEG_UNDERRUN;
+        if (ent == FE_LONG) ent = decode_long<FAST_LIT>(pk, ssl, T.ll);
+        if ((ent & 15) == 0) {
+          why = FAIL_CODE_LIT;
+          break;
         }
-        return E_INVALID_CODE;
       }
-    }
-    u32 L = ent & 15, sym = ent >> 4;
-    if (sym < 256) {
-      br_skip(st.br, L);
-      K1_CHECK(p0);
-      st.tok[st.ntok++] = (u16)sym;
-      st.produced += 1;
-    } else if (sym == 256) {  // end of block
-      br_skip(st.br, L);
-      K1_CHECK(p0);
-      return 0;
-    } else {
-      if (sym > 285) {  // 286/287 are coded but may not be used (huffman-tree.lisp:176-177)
-        br_skip(st.br, L);
-        K1_CHECK(p0);
-        return E_INVALID_CODE;
-      }
-      u32 base, X;
-      len_base_extra(sym - 257, base, X);
-      u32 len = base + bfe(pk, L, X);
-      br_skip(st.br, L + X);
-      u32 pd = br_peek(st.br);
-      u32 de = S.dist[pd & ((1u << FAST_DIST) - 1)][lane];
-      if ((de & 15) == 0) {
-        if (de == FE_LONG) de = decode_long<FAST_DIST>(pd, sdist, T.ld);
+      u32 L = ent & 15, sym = ent >> 4;
+      if (sym < 256) {
+        K1_SKIP(L);
+        if (rem < 0) { why = FAIL_LIMIT; break; }
+        *tp++ = (u16)sym;
+        prod += 1;
+      } else if (sym == 256) {  // end of block
+        K1_SKIP(L);
+        if (rem < 0) { why = FAIL_LIMIT; break; }
+        why = DONE_EOB;
+        break;
+      } else {
+        if (sym > 285) {  // 286/287 are coded but may not be used (huffman-tree.lisp:176-177)
+          K1_SKIP(L);
+          why = rem < 0 ? FAIL_LIMIT : FAIL_SYM;
+          break;
+        }
+        u32 base, X;
+        len_base_extra(sym - 257, base, X);
+        u32 len = base + tbz_bfe(pk, L, X);
+        K1_SKIP(L + X);
+        u32 pd = tbz_alignbit(hi, lo, o);
+        u32 de = S.dist[pd & ((1u << FAST_DIST) - 1)][lane];
         if ((de & 15) == 0) {
-          if (st.br.pos + T.ld.min_len > st.end_bit) {
-            st.fail_pos = p0;
-            return SEG_UNDERRUN;
+          if (de == FE_LONG) de = decode_long<FAST_DIST>(pd, ssd, T.ld);
+          if ((de & 15) == 0) {
+            why = FAIL_CODE_DIST;
+            break;
           }
-          return E_INVALID_CODE;
         }
+        u32 DL = de & 15, ds = de >> 4;
+        if (ds > 29) {  // 30/31 (huffman-tree.lisp:172-175)
+          K1_SKIP(DL);
+          why = rem < 0 ? FAIL_LIMIT : FAIL_SYM;
+          break;
+        }
+        u32 dbase, DX;
+        dist_base_extra(ds, dbase, DX);
+        u32 dist = dbase + tbz_bfe(pd, DL, DX);
+        K1_SKIP(DL + DX);
+        if (rem < 0) { why = FAIL_LIMIT; break; }
+        u32 h = hist + prod;
+        h = h > 32768 ? 32768 : h;
+        if (dist > h) {
+          u32 d = dist - h;
+          deficit = d > deficit ? d : deficit;
+        }
+        tp[0] = (u16)(TOK_MATCH | (len - 3));
+        tp[1] = (u16)(dist - 1);
+        tp += 2;
+        prod += len;
       }
-      u32 DL = de & 15, ds = de >> 4;
-      if (ds > 29) {  // 30/31 (huffman-tree.lisp:172-175)
-        br_skip(st.br, DL);
-        K1_CHECK(p0);
-        return E_INVALID_CODE;
-      }
-      u32 dbase, DX;
-      dist_base_extra(ds, dbase, DX);
-      u32 dist = dbase + bfe(pd, DL, DX);
-      br_skip(st.br, DL + DX);
-      K1_CHECK(p0);
-      if ((u64)dist > st.produced) {
-        u32 d = dist - (u32)st.produced;
-        if (d > st.deficit) st.deficit = d;
-      }
-      st.tok[st.ntok] = (u16)(TOK_MATCH | (len - 3));
-      st.tok[st.ntok + 1] = (u16)(dist - 1);
-      st.ntok += 2;
-      st.produced += len;
     }
+#undef K1_SKIP
+    // ---- write the phase back into the 64-bit state
+    u32 used = (u32)(rem_start - rem);      // bits consumed in this phase (also counts the failed token's)
+    u32 tok_bits = (u32)(rem_tok - rem);    // … of which belong to the token in flight at a failure
+    B.pos += used;
+    B.wi += k - 3;
+    B.lo = lo;
+    B.hi = hi;
+    B.nx = nx;
+    B.o = o;
+    st.tok = tp;
+    st.produced += prod;
+    st.deficit = deficit;
+    if (why == RUN) continue;  // window exhausted: next phase
+    if (why == DONE_EOB) return 0;
+    const u64 p0 = B.pos - tok_bits;  // where the failing token started
+    if (why == FAIL_LIMIT) {
+      st.fail_pos = p0;
+      return B.pos > st.end_bit ? SEG_UNDERRUN : SEG_OVERSHOOT;
+    }
+    if (why == FAIL_SYM) return E_INVALID_CODE;
+    // an unassigned bit pattern: error unless the input ends inside the bits the reference would need
+    bad_bits = why == FAIL_CODE_LIT ? T.ll.min_len : T.ld.min_len;
+    if (B.pos + bad_bits > st.end_bit) {
+      st.fail_pos = p0;
+      return SEG_UNDERRUN;
+    }
+    return E_INVALID_CODE;
   }
 }
 
@@ -642,14 +774,14 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
   u8* sc = P.scratch + (u64)idx * K1_SCRATCH;
   K1State st;
   K1Tables T;
-  br_init(st.br, P.in_base, it.end_byte);
+  br_init(st.br, P.in_base, it.end_byte, S.inbuf);
   br_seek(st.br, it.start_bit);
   st.end_bit = it.end_byte * 8;
   st.limit_bit = fixup ? ~0ull : it.limit_bit;
   st.produced = 0;
-  st.ntok = 0;
   st.deficit = 0;
-  st.tok = P.tok + it.start_bit;
+  st.tok0 = P.tok + it.start_bit;
+  st.tok = st.tok0;
   st.fail_pos = it.start_bit;
 
   i32 status = 0;
@@ -662,7 +794,7 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
   while (status == 0) {
     blk_pos = st.br.pos;
     blk_prod = st.produced;
-    blk_tok = st.ntok;
+    blk_tok = (u64)(st.tok - st.tok0);
     u32 pk = br_peek(st.br);
     br_skip(st.br, 3);
     if (st.br.pos > st.end_bit) { st.fail_pos = blk_pos; status = SEG_UNDERRUN; break; }
@@ -681,11 +813,11 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
       u64 avail = it.end_byte - byte0;
       u32 ncopy = avail < LEN ? (u32)avail : LEN;
       if (ncopy) {  // one stored-run token: K2 copies the octets straight from the input
-        st.tok[st.ntok] = (u16)(TOK_STORED | (ncopy & 0x3fff));
-        st.tok[st.ntok + 1] = (u16)((ncopy >> 14) | ((u32)(byte0 & 0x1fff) << 2));
-        st.tok[st.ntok + 2] = (u16)((byte0 >> 13) & 0x7fff);
-        st.tok[st.ntok + 3] = (u16)((byte0 >> 28) & 0x7fff);
-        st.ntok += 4;
+        st.tok[0] = (u16)(TOK_STORED | (ncopy & 0x3fff));
+        st.tok[1] = (u16)((ncopy >> 14) | ((u32)(byte0 & 0x1fff) << 2));
+        st.tok[2] = (u16)((byte0 >> 13) & 0x7fff);
+        st.tok[3] = (u16)((byte0 >> 28) & 0x7fff);
+        st.tok += 4;
         st.produced += ncopy;
       }
       if (ncopy < LEN) { st.fail_pos = (byte0 + ncopy) * 8; status = SEG_UNDERRUN; break; }
@@ -696,7 +828,7 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
     } else {
       if (btype == 1) {
         if (tables != 1) {
-          status = k1_build_fixed(S, T, sc);
+          status = k1_build_fixed(S, st, T, sc);
           tables = 1;
         }
       } else {
@@ -755,7 +887,7 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
   } else {
     r.end_bit = (status == SEG_UNDERRUN) ? st.fail_pos : st.br.pos;
     r.out_bytes = st.produced;
-    r.tok_words = st.ntok;
+    r.tok_words = (u64)(st.tok - st.tok0);
   }
   r.status = status;
   r.max_deficit = st.deficit;
@@ -784,6 +916,7 @@ constexpr u32 K2_WIN = 36864;   // 32 KiB history + one batch span + slack; mult
 constexpr u32 K2_SPAN = 3072;   // max octets one batch may produce (cut otherwise)
 constexpr u32 K2_FLUSH = 8192;  // flush the ring to HBM every this many octets
 constexpr u32 K2_SHORT = 16;    // matches up to this length are copied by their own lane
+constexpr u32 K2_TOKBUF = 2048; // token words staged in LDS per load (one memory round trip per ~32 batches)
 
 struct K2Params {
   const u16* tok;
@@ -840,6 +973,7 @@ TBZ_DEV void k2_copy_coop(u8* win, u32 rd, u32 dd, u32 l) {
 
 TBZ_KERNEL void tbz_k2_lz77(K2Params P) {
   TBZ_SHARED __attribute__((aligned(16))) u8 win[K2_WIN];
+  TBZ_SHARED u16 tks[K2_TOKBUF];
   if (tbz_block() >= P.n_groups) return;
   const u32 lane = tbz_lane();
   const u64 lane_bit = 1ull << lane;
@@ -853,10 +987,18 @@ TBZ_KERNEL void tbz_k2_lz77(K2Params P) {
   for (u32 s = 0; s < g.seg_count && pos < clip; s++) {
     const Seg sg = P.segs[g.seg_first + s];
     u64 p = 0;
+    u64 tb = ~0ull;  // segment-relative index of tks[0]; ~0 = nothing staged
     while (p < sg.tok_words && pos < clip) {
       u64 left = sg.tok_words - p;
       u32 n = left < 64 ? (u32)left : 64;
-      u32 w = lane < n ? P.tok[sg.tok_index + p + lane] : 0;
+      if (tb == ~0ull || p + n > tb + K2_TOKBUF) {  // stage the next K2_TOKBUF words, coalesced
+        tbz_sync();
+        tb = p;
+        u64 cnt = left < K2_TOKBUF ? left : K2_TOKBUF;
+        for (u32 k = lane; k < (u32)cnt; k += 64) tks[k] = P.tok[sg.tok_index + p + k];
+        tbz_sync();
+      }
+      u32 w = lane < n ? tks[(u32)(p - tb) + lane] : 0;
       const u64 valid = n == 64 ? ~0ull : ((1ull << n) - 1);
       u64 hb = tbz_ballot((w & 0x8000u) != 0) & valid;            // heads (payload words have bit 15 clear)
       u64 sb = tbz_ballot((w & 0xC000u) == 0xC000u) & valid;      // stored-run heads

@@ -61,6 +61,10 @@ TBZ_DEV u32 tbz_brev32(u32 v) { return __brev(v); }
 TBZ_DEV u32 tbz_clz32(u32 v) { return (u32)__clz((int)v); }
 TBZ_DEV u32 tbz_atomic_add_lds(u32* p, u32 v) { return atomicAdd(p, v); }
 
+// 32 bits of the 64-bit value hi:lo starting at bit o (o < 32): one v_alignbit_b32
+TBZ_DEV u32 tbz_alignbit(u32 hi, u32 lo, u32 o) { return __builtin_amdgcn_alignbit(hi, lo, o); }
+// n bits of v starting at bit off (n = 0 gives 0): one v_bfe_u32
+TBZ_DEV u32 tbz_bfe(u32 v, u32 off, u32 n) { return __builtin_amdgcn_ubfe(v, off, n); }
 // value of lane `i` (i wave-uniform): v_readlane, no LDS round trip
 TBZ_DEV u32 tbz_readlane(u32 v, u32 i) { return (u32)__builtin_amdgcn_readlane((int)v, (int)i); }
 // whole-wave shift by one lane through DPP (no LDS): shr1: lane i <- lane i-1 (lane 0 <- 0);

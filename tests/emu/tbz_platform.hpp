@@ -239,6 +239,8 @@ TBZ_DEV u32 tbz_brev32(u32 v) {
 TBZ_DEV u32 tbz_clz32(u32 v) { return v ? (u32)__builtin_clz(v) : 32; }
 TBZ_DEV u32 tbz_atomic_add_lds(u32* p, u32 v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
+TBZ_DEV u32 tbz_alignbit(u32 hi, u32 lo, u32 o) { return (u32)(((((u64)hi) << 32) | lo) >> (o & 31)); }
+TBZ_DEV u32 tbz_bfe(u32 v, u32 off, u32 n) { return n ? ((v >> (off & 31)) & (n >= 32 ? ~0u : ((1u << n) - 1))) : 0; }
 TBZ_DEV u32 tbz_readlane(u32 v, u32 i) { return (u32)tbz_emu::xchg(v, i); }
 TBZ_DEV u32 tbz_wave_shr1(u32 v) {
   u32 l = (u32)tbz_emu::st().cur;

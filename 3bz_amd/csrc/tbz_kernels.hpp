@@ -191,25 +191,19 @@ TBZ_KERNEL void tbz_k0_scan_emit(K0Params P) {
 // Everything the token loop touches is in registers or LDS — NO global loads inside it, because
 // vmcnt is a per-wave in-order counter: one lane's load makes all 64 lanes wait for every store in
 // flight (measured: a full memory round trip per iteration).
-//   - lookup tables in LDS, LANE-INTERLEAVED: entry i of lane l is element [i][l], so the bank is a
-//     function of the lane only and 64 random lookups never collide by index
-//   - lit/len: 8-bit root (256 x u16 per lane); longer codes: canonical search with the per-length
-//     limits in registers and the long-code symbols in LDS (`slong`)
-//   - distance: 5-bit root (32 x u16 per lane) + the 32 distance symbols in LDS (`sdist`)
-//   - compressed input: a 64-word LDS window per lane, reloaded by all lanes together once per
-//     phase (nested loops make the wave reconverge at the reload)
+//   - NO lookup tables: a fast table only pays if all 64 lanes hit it, which never happens (some lane
+//     always has a long code, so the wave always runs both paths), and it costs the LDS that limits
+//     occupancy.  Instead: canonical decode — the code length is 1 + #{L : r16 >= limit[L]} (fifteen
+//     register compares), the symbol comes from a compact per-lane list in LDS.  25.5 KiB per
+//     workgroup -> 6 workgroups = 384 decoders per CU
+//   - compressed input: a 24-word LDS window per lane, reloaded by all lanes together once per
+//     phase of 40 tokens (nested loops make the wave reconverge at the reload)
 //   - tokens are stored straight to the item's token region (consecutive u16 per lane, merged in L2);
 //     stores need no wait
 // Replaces deflate.lisp:518-702 + huffman-tree.lisp:99-218 (same acceptance rules and errors).
 // ================================================================================================
 
 TBZ_CONSTANT u8 c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-
-constexpr int FAST_LIT = 8, FAST_DIST = 5, FAST_CL = 7;
-// u16 fast-table entry: [3:0] code length L (0 = special), [15:4] symbol.
-//   L = 0, symbol 0 : unassigned pattern (hole of an incomplete code)      -> invalid
-//   L = 0, symbol 1 : code longer than the root index                       -> canonical path
-constexpr u32 FE_HOLE = 0x0000, FE_LONG = 0x0010;
 
 // token words (u16):
 //   0x00bb                      literal octet
@@ -219,20 +213,25 @@ constexpr u32 FE_HOLE = 0x0000, FE_LONG = 0x0010;
 // payload words always have bit 15 clear, so a word with bit 15 set is always a head.
 constexpr u32 TOK_MATCH = 0x8000u, TOK_STORED = 0xC000u;
 
-constexpr u32 K1_SCRATCH = 1024;  // octets of global scratch per item: lens[320] | sorted_lit u16[288] | spare
-constexpr u32 K1_SC_LENS = 0, K1_SC_SLIT = 320, K1_SC_SCL = 960;
-constexpr u32 K1_INBUF = 64;      // 32-bit words of compressed input windowed per lane (256 octets)
-constexpr u32 K1_SLONG = 128;     // long-code literal/length symbols held in LDS per lane (the rest: global scratch)
+constexpr u32 K1_SCRATCH = 1024;  // octets of global scratch per item: lens[320] | overflow symbols u16[288] | spare
+constexpr u32 K1_SC_LENS = 0, K1_SC_SLIT = 320;
+constexpr u32 K1_INBUF = 24;      // 32-bit words of compressed input windowed per lane (96 octets)
+constexpr u32 K1_PHASE = 40;      // tokens decoded per phase between window reloads
+constexpr u32 K1_LCAP = 192;      // lit/len symbols (canonical order) held in LDS per lane; the rest: global scratch
 
+// Per-workgroup LDS, every array LANE-INTERLEAVED ([index][lane]): the bank depends on the lane only, so
+// 64 lanes reading 64 different indices never conflict beyond the 2-lanes-per-dword sharing of the
+// narrow types.  25.5 KiB -> 6 workgroups (384 decoders) per CU.
 struct K1Lds {
-  u16 lit[1 << FAST_LIT][64];    // 32 KiB (also hosts the 7-bit code-length-code table while a header is parsed)
-  u16 slong[K1_SLONG][64];       // 16 KiB: lit/len symbols whose code is longer than the root, canonical order
-  u16 dist[1 << FAST_DIST][64];  // 4 KiB
-  u8 sdist[32][64];              // 2 KiB: distance symbols in canonical order
-  u32 inbuf[K1_INBUF][64];       // 16 KiB: per-lane window of the compressed stream; its first 4 KiB double as the
-                                 //         per-lane counters while a table is built (the window is reloaded after)
+  u8 lsym8[K1_LCAP][64];        // 12 KiB   lit/len symbols in canonical order, low 8 bits
+  u32 lbit8[K1_LCAP / 32][64];  // 1.5 KiB  … bit 8 (end-of-block and length symbols)
+  u16 ldlt[16][64];             // 2 KiB    lit/len: slot = code + ldlt[len]
+  u8 dsym8[32][64];             // 2 KiB    distance symbols in canonical order (also the code-length code's)
+  u16 ddlt[16][64];             // 2 KiB
+  u32 inbuf[K1_INBUF][64];      // 6 KiB    per-lane window of the compressed stream; its first 4 KiB double as
+                                //          the per-lane counters while a code is built (the window is reloaded after)
 };
-static_assert(sizeof(K1Lds) <= 80 * 1024, "two K1 workgroups must fit one CU's 160 KiB LDS");
+static_assert(sizeof(K1Lds) <= 26 * 1024, "six K1 workgroups must fit one CU's 160 KiB LDS");
 
 struct K1Params {
   const u8* in_base;
@@ -347,29 +346,32 @@ TBZ_DEV void dist_base_extra(u32 d /* 0..29 */, u32& base, u32& extra) {
   base = small ? 1 + d : b;
 }
 
-// canonical-code state of the lengths above the fast root, kept in registers
-template <int FAST>
-struct LongCodes {
-  u32 lim[15 - FAST];  // first[L] + count[L]   (0 when no code has this length)
-  u32 dlt[15 - FAST];  // offs[L] - first[L]    (mod 2^32): symbol slot = code + dlt
-  u32 min_len;         // shortest code length = width of the reference's root table (huffman-tree.lisp:144)
-  u32 nshort;          // symbols whose code fits the root (their slots come first in canonical order)
+// Canonical code of one alphabet, per lane.  lim[L-1] = (first code of length L + number of codes of
+// length L) left-aligned to 16 bits; the sequence is non-decreasing in L, so for the first 16 stream
+// bits r16 (MSB-first) the code length is 1 + #{L : r16 >= lim[L-1]} — fifteen compares, no table.
+// 16 means "no code starts like this" (a hole of an incomplete code, or an empty alphabet).
+struct Canon {
+  u32 lim[15];
+  u32 min_len;  // shortest code length = width of the reference's root table (huffman-tree.lisp:144)
 };
 
-// where the canonical-order symbol list of an alphabet lives
-struct SortedStore {
-  u16* glob;            // global scratch (whole list), or null
-  u16 (*lds16)[64];     // LDS copy of the slots >= nshort (lit/len long codes), or null
-  u8 (*lds8)[64];       // LDS copy of all slots (distance), or null
-  u32 cap16;
+// where an alphabet's per-lane decode data lives (all LDS except the overflow list)
+struct CanonStore {
+  u16 (*dlt)[64];   // [16][64]: slot in canonical order = (code of length L) + dlt[L]   (mod 2^16)
+  u8 (*sym8)[64];   // [cap][64]: low 8 bits of the symbol at each slot
+  u32 (*bit8)[64];  // [cap/32][64]: bit 8 of the symbol at each slot (null: symbols < 256)
+  u16* glob;        // global scratch: symbols of slots >= cap (null: cap covers the alphabet)
+  u32 cap;
 };
 
-// Per-lane canonical-Huffman table build.  `lens` (global scratch) holds n code lengths 0..15.
+// out of line on purpose: if this load is visible next to the LDS reads the compiler if-converts them
+// into one flat_load + vmcnt(0), which stalls the wave on every token store in flight
+TBZ_DEV_NOINLINE u32 k1_sorted_global(const u16* p, u32 slot) { return p[slot]; }
+
+// Per-lane canonical-Huffman build.  `lens` (global scratch) holds n code lengths 0..15.
 // Acceptance rules of build-tree-part (huffman-tree.lisp:112-122): over-subscribed -> error;
-// incomplete -> error unless at most one symbol is coded; all-zero -> table of holes.
-template <int FAST>
-TBZ_DEV i32 build_table(const u8* lens, u32 n, u16 (*fast)[64], u16 (*tmp)[64], const SortedStore& ss,
-                        LongCodes<FAST>& lc) {
+// incomplete -> error unless at most one symbol is coded; all-zero -> every pattern is a hole.
+TBZ_DEV i32 build_canon(const u8* lens, u32 n, u16 (*tmp)[64], const CanonStore& cs, Canon& cn) {
   const u32 lane = tbz_lane();
 #pragma unroll
   for (int L = 0; L < 16; L++) tmp[L][lane] = 0;
@@ -379,8 +381,7 @@ TBZ_DEV i32 build_table(const u8* lens, u32 n, u16 (*fast)[64], u16 (*tmp)[64], 
   }
   u32 used = 0, code = 0, off = 0, prev = 0;
   i32 left = 1, err = 0;
-  lc.min_len = 0;
-  lc.nshort = 0;
+  cn.min_len = 0;
 #pragma unroll
   for (int L = 1; L < 16; L++) {
     u32 c = tmp[L][lane];
@@ -388,66 +389,51 @@ TBZ_DEV i32 build_table(const u8* lens, u32 n, u16 (*fast)[64], u16 (*tmp)[64], 
     if ((i32)c > left && !err) err = E_OVERSUB;
     left -= (i32)c;
     used += c;
-    if (c && !lc.min_len) lc.min_len = L;
+    if (c && !cn.min_len) cn.min_len = L;
     code = (code + prev) << 1;  // first canonical code of length L
     prev = c;
-    tmp[L][lane] = (u16)off;                // next free slot in canonical order
-    tmp[16 + L][lane] = (u16)(code - off);  // code = slot + this   (mod 2^16; codes are < 2^15)
-    if (L > FAST) {
-      lc.lim[L - FAST - 1] = c ? code + c : 0;
-      lc.dlt[L - FAST - 1] = off - code;
-    }
+    tmp[L][lane] = (u16)off;            // next free slot in canonical order
+    cs.dlt[L][lane] = (u16)(off - code);
+    cn.lim[L - 1] = (code + c) << (16 - L);
     off += c;
-    if (L == FAST) lc.nshort = off;
   }
   if (!err && left > 0 && used > 1) err = E_INCOMPLETE;
   if (err) return err;
-  for (u32 i = 0; i < (1u << FAST); i++) fast[i][lane] = (u16)FE_HOLE;
+  if (cs.bit8)
+    for (u32 k = 0; k < cs.cap / 32; k++) cs.bit8[k][lane] = 0;
   for (u32 i = 0; i < n; i++) {
     u32 l = lens[i];
     if (!l) continue;
     u32 slot = tmp[l][lane];
     tmp[l][lane] = (u16)(slot + 1);
-    u32 cd = (slot + tmp[16 + l][lane]) & 0xffff;
-    if (ss.glob) ss.glob[slot] = (u16)i;
-    if (ss.lds8) ss.lds8[slot & 31][lane] = (u8)i;
-    u32 rev = tbz_brev32(cd) >> (32 - l);
-    if (l <= (u32)FAST) {
-      u16 ent = (u16)((i << 4) | l);
-      for (u32 k = rev; k < (1u << FAST); k += (1u << l)) fast[k][lane] = ent;
+    if (slot < cs.cap) {
+      cs.sym8[slot][lane] = (u8)i;
+      if (i >= 256) cs.bit8[slot >> 5][lane] |= 1u << (slot & 31);
     } else {
-      fast[rev & ((1u << FAST) - 1)][lane] = (u16)FE_LONG;
-      u32 ls = slot - lc.nshort;
-      if (ss.lds16 && ls < ss.cap16) ss.lds16[ls][lane] = (u16)i;
+      cs.glob[slot] = (u16)i;
     }
   }
   return 0;
 }
 
-// canonical decode of a code longer than the root index: returns (sym << 4) | L, or FE_HOLE
-template <int FAST>
-TBZ_DEV u32 decode_long(u32 peek, const SortedStore& ss, const LongCodes<FAST>& lc) {
-  u32 r = tbz_brev32(peek);
-  u32 slot = 0, len = 0;
+// decode one symbol from the 32 bits `pk` (LSB-first stream order).  Returns the code length (16 =
+// hole) and the symbol.
+TBZ_DEV u32 canon_decode(u32 pk, const Canon& cn, const CanonStore& cs, u32& sym) {
+  const u32 lane = tbz_lane();
+  u32 r16 = tbz_brev32(pk) >> 16;
+  u32 L = 1;
 #pragma unroll
-  for (int k = 15 - FAST - 1; k >= 0; k--) {  // longest first, so the shortest matching length wins
-    const u32 L = FAST + 1 + k;
-    u32 cd = r >> (32 - L);
-    bool hit = cd < lc.lim[k];
-    slot = hit ? cd + lc.dlt[k] : slot;
-    len = hit ? L : len;
-  }
-  if (len == 0) return FE_HOLE;
-  slot &= 0xffff;
-  u32 sym;
-  if (ss.lds8) {
-    sym = ss.lds8[slot & 31][tbz_lane()];
+  for (int k = 0; k < 15; k++) L += r16 >= cn.lim[k] ? 1u : 0u;
+  u32 slot = ((r16 >> (16 - (L & 15))) + cs.dlt[L & 15][lane]) & 0xffff;
+  u32 s;
+  if (slot < cs.cap) {
+    s = cs.sym8[slot][lane];
+    if (cs.bit8) s |= ((cs.bit8[slot >> 5][lane] >> (slot & 31)) & 1u) << 8;
   } else {
-    u32 ls = slot - lc.nshort;
-    if (ls < ss.cap16) sym = ss.lds16[ls][tbz_lane()];
-    else sym = ss.glob[slot];  // more long codes than the LDS list holds (not seen on text; kept for correctness)
+    s = (L < 16 && cs.glob) ? k1_sorted_global(cs.glob, slot) : 0;
   }
-  return (sym << 4) | len;
+  sym = s;
+  return L;
 }
 
 struct K1State {
@@ -475,26 +461,27 @@ struct K1State {
   } while (0)
 
 struct K1Tables {
-  LongCodes<FAST_LIT> ll;
-  LongCodes<FAST_DIST> ld;
+  Canon ll;  // literal/length alphabet
+  Canon ld;  // distance alphabet
 };
 TBZ_DEV u16 (*k1_tmp(K1Lds& S))[64] { return (u16(*)[64])S.inbuf; }
-TBZ_DEV SortedStore k1_ss_lit(K1Lds& S, u8* sc) { return SortedStore{(u16*)(sc + K1_SC_SLIT), S.slong, nullptr, K1_SLONG}; }
-TBZ_DEV SortedStore k1_ss_dist(K1Lds& S) { return SortedStore{nullptr, nullptr, S.sdist, 0}; }
+TBZ_DEV CanonStore k1_cs_lit(K1Lds& S, u8* sc) {
+  return CanonStore{S.ldlt, S.lsym8, S.lbit8, (u16*)(sc + K1_SC_SLIT), K1_LCAP};
+}
+TBZ_DEV CanonStore k1_cs_dist(K1Lds& S) { return CanonStore{S.ddlt, S.dsym8, nullptr, nullptr, 32}; }
 
 // fixed (BTYPE=1) code lengths: huffman-tree.lisp:89-97
 TBZ_DEV i32 k1_build_fixed(K1Lds& S, K1State& st, K1Tables& T, u8* sc) {
-  st.br.bw = 1ull << 62;  // the table builders use the window's LDS as scratch
+  st.br.bw = 1ull << 62;  // the builders use the window's LDS as scratch
   u8* lens = sc + K1_SC_LENS;
   for (u32 i = 0; i < 320; i++) lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5;
-  i32 e = build_table<FAST_LIT>(lens, 288, S.lit, k1_tmp(S), k1_ss_lit(S, sc), T.ll);
+  i32 e = build_canon(lens, 288, k1_tmp(S), k1_cs_lit(S, sc), T.ll);
   if (e) return e;
-  return build_table<FAST_DIST>(lens + 288, 32, S.dist, k1_tmp(S), k1_ss_dist(S), T.ld);
+  return build_canon(lens + 288, 32, k1_tmp(S), k1_cs_dist(S), T.ld);
 }
 
 // :dynamic-huffman-block … :dht-len-table-data (deflate.lisp:577-669)
 TBZ_DEV i32 k1_dynamic_header(K1Lds& S, K1State& st, K1Tables& T, u8* sc) {
-  const u32 lane = tbz_lane();
   const u64 p0 = st.br.pos;
   u32 pk = br_peek(st.br);
   u32 hlit = (pk & 31) + 257, hdist = ((pk >> 5) & 31) + 1, hclen = ((pk >> 10) & 15) + 4;
@@ -508,21 +495,23 @@ TBZ_DEV i32 k1_dynamic_header(K1Lds& S, K1State& st, K1Tables& T, u8* sc) {
     lens[c_cl_order[i]] = (u8)v;
   }
   K1_CHECK(p0);
-  // the window's LDS is scratch for the three table builds below: carry on from registers/memory
-  // (a header is ~60 octets) and let the token loop reload it
+  // the window's LDS is scratch for the table builds below: carry on from registers/memory (a header
+  // is ~60 octets) and let the token loop reload it.  The code-length code borrows the distance
+  // alphabet's LDS (the distance code is built after the lengths are read).
   st.br.bw = 1ull << 62;
-  LongCodes<FAST_CL> lcl;  // max code length is 7: never consulted
-  i32 e = build_table<FAST_CL>(lens, 19, S.lit, k1_tmp(S), SortedStore{(u16*)(sc + K1_SC_SCL), nullptr, nullptr, 0}, lcl);
+  Canon ccl;
+  const CanonStore cscl = k1_cs_dist(S);
+  i32 e = build_canon(lens, 19, k1_tmp(S), cscl, ccl);
   if (e) return e;
   const u32 n = hlit + hdist;
   u32 i = 0, last = 0xff;
   while (i < n) {
     const u64 ps = st.br.pos;
     pk = br_peek(st.br);
-    u32 ent = S.lit[pk & ((1u << FAST_CL) - 1)][lane];
-    u32 L = ent & 15, sym = ent >> 4;
-    if (L == 0) {  // unassigned pattern: error unless the input ends inside the root index
-      if (st.br.pos + lcl.min_len > st.end_bit) {
+    u32 sym;
+    u32 L = canon_decode(pk, ccl, cscl, sym);
+    if (L > 15) {  // unassigned pattern: error unless the input ends inside the root index
+      if (st.br.pos + ccl.min_len > st.end_bit) {
         st.fail_pos = ps;
         return SEG_UNDERRUN;
       }
@@ -551,21 +540,22 @@ TBZ_DEV i32 k1_dynamic_header(K1Lds& S, K1State& st, K1Tables& T, u8* sc) {
       i += rep;
     }
   }
-  e = build_table<FAST_LIT>(lens, hlit, S.lit, k1_tmp(S), k1_ss_lit(S, sc), T.ll);
+  e = build_canon(lens, hlit, k1_tmp(S), k1_cs_lit(S, sc), T.ll);
   if (e) return e;
-  return build_table<FAST_DIST>(lens + hlit, hdist, S.dist, k1_tmp(S), k1_ss_dist(S), T.ld);
+  return build_canon(lens + hlit, hdist, k1_tmp(S), k1_cs_dist(S), T.ld);
 }
 
 // :decode-compressed-data (deflate.lisp:673-702): returns 0 at end-of-block.
 //
-// Structure: phases.  A phase reloads the lane's 64-word LDS window at the current position and then
-// decodes tokens out of it with 32-bit phase-local state until the window runs low.  The two loops
-// are nested ON PURPOSE: lanes leave the inner loop at different times and the wave reconverges at
-// the reload, so the 64 lanes reload together once per ~100-200 tokens instead of one lane or other
-// stalling the wave every iteration.
+// Structure: phases.  A phase reloads the lane's LDS input window at the current position and then
+// decodes at most K1_PHASE tokens out of it with 32-bit phase-local state.  The two loops are nested ON
+// PURPOSE: the wave reconverges at the reload, so the 64 lanes reload together instead of one lane or
+// other stalling the wave on memory every iteration; and a phase is bounded by an iteration count (the
+// window is sized so that few lanes run out earlier), so lanes do not idle waiting for the slowest
+// consumer of bits.
 TBZ_DEV i32 k1_decode_block(K1Lds& S, K1State& st, const K1Tables& T, u8* sc) {
   const u32 lane = tbz_lane();
-  const SortedStore ssl = k1_ss_lit(S, sc), ssd = k1_ss_dist(S);
+  const CanonStore csl = k1_cs_lit(S, sc), csd = k1_cs_dist(S);
   enum { RUN = 0, DONE_EOB, FAIL_LIMIT, FAIL_CODE_LIT, FAIL_CODE_DIST, FAIL_SYM };
   for (;;) {
     br_refill(st.br);
@@ -581,7 +571,7 @@ TBZ_DEV i32 k1_decode_block(K1Lds& S, K1State& st, const K1Tables& T, u8* sc) {
     u32 prod = 0;       // octets produced in this phase
     u32 deficit = st.deficit;
     u16* tp = st.tok;
-    u32 why = RUN, bad_bits = 0;
+    u32 why = RUN;
 
 #define K1_SKIP(n)          \
   do {                      \
@@ -596,18 +586,15 @@ TBZ_DEV i32 k1_decode_block(K1Lds& S, K1State& st, const K1Tables& T, u8* sc) {
     }                       \
   } while (0)
 
-    while (k < K1_INBUF - 3) {  // a token takes at most 3 window words
+    for (u32 it = 0; it < K1_PHASE && k < K1_INBUF - 3; it++) {  // a token takes at most 3 window words
       rem_tok = rem;
       u32 pk = tbz_alignbit(hi, lo, o);
-      u32 ent = S.lit[pk & ((1u << FAST_LIT) - 1)][lane];
-      if ((ent & 15) == 0) {
-        if (ent == FE_LONG) ent = decode_long<FAST_LIT>(pk, ssl, T.ll);
-        if ((ent & 15) == 0) {
-          why = FAIL_CODE_LIT;
-          break;
-        }
+      u32 sym;
+      u32 L = canon_decode(pk, T.ll, csl, sym);
+      if (L > 15) {
+        why = FAIL_CODE_LIT;
+        break;
       }
-      u32 L = ent & 15, sym = ent >> 4;
       if (sym < 256) {
         K1_SKIP(L);
         if (rem < 0) { why = FAIL_LIMIT; break; }
@@ -629,15 +616,12 @@ TBZ_DEV i32 k1_decode_block(K1Lds& S, K1State& st, const K1Tables& T, u8* sc) {
         u32 len = base + tbz_bfe(pk, L, X);
         K1_SKIP(L + X);
         u32 pd = tbz_alignbit(hi, lo, o);
-        u32 de = S.dist[pd & ((1u << FAST_DIST) - 1)][lane];
-        if ((de & 15) == 0) {
-          if (de == FE_LONG) de = decode_long<FAST_DIST>(pd, ssd, T.ld);
-          if ((de & 15) == 0) {
-            why = FAIL_CODE_DIST;
-            break;
-          }
+        u32 ds;
+        u32 DL = canon_decode(pd, T.ld, csd, ds);
+        if (DL > 15) {
+          why = FAIL_CODE_DIST;
+          break;
         }
-        u32 DL = de & 15, ds = de >> 4;
         if (ds > 29) {  // 30/31 (huffman-tree.lisp:172-175)
           K1_SKIP(DL);
           why = rem < 0 ? FAIL_LIMIT : FAIL_SYM;
@@ -673,7 +657,7 @@ TBZ_DEV i32 k1_decode_block(K1Lds& S, K1State& st, const K1Tables& T, u8* sc) {
     st.tok = tp;
     st.produced += prod;
     st.deficit = deficit;
-    if (why == RUN) continue;  // window exhausted: next phase
+    if (why == RUN) continue;  // phase over: reload and go on
     if (why == DONE_EOB) return 0;
     const u64 p0 = B.pos - tok_bits;  // where the failing token started
     if (why == FAIL_LIMIT) {
@@ -682,7 +666,7 @@ TBZ_DEV i32 k1_decode_block(K1Lds& S, K1State& st, const K1Tables& T, u8* sc) {
     }
     if (why == FAIL_SYM) return E_INVALID_CODE;
     // an unassigned bit pattern: error unless the input ends inside the bits the reference would need
-    bad_bits = why == FAIL_CODE_LIT ? T.ll.min_len : T.ld.min_len;
+    u32 bad_bits = why == FAIL_CODE_LIT ? T.ll.min_len : T.ld.min_len;
     if (B.pos + bad_bits > st.end_bit) {
       st.fail_pos = p0;
       return SEG_UNDERRUN;
@@ -915,7 +899,7 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
 constexpr u32 K2_WIN = 36864;   // 32 KiB history + one batch span + slack; multiple of 16
 constexpr u32 K2_SPAN = 3072;   // max octets one batch may produce (cut otherwise)
 constexpr u32 K2_FLUSH = 8192;  // flush the ring to HBM every this many octets
-constexpr u32 K2_SHORT = 16;    // matches up to this length are copied by their own lane
+constexpr u32 K2_SHORT = 8;     // matches up to this length are copied by their own lane
 constexpr u32 K2_TOKBUF = 2048; // token words staged in LDS per load (one memory round trip per ~32 batches)
 
 struct K2Params {
@@ -1061,14 +1045,20 @@ TBZ_KERNEL void tbz_k2_lz77(K2Params P) {
         bool ready = (pend & lane_bit) && need <= hwm;
         u64 rdy = tbz_ballot(ready);
         u64 longs = tbz_ballot(ready && len > K2_SHORT);
-        if (ready && len <= K2_SHORT) {  // own-lane copy; an overlapping match repeats its dist-octet pattern
+        if (ready && len <= K2_SHORT) {
+          // own-lane copy.  An overlapping match repeats its dist-octet pattern, so every source octet
+          // is final already: read all of them first (independent LDS reads, one wait), then write.
+          u8 b[K2_SHORT];
           u32 jj = 0;
-          for (u32 j = 0; j < len; j++) {
-            u8 b = win[ring(rs + jj)];
-            win[ring(rd + j)] = b;
+#pragma unroll
+          for (u32 j = 0; j < K2_SHORT; j++) {
+            b[j] = j < len ? win[ring(rs + jj)] : 0;
             jj++;
             if (jj == dist) jj = 0;
           }
+#pragma unroll
+          for (u32 j = 0; j < K2_SHORT; j++)
+            if (j < len) win[ring(rd + j)] = b[j];
         }
         while (longs) {
           u32 i = (u32)tbz_ffs64(longs) - 1;

@@ -42,7 +42,7 @@ struct tbz_ctx {
   tbz_timings tim{};
   // device pools (grow-only)
   tbz::DevBuf d_str_off, d_str_len, d_tile_first, d_tile_counts, d_tile_offsets, d_markers, d_items, d_res,
-      d_tok, d_scratch, d_segs, d_groups, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
+      d_tok, d_scratch, d_segs, d_groups, d_order, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
       d_out_stage;
 };
 
@@ -491,9 +491,36 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if (!d_out) return TBZ_E_ARG;
     if ((r = upload(ctx, ctx->d_segs, h_segs))) return r;
     if ((r = upload(ctx, ctx->d_groups, h_groups))) return r;
+    // groups whose whole output fits a linear LDS window (the common case: flush-delimited segments)
+    // run with dynamic LDS sized to the largest of them; the rest take the 32 KiB-history ring kernel
+    std::vector<uint32_t> order_small, order_big;
+    uint64_t max_small = 0;
+    for (size_t gi = 0; gi < h_groups.size(); gi++) {
+      uint64_t tot = 0;
+      for (uint32_t k = 0; k < h_groups[gi].seg_count; k++) tot += h_segs[h_groups[gi].seg_first + k].out_bytes;
+      if (tot + 16 <= K2_SMALL_MAX) {
+        order_small.push_back((uint32_t)gi);
+        max_small = std::max(max_small, tot);
+      } else {
+        order_big.push_back((uint32_t)gi);
+      }
+    }
+    std::vector<uint32_t> order(order_small);
+    order.insert(order.end(), order_big.begin(), order_big.end());
+    if ((r = upload(ctx, ctx->d_order, order))) return r;
     K2Params k2{(const u16*)ctx->d_tok.p, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p,
-                (const u8*)d_in, (u8*)d_out, (u32)h_groups.size()};
-    TBZ_LAUNCH(tbz_k2_lz77, h_groups.size(), ctx->stream, k2);
+                (const u32*)ctx->d_order.p, (const u8*)d_in, (u8*)d_out, 0, 0};
+    if (!order_small.empty()) {
+      k2.n_groups = (u32)order_small.size();
+      k2.win_bytes = (u32)((max_small + 16 + 255) & ~255ull);
+      TBZ_LAUNCH_DYN(tbz_k2_lz77_small, order_small.size(), k2.win_bytes + 2 * K2_TOKBUF, ctx->stream, k2);
+    }
+    if (!order_big.empty()) {
+      k2.order = (const u32*)ctx->d_order.p + order_small.size();
+      k2.n_groups = (u32)order_big.size();
+      k2.win_bytes = 0;
+      TBZ_LAUNCH(tbz_k2_lz77, order_big.size(), ctx->stream, k2);
+    }
     TBZ_HIP(hipGetLastError());
   }
   if ((r = record(ctx, 5))) return r;
@@ -624,7 +651,7 @@ void tbz_ctx_destroy(tbz_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   tbz::DevBuf* bufs[] = {&ctx->d_str_off, &ctx->d_str_len, &ctx->d_tile_first, &ctx->d_tile_counts,
-                         &ctx->d_tile_offsets, &ctx->d_markers, &ctx->d_items, &ctx->d_res, &ctx->d_tok, &ctx->d_scratch,
+                         &ctx->d_tile_offsets, &ctx->d_markers, &ctx->d_items, &ctx->d_res, &ctx->d_tok, &ctx->d_scratch, &ctx->d_order,
                          &ctx->d_segs, &ctx->d_groups, &ctx->d_ck_chunks, &ctx->d_ck_parts, &ctx->d_ck_streams,
                          &ctx->d_ck_out, &ctx->d_crc_tab, &ctx->d_in_stage, &ctx->d_out_stage};
   for (auto* b : bufs)

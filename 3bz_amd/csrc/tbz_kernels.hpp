@@ -900,21 +900,30 @@ constexpr u32 K2_WIN = 36864;   // 32 KiB history + one batch span + slack; mult
 constexpr u32 K2_SPAN = 3072;   // max octets one batch may produce (cut otherwise)
 constexpr u32 K2_FLUSH = 8192;  // flush the ring to HBM every this many octets
 constexpr u32 K2_SHORT = 8;     // matches up to this length are copied by their own lane
-constexpr u32 K2_TOKBUF = 2048; // token words staged in LDS per load (one memory round trip per ~32 batches)
+constexpr u32 K2_TOKBUF = 1024; // token words staged in LDS per load (one memory round trip per ~16 batches)
+constexpr u32 K2_SMALL_MAX = 32768;  // groups producing at most this much (incl. 16 octets slack) take the linear path
 
 struct K2Params {
   const u16* tok;
   const Seg* segs;
   const Group* groups;
+  const u32* order;   // group indices this launch handles
   const u8* in_base;  // source of stored runs
   u8* out_base;
-  u32 n_groups;
+  u32 n_groups;       // entries in `order`
+  u32 win_bytes;      // LINEAR launches: octets of the window (dynamic LDS = win_bytes + 2*K2_TOKBUF)
 };
 
-TBZ_DEV u32 ring(u32 x) { return x >= K2_WIN ? x - K2_WIN : x; }  // x < 2*K2_WIN
+// A group whose whole output fits the LDS window needs no ring: LINEAR = true keeps every octet of
+// the group at window[a0 + offset] (no wrap arithmetic, no span cut, one flush at the end) and takes
+// its window from dynamic LDS sized by the host to the largest such group, so that e.g. 16 KiB
+// segments run 8 workgroups per CU instead of 4.  LINEAR = false is the general 32 KiB-history ring.
+template <bool LINEAR>
+TBZ_DEV u32 ring(u32 x) { return LINEAR ? x : (x >= K2_WIN ? x - K2_WIN : x); }  // x < 2*K2_WIN
 
-// store ring[from..to) (group-relative octet offsets) to out, clipped at `clip`; `a0` = (address of
-// the group's first octet) & 15 so that ring index == address (mod 16) and 16-byte chunks are aligned
+// store window[from..to) (group-relative octet offsets) to out, clipped at `clip`; `a0` = (address of
+// the group's first octet) & 15 so that window index == address (mod 16) and 16-byte chunks are aligned
+template <bool LINEAR>
 TBZ_DEV void k2_flush(const u8* win, u8* outp, u64 from, u64 to, u64 clip, u32 a0) {
   if (to > clip) to = clip;
   if (from >= to) return;
@@ -923,50 +932,53 @@ TBZ_DEV void k2_flush(const u8* win, u8* outp, u64 from, u64 to, u64 clip, u32 a
   u64 head_end = ((from + a0 + 15) & ~15ull) - a0;  // first 16-aligned offset >= from
   if (head_end > to) head_end = to;
   u64 body_end = head_end + ((to - head_end) & ~15ull);
-  if (from + lane < head_end) outp[from + lane] = win[(u32)((from + lane + a0) % K2_WIN)];
+  if (from + lane < head_end) outp[from + lane] = win[LINEAR ? (u32)(from + lane + a0) : (u32)((from + lane + a0) % K2_WIN)];
   u64 nchunk = (body_end - head_end) >> 4;
-  u32 r0 = (u32)((head_end + a0) % K2_WIN);
-  for (u32 c = lane; c < (u32)nchunk; c += 64) {  // nchunk*16 < K2_WIN
-    u32 ri = ring(r0 + c * 16);
+  u32 r0 = LINEAR ? (u32)(head_end + a0) : (u32)((head_end + a0) % K2_WIN);
+  for (u32 c = lane; c < (u32)nchunk; c += 64) {
+    u32 ri = ring<LINEAR>(r0 + c * 16);
     uint4 v = *(const uint4*)(win + ri);
     *(uint4*)(outp + head_end + (u64)c * 16) = v;
   }
-  if (body_end + lane < to) outp[body_end + lane] = win[(u32)((body_end + lane + a0) % K2_WIN)];
+  if (body_end + lane < to)
+    outp[body_end + lane] = win[LINEAR ? (u32)(body_end + lane + a0) : (u32)((body_end + lane + a0) % K2_WIN)];
   tbz_sync();
 }
 
-// all 64 lanes copy l octets inside the ring: dst index rd, source rs = rd - dd.  An overlapping
+// all 64 lanes copy l octets inside the window: dst index rd, source rs = rd - dd.  An overlapping
 // copy (dd < l) repeats the dd-octet pattern (the special cases of deflate.lisp:281-334).
+template <bool LINEAR>
 TBZ_DEV void k2_copy_coop(u8* win, u32 rd, u32 dd, u32 l) {
   const u32 lane = tbz_lane();
-  u32 rs = rd >= dd ? rd - dd : rd + K2_WIN - dd;
+  u32 rs = LINEAR ? (rd >= dd ? rd - dd : 0) : (rd >= dd ? rd - dd : rd + K2_WIN - dd);
+  if (dd >= l) {  // disjoint: plain strided copy
+    for (u32 j = lane; j < l; j += 64) {
+      u8 b = win[ring<LINEAR>(rs + j)];
+      win[ring<LINEAR>(rd + j)] = b;
+    }
+    return;
+  }
   float inv = 1.0f / (float)dd;
   for (u32 j = lane; j < l; j += 64) {
-    u32 jj = j;
-    if (dd < l) {
-      u32 q = (u32)((float)j * inv);
-      i32 r = (i32)j - (i32)(q * dd);
-      if (r < 0) r += (i32)dd;
-      if (r >= (i32)dd) r -= (i32)dd;
-      jj = (u32)r;
-    }
-    u8 b = win[ring(rs + jj)];
-    win[ring(rd + j)] = b;
+    u32 q = (u32)((float)j * inv);
+    i32 r = (i32)j - (i32)(q * dd);
+    if (r < 0) r += (i32)dd;
+    if (r >= (i32)dd) r -= (i32)dd;
+    u8 b = win[ring<LINEAR>(rs + (u32)r)];
+    win[ring<LINEAR>(rd + j)] = b;
   }
 }
 
-TBZ_KERNEL void tbz_k2_lz77(K2Params P) {
-  TBZ_SHARED __attribute__((aligned(16))) u8 win[K2_WIN];
-  TBZ_SHARED u16 tks[K2_TOKBUF];
-  if (tbz_block() >= P.n_groups) return;
+template <bool LINEAR>
+TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks) {
   const u32 lane = tbz_lane();
   const u64 lane_bit = 1ull << lane;
-  const Group g = P.groups[tbz_block()];
+  const Group g = P.groups[P.order[tbz_block()]];
   u8* outp = P.out_base + g.out_abs;
   const u32 a0 = (u32)((uintptr_t)outp & 15);
   const u64 clip = g.out_end > g.out_abs ? g.out_end - g.out_abs : 0;
   u64 pos = 0, flushed = 0;
-  u32 rpos = a0;  // ring index of `pos`
+  u32 rpos = a0;  // window index of `pos`
 
   for (u32 s = 0; s < g.seg_count && pos < clip; s++) {
     const Seg sg = P.segs[g.seg_first + s];
@@ -984,11 +996,11 @@ TBZ_KERNEL void tbz_k2_lz77(K2Params P) {
       }
       u32 w = lane < n ? tks[(u32)(p - tb) + lane] : 0;
       const u64 valid = n == 64 ? ~0ull : ((1ull << n) - 1);
-      u64 hb = tbz_ballot((w & 0x8000u) != 0) & valid;            // heads (payload words have bit 15 clear)
-      u64 sb = tbz_ballot((w & 0xC000u) == 0xC000u) & valid;      // stored-run heads
-      u64 mb = hb & ~sb;                                          // match heads
+      u64 hb = tbz_ballot((w & 0x8000u) != 0) & valid;        // heads (payload words have bit 15 clear)
+      u64 sb = tbz_ballot((w & 0xC000u) == 0xC000u) & valid;  // stored-run heads
+      u64 mb = hb & ~sb;                                      // match heads
       if (sb & 1) {
-        // ---- stored run at the front of the batch: cooperative copy input -> ring, flushing as we go
+        // ---- stored run at the front of the batch: cooperative copy input -> window, flushing as we go
         if (n < 4) break;  // malformed (never produced by K1)
         u32 w1 = tbz_readlane(w, 1), w2 = tbz_readlane(w, 2), w3 = tbz_readlane(w, 3), w0 = tbz_readlane(w, 0);
         u64 cnt = (w0 & 0x3fff) | ((u64)(w1 & 3) << 14);
@@ -996,16 +1008,16 @@ TBZ_KERNEL void tbz_k2_lz77(K2Params P) {
         while (cnt) {
           u32 c = cnt < 4096 ? (u32)cnt : 4096;
           tbz_sync();
-          for (u32 j = lane; j < c; j += 64) win[ring(rpos + j)] = P.in_base[src + j];
+          for (u32 j = lane; j < c; j += 64) win[ring<LINEAR>(rpos + j)] = P.in_base[src + j];
           tbz_sync();
           pos += c;
-          rpos = ring(rpos + c);
+          rpos = ring<LINEAR>(rpos + c);
           src += c;
           cnt -= c;
-          if (pos - flushed >= K2_FLUSH || pos >= clip) {
+          if (!LINEAR && (pos - flushed >= K2_FLUSH || pos >= clip)) {
             u64 upto = pos >= clip ? pos : ((pos + a0) & ~15ull) - a0;
             if (upto > flushed) {
-              k2_flush(win, outp, flushed, upto, clip, a0);
+              k2_flush<LINEAR>(win, outp, flushed, upto, clip, a0);
               flushed = upto;
             }
           }
@@ -1018,26 +1030,27 @@ TBZ_KERNEL void tbz_k2_lz77(K2Params P) {
       u32 n_eff = sb ? (u32)tbz_ffs64(sb) - 1 : n;
       const u64 veff = n_eff == 64 ? ~0ull : ((1ull << n_eff) - 1);
       mb &= veff;
-      u64 pm = (mb << 1);                       // payload (distance) words
+      u64 pm = (mb << 1);               // payload (distance) words
       u64 lits = veff & ~mb & ~pm;
-      u64 cut_ok = (lits | pm) & veff;          // a batch may end after a literal or after a distance word
+      u64 cut_ok = (lits | pm) & veff;  // a batch may end after a literal or after a distance word
       bool head = (mb & lane_bit) != 0, islit = (lits & lane_bit) != 0;
       u32 len = head ? (w & 0xff) + 3 : (islit ? 1u : 0u);
       u32 incl = tbz_wave_incl_scan_u32(len);
-      u64 ok = tbz_ballot(incl <= K2_SPAN) & cut_ok;
+      // the ring must not be overrun inside one batch; a linear window holds the whole group anyway
+      u64 ok = LINEAR ? cut_ok : (tbz_ballot(incl <= K2_SPAN) & cut_ok);
       if (ok == 0) break;  // malformed token stream (never produced by K1)
       u32 m = 64 - (u32)__builtin_clzll(ok);
       u32 total = tbz_readlane(incl, m - 1);
       const u64 act = m == 64 ? ~0ull : ((1ull << m) - 1);
       u32 dofs = incl - len;  // octet offset of this token inside the batch
       u32 dist = (tbz_wave_shl1(w) & 0x7fffu) + 1;
-      if (islit && (act & lane_bit)) win[ring(rpos + dofs)] = (u8)w;
+      if (islit && (act & lane_bit)) win[ring<LINEAR>(rpos + dofs)] = (u8)w;
       // multi-round resolution
       u64 pend = mb & act;
       // the part of the source a match does not write itself ends at dofs - dist + min(len, dist)
       i32 need = (i32)dofs - (i32)dist + (i32)(len < dist ? len : dist);
-      u32 rd = ring(rpos + dofs);
-      u32 rs = rd >= dist ? rd - dist : rd + K2_WIN - dist;
+      u32 rd = ring<LINEAR>(rpos + dofs);
+      u32 rs = LINEAR ? (rd >= dist ? rd - dist : 0) : (rd >= dist ? rd - dist : rd + K2_WIN - dist);
       tbz_sync();
       while (pend) {
         u32 first = (u32)tbz_ffs64(pend) - 1;
@@ -1052,35 +1065,49 @@ TBZ_KERNEL void tbz_k2_lz77(K2Params P) {
           u32 jj = 0;
 #pragma unroll
           for (u32 j = 0; j < K2_SHORT; j++) {
-            b[j] = j < len ? win[ring(rs + jj)] : 0;
+            b[j] = j < len ? win[ring<LINEAR>(rs + jj)] : 0;
             jj++;
             if (jj == dist) jj = 0;
           }
 #pragma unroll
           for (u32 j = 0; j < K2_SHORT; j++)
-            if (j < len) win[ring(rd + j)] = b[j];
+            if (j < len) win[ring<LINEAR>(rd + j)] = b[j];
         }
         while (longs) {
           u32 i = (u32)tbz_ffs64(longs) - 1;
           longs &= longs - 1;
-          k2_copy_coop(win, tbz_readlane(rd, i), tbz_readlane(dist, i), tbz_readlane(len, i));
+          k2_copy_coop<LINEAR>(win, tbz_readlane(rd, i), tbz_readlane(dist, i), tbz_readlane(len, i));
         }
         pend &= ~rdy;
         tbz_sync();
       }
       pos += total;
-      rpos = ring(rpos + total);
+      rpos = ring<LINEAR>(rpos + total);
       p += m;
-      if (pos - flushed >= K2_FLUSH) {
+      if (!LINEAR && pos - flushed >= K2_FLUSH) {
         u64 upto = ((pos + a0) & ~15ull) - a0;  // keep the unaligned tail in the ring
         if (upto > flushed) {
-          k2_flush(win, outp, flushed, upto, clip, a0);
+          k2_flush<LINEAR>(win, outp, flushed, upto, clip, a0);
           flushed = upto;
         }
       }
     }
   }
-  k2_flush(win, outp, flushed, pos, clip, a0);
+  k2_flush<LINEAR>(win, outp, flushed, pos, clip, a0);
+}
+
+TBZ_KERNEL void tbz_k2_lz77(K2Params P) {
+  TBZ_SHARED __attribute__((aligned(16))) u8 win[K2_WIN];
+  TBZ_SHARED u16 tks[K2_TOKBUF];
+  if (tbz_block() >= P.n_groups) return;
+  k2_body<false>(P, win, tks);
+}
+
+// groups whose output (plus 16 octets of alignment slack) fits P.win_bytes
+TBZ_KERNEL void tbz_k2_lz77_small(K2Params P) {
+  TBZ_DYN_SHARED(u8, dyn);
+  if (tbz_block() >= P.n_groups) return;
+  k2_body<true>(P, dyn, (u16*)(dyn + P.win_bytes));
 }
 
 // ================================================================================================

@@ -84,6 +84,9 @@ TBZ_DEV u32 tbz_wave_incl_scan_u32(u32 x) {
   return (u32)v;
 }
 
+#define TBZ_DYN_SHARED(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
+#define TBZ_LAUNCH_DYN(kernel, grid, lds_bytes, stream, ...) \
+  hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3(64), (lds_bytes), (stream), __VA_ARGS__)
 #define TBZ_LAUNCH(kernel, grid, stream, ...) \
   hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3(64), 0, (stream), __VA_ARGS__)
 #endif  // TBZ_PLATFORM_HPP_INCLUDED

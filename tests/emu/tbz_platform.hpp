@@ -261,6 +261,9 @@ TBZ_DEV u32 tbz_wave_incl_scan_u32(u32 v) {
   return v;
 }
 
+#define TBZ_DYN_SHARED(T, name) static __attribute__((aligned(16))) T name[64 * 1024]
+#define TBZ_LAUNCH_DYN(kernel, grid, lds_bytes, stream, ...) \
+  tbz_emu::launch((u32)(grid), [&] { kernel(__VA_ARGS__); })
 #define TBZ_LAUNCH(kernel, grid, stream, ...) \
   tbz_emu::launch((u32)(grid), [&] { kernel(__VA_ARGS__); })
 

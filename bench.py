@@ -68,14 +68,14 @@ def main():
     d_in = torch.from_numpy(np.frombuffer(stream, dtype=np.uint8).copy()).cuda(local_rank)
     d_out = torch.empty(U + 64, dtype=torch.uint8, device="cuda:%d" % local_rank)
     eng = T.Engine(local_rank)
-    rec = torch.zeros(64, dtype=torch.uint8, device="cuda:%d" % local_rank)
-    gathered = [torch.zeros_like(rec) for _ in range(world)] if world > 1 else None
+    M = importlib.import_module("3bz_amd.multi")
+    owner = list(range(world))  # stream i lives on rank i: one stream of the same shape per GPU
 
     def step():
         res = eng.inflate_device(d_in.data_ptr(), C, d_out.data_ptr(), U, T.FORMATS["zlib"])
         if world > 1:  # X1: exchange the fixed 64-byte result records (latency-bound, not data-path)
-            rec.copy_(torch.frombuffer(bytearray(bytes(res)), dtype=torch.uint8))
-            dist.all_gather(gathered, rec)
+            allr = M.exchange_results([res], owner, rank, world, dist, torch, device="cuda:%d" % local_rank)
+            assert all(r.status == 0 for r in allr)
         return res
 
     def barrier():

@@ -213,25 +213,26 @@ TBZ_CONSTANT u8 c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3
 // payload words always have bit 15 clear, so a word with bit 15 set is always a head.
 constexpr u32 TOK_MATCH = 0x8000u, TOK_STORED = 0xC000u;
 
-constexpr u32 K1_SCRATCH = 1024;  // octets of global scratch per item: lens[320] | overflow symbols u16[288] | spare
-constexpr u32 K1_SC_LENS = 0, K1_SC_SLIT = 320;
-constexpr u32 K1_INBUF = 24;      // 32-bit words of compressed input windowed per lane (96 octets)
-constexpr u32 K1_PHASE = 40;      // tokens decoded per phase between window reloads
-constexpr u32 K1_LCAP = 192;      // lit/len symbols (canonical order) held in LDS per lane; the rest: global scratch
+constexpr u32 K1_SCRATCH = 512;   // octets of global scratch per item: lens[320] (code lengths while a header is parsed)
+constexpr u32 K1_SC_LENS = 0;
+constexpr u32 K1_INBUF = 20;      // 32-bit words of compressed input windowed per lane (80 octets); multiple of 4
+constexpr u32 K1_PHASE = 32;      // tokens decoded per phase between window reloads
+constexpr u32 K1_LCAP = 288;      // every lit/len symbol (canonical order) is held in LDS per lane
 
 // Per-workgroup LDS, every array LANE-INTERLEAVED ([index][lane]): the bank depends on the lane only, so
 // 64 lanes reading 64 different indices never conflict beyond the 2-lanes-per-dword sharing of the
-// narrow types.  25.5 KiB -> 6 workgroups (384 decoders) per CU.
+// narrow types.  32 KiB -> 5 workgroups (320 decoders) per CU.
 struct K1Lds {
-  u8 lsym8[K1_LCAP][64];        // 12 KiB   lit/len symbols in canonical order, low 8 bits
-  u32 lbit8[K1_LCAP / 32][64];  // 1.5 KiB  … bit 8 (end-of-block and length symbols)
+  u8 lsym8[K1_LCAP][64];        // 18 KiB   lit/len symbols in canonical order, low 8 bits
+  u32 lbit8[K1_LCAP / 32][64];  // 2.25 KiB … bit 8 (end-of-block and length symbols)
   u16 ldlt[16][64];             // 2 KiB    lit/len: slot = code + ldlt[len]
   u8 dsym8[32][64];             // 2 KiB    distance symbols in canonical order (also the code-length code's)
   u16 ddlt[16][64];             // 2 KiB
-  u32 inbuf[K1_INBUF][64];      // 6 KiB    per-lane window of the compressed stream; its first 4 KiB double as
+  u32 inbuf[K1_INBUF][64];      // 5 KiB      per-lane window of the compressed stream; its first 4 KiB double as
                                 //          the per-lane counters while a code is built (the window is reloaded after)
 };
-static_assert(sizeof(K1Lds) <= 26 * 1024, "six K1 workgroups must fit one CU's 160 KiB LDS");
+static_assert(K1_INBUF % 4 == 0 && K1_INBUF * 256 >= 4096, "window: 16-octet loads; doubles as 4 KiB of build counters");
+static_assert(sizeof(K1Lds) <= 32 * 1024, "five K1 workgroups must fit one CU's 160 KiB LDS");
 
 struct K1Params {
   const u8* in_base;
@@ -360,13 +361,8 @@ struct CanonStore {
   u16 (*dlt)[64];   // [16][64]: slot in canonical order = (code of length L) + dlt[L]   (mod 2^16)
   u8 (*sym8)[64];   // [cap][64]: low 8 bits of the symbol at each slot
   u32 (*bit8)[64];  // [cap/32][64]: bit 8 of the symbol at each slot (null: symbols < 256)
-  u16* glob;        // global scratch: symbols of slots >= cap (null: cap covers the alphabet)
-  u32 cap;
+  u32 cap;          // slots; covers the whole alphabet (288 / 32)
 };
-
-// out of line on purpose: if this load is visible next to the LDS reads the compiler if-converts them
-// into one flat_load + vmcnt(0), which stalls the wave on every token store in flight
-TBZ_DEV_NOINLINE u32 k1_sorted_global(const u16* p, u32 slot) { return p[slot]; }
 
 // Per-lane canonical-Huffman build.  `lens` (global scratch) holds n code lengths 0..15.
 // Acceptance rules of build-tree-part (huffman-tree.lisp:112-122): over-subscribed -> error;
@@ -406,12 +402,8 @@ TBZ_DEV i32 build_canon(const u8* lens, u32 n, u16 (*tmp)[64], const CanonStore&
     if (!l) continue;
     u32 slot = tmp[l][lane];
     tmp[l][lane] = (u16)(slot + 1);
-    if (slot < cs.cap) {
-      cs.sym8[slot][lane] = (u8)i;
-      if (i >= 256) cs.bit8[slot >> 5][lane] |= 1u << (slot & 31);
-    } else {
-      cs.glob[slot] = (u16)i;
-    }
+    cs.sym8[slot][lane] = (u8)i;  // slot < n <= cap
+    if (i >= 256) cs.bit8[slot >> 5][lane] |= 1u << (slot & 31);
   }
   return 0;
 }
@@ -425,13 +417,9 @@ TBZ_DEV u32 canon_decode(u32 pk, const Canon& cn, const CanonStore& cs, u32& sym
 #pragma unroll
   for (int k = 0; k < 15; k++) L += r16 >= cn.lim[k] ? 1u : 0u;
   u32 slot = ((r16 >> (16 - (L & 15))) + cs.dlt[L & 15][lane]) & 0xffff;
-  u32 s;
-  if (slot < cs.cap) {
-    s = cs.sym8[slot][lane];
-    if (cs.bit8) s |= ((cs.bit8[slot >> 5][lane] >> (slot & 31)) & 1u) << 8;
-  } else {
-    s = (L < 16 && cs.glob) ? k1_sorted_global(cs.glob, slot) : 0;
-  }
+  slot = slot < cs.cap ? slot : 0;  // only a hole (L = 16) can point outside; its symbol is never used
+  u32 s = cs.sym8[slot][lane];
+  if (cs.bit8) s |= ((cs.bit8[slot >> 5][lane] >> (slot & 31)) & 1u) << 8;
   sym = s;
   return L;
 }
@@ -465,10 +453,10 @@ struct K1Tables {
   Canon ld;  // distance alphabet
 };
 TBZ_DEV u16 (*k1_tmp(K1Lds& S))[64] { return (u16(*)[64])S.inbuf; }
-TBZ_DEV CanonStore k1_cs_lit(K1Lds& S, u8* sc) {
-  return CanonStore{S.ldlt, S.lsym8, S.lbit8, (u16*)(sc + K1_SC_SLIT), K1_LCAP};
+TBZ_DEV CanonStore k1_cs_lit(K1Lds& S, u8*) {
+  return CanonStore{S.ldlt, S.lsym8, S.lbit8, K1_LCAP};
 }
-TBZ_DEV CanonStore k1_cs_dist(K1Lds& S) { return CanonStore{S.ddlt, S.dsym8, nullptr, nullptr, 32}; }
+TBZ_DEV CanonStore k1_cs_dist(K1Lds& S) { return CanonStore{S.ddlt, S.dsym8, nullptr, 32}; }
 
 // fixed (BTYPE=1) code lengths: huffman-tree.lisp:89-97
 TBZ_DEV i32 k1_build_fixed(K1Lds& S, K1State& st, K1Tables& T, u8* sc) {
@@ -573,17 +561,18 @@ TBZ_DEV i32 k1_decode_block(K1Lds& S, K1State& st, const K1Tables& T, u8* sc) {
     u16* tp = st.tok;
     u32 why = RUN;
 
-#define K1_SKIP(n)          \
-  do {                      \
-    o += (n);               \
-    rem -= (i32)(n);        \
-    if (o >= 32) {          \
-      o -= 32;              \
-      lo = hi;              \
-      hi = nx;              \
-      nx = B.buf[k][lane];  \
-      k++;                  \
-    }                       \
+// branch-free: the next window word is read every time and selected in when a word boundary is crossed
+#define K1_SKIP(n)                   \
+  do {                               \
+    o += (n);                        \
+    rem -= (i32)(n);                 \
+    const u32 nw_ = B.buf[k][lane];  \
+    const bool ge_ = o >= 32;        \
+    o = ge_ ? o - 32 : o;            \
+    lo = ge_ ? hi : lo;              \
+    hi = ge_ ? nx : hi;              \
+    nx = ge_ ? nw_ : nx;             \
+    k += ge_ ? 1u : 0u;              \
   } while (0)
 
     for (u32 it = 0; it < K1_PHASE && k < K1_INBUF - 3; it++) {  // a token takes at most 3 window words

@@ -18,6 +18,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -40,9 +41,11 @@ struct tbz_ctx {
   hipEvent_t ev[10] = {};
   std::string err;
   tbz_timings tim{};
+  uint64_t gang_rounds = 0, gang_valid = 0;  // diagnostics of the last call (K1g)
+  int k1_mode = 0;  // 0 auto, 1 lane-per-item, 4..64 gang of that many lanes (env TBZ_K1_MODE; tests force each)
   // device pools (grow-only)
   tbz::DevBuf d_str_off, d_str_len, d_tile_first, d_tile_counts, d_tile_offsets, d_markers, d_items, d_res,
-      d_tok, d_scratch, d_segs, d_groups, d_order, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
+      d_tok, d_scratch, d_stage, d_segs, d_groups, d_order, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
       d_out_stage;
 };
 
@@ -213,6 +216,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   if (!size_only && n && (!out_offs || !out_caps)) return TBZ_E_ARG;
   TBZ_HIP(hipSetDevice(ctx->device));
   ctx->tim = tbz_timings{};
+  ctx->gang_rounds = ctx->gang_valid = 0;
   for (size_t i = 0; i < n; i++) memset(&results[i], 0, sizeof(tbz_result));
   if (n == 0) return 0;
   if (n > 0x7fffffffu) return TBZ_E_ARG;
@@ -300,18 +304,45 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   if ((r = ensure(ctx, ctx->d_tok, (size_t)in_extent * 16 + 64))) return r;
   if ((r = upload(ctx, ctx->d_items, items))) return r;
   if ((r = ensure(ctx, ctx->d_res, items.size() * sizeof(SegResult)))) return r;
-  // one lane per item; with few items use fewer lanes per workgroup so that every CU gets work
-  auto items_per_wg = [](size_t n_it) {
+  // K1 flavour.  One lane per item is bound by ONE item's serial chain (~1.1 us per token) until there
+  // are enough items to saturate instruction issue (~64 Ki lanes on an MI355X: measured equal at 65 536
+  // items); below that a gang of 8 (4) lanes per item shortens the chain 8x (4x) for ~25 % more work.
+  auto k1_gang = [&](size_t n_it) -> int {
+    if (ctx->k1_mode) return ctx->k1_mode;
+    int G = 1;
+    while (G < 64 && n_it * (size_t)G * 2 <= 65536) G <<= 1;  // keep items x G around the chip's 64 Ki lanes
+    return G == 2 ? 4 : G;
+  };
+  auto items_per_wg = [](size_t n_it) {  // lane-per-item flavour: spread few items over all CUs
     u32 ipw = 64;
     while (ipw > 1 && n_it / ipw < 512) ipw >>= 1;
     return ipw;
   };
   if ((r = ensure(ctx, ctx->d_scratch, items.size() * (size_t)K1_SCRATCH))) return r;
-  K1Params k1{(const u8*)d_in, (u16*)ctx->d_tok.p, (const Item*)ctx->d_items.p, (SegResult*)ctx->d_res.p,
-              (const u64*)ctx->d_markers.p, (u8*)ctx->d_scratch.p, (u32)markers.size(), (u32)items.size(),
-              items_per_wg(items.size())};
+  auto launch_k1 = [&](const Item* d_items, SegResult* d_res, size_t n_it) -> int {
+    int G = k1_gang(n_it);
+    if (G == 1) {
+      K1Params k1{(const u8*)d_in, (u16*)ctx->d_tok.p, d_items, d_res, (const u64*)ctx->d_markers.p,
+                  (u8*)ctx->d_scratch.p, (u32)markers.size(), (u32)n_it, items_per_wg(n_it)};
+      TBZ_LAUNCH(tbz_k1_huff_decode, (n_it + k1.items_per_wg - 1) / k1.items_per_wg, ctx->stream, k1);
+      return 0;
+    }
+    size_t per = 64 / G, nwg = (n_it + per - 1) / per;
+    int rr = ensure(ctx, ctx->d_stage, nwg * 64 * (size_t)KG_STAGE * 2);
+    if (rr) return rr;
+    K1gParams kg{(const u8*)d_in, (u16*)ctx->d_tok.p, (u16*)ctx->d_stage.p, d_items, d_res,
+                 (const u64*)ctx->d_markers.p, (u8*)ctx->d_scratch.p, (u32)markers.size(), (u32)n_it};
+    switch (G) {
+      case 4: TBZ_LAUNCH(tbz_k1g4_huff_decode, nwg, ctx->stream, kg); break;
+      case 8: TBZ_LAUNCH(tbz_k1g8_huff_decode, nwg, ctx->stream, kg); break;
+      case 16: TBZ_LAUNCH(tbz_k1g16_huff_decode, nwg, ctx->stream, kg); break;
+      case 32: TBZ_LAUNCH(tbz_k1g32_huff_decode, nwg, ctx->stream, kg); break;
+      default: TBZ_LAUNCH(tbz_k1g64_huff_decode, nwg, ctx->stream, kg); break;
+    }
+    return 0;
+  };
   if ((r = record(ctx, 2))) return r;
-  TBZ_LAUNCH(tbz_k1_huff_decode, (items.size() + k1.items_per_wg - 1) / k1.items_per_wg, ctx->stream, k1);
+  if ((r = launch_k1((const Item*)ctx->d_items.p, (SegResult*)ctx->d_res.p, items.size()))) return r;
   TBZ_HIP(hipGetLastError());
   if ((r = record(ctx, 3))) return r;
   ctx->tim.huff_launches = 1;
@@ -338,6 +369,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     else if (h.continues) S.next_continues = true;  // nothing emitted: carry the flag forward
     S.total_out += q.out_bytes;
     ctx->tim.token_words += q.tok_words;
+    ctx->gang_rounds += q.reserved >> 32;
+    ctx->gang_valid += q.reserved & 0xffffffffu;
     if (q.status == SEG_LANDED) {
       uint32_t mk = is_fixup ? q.land_marker : 0;
       if (is_fixup) S.cur_item = S.first_item + 1 + (mk - S.first_marker);
@@ -398,13 +431,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     ctx->tim.fixup_rounds++;
     if ((r = upload(ctx, ctx->d_items, fix))) return r;
     if ((r = ensure(ctx, ctx->d_res, fix.size() * sizeof(SegResult)))) return r;
-    K1Params kf = k1;
-    kf.items = (const Item*)ctx->d_items.p;
-    kf.res = (SegResult*)ctx->d_res.p;
-    kf.n_items = (u32)fix.size();
-    kf.items_per_wg = items_per_wg(fix.size());
     if ((r = record(ctx, 2))) return r;
-    TBZ_LAUNCH(tbz_k1_huff_decode, (fix.size() + kf.items_per_wg - 1) / kf.items_per_wg, ctx->stream, kf);
+    if ((r = launch_k1((const Item*)ctx->d_items.p, (SegResult*)ctx->d_res.p, fix.size()))) return r;
     TBZ_HIP(hipGetLastError());
     if ((r = record(ctx, 3))) return r;
     ctx->tim.huff_launches++;
@@ -429,6 +457,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     }
   }
   ctx->tim.huff_ms = huff_ms;
+  if (getenv("TBZ_DEBUG")) fprintf(stderr, "tbz: gang rounds %llu, committed lanes %llu (%.2f per round)\n", (unsigned long long)ctx->gang_rounds, (unsigned long long)ctx->gang_valid, ctx->gang_rounds ? (double)ctx->gang_valid / ctx->gang_rounds : 0.0);
 
   // ---------------------------------------------------------------- per-stream layout, groups, status
   std::vector<Seg> h_segs;
@@ -642,6 +671,13 @@ int tbz_ctx_create(int device_id, tbz_ctx** out_ctx) {
   }
   if ((e = hipMemcpy(ctx->d_crc_tab.p, t.data(), t.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
     return fail(e, "hipMemcpy");
+  if (const char* m = getenv("TBZ_K1_MODE")) {
+    if (!strcmp(m, "lane")) ctx->k1_mode = 1;
+    else if (!strncmp(m, "gang", 4)) {
+      int g = atoi(m + 4);
+      if (g == 4 || g == 8 || g == 16 || g == 32 || g == 64) ctx->k1_mode = g;
+    }
+  }
   *out_ctx = ctx;
   return 0;
 }
@@ -651,7 +687,7 @@ void tbz_ctx_destroy(tbz_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   tbz::DevBuf* bufs[] = {&ctx->d_str_off, &ctx->d_str_len, &ctx->d_tile_first, &ctx->d_tile_counts,
-                         &ctx->d_tile_offsets, &ctx->d_markers, &ctx->d_items, &ctx->d_res, &ctx->d_tok, &ctx->d_scratch, &ctx->d_order,
+                         &ctx->d_tile_offsets, &ctx->d_markers, &ctx->d_items, &ctx->d_res, &ctx->d_tok, &ctx->d_scratch, &ctx->d_stage, &ctx->d_order,
                          &ctx->d_segs, &ctx->d_groups, &ctx->d_ck_chunks, &ctx->d_ck_parts, &ctx->d_ck_streams,
                          &ctx->d_ck_out, &ctx->d_crc_tab, &ctx->d_in_stage, &ctx->d_out_stage};
   for (auto* b : bufs)

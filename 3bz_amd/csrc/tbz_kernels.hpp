@@ -70,7 +70,7 @@ TBZ_DEV u32 load_u32_unaligned(const u32* TBZ_RESTRICT w, u64 idx, u64 nwords) {
 // K0 — marker scan.  A marker is the byte AFTER `00 00 FF FF` (the LEN/NLEN of an empty stored
 // block, which zlib emits for Z_SYNC_FLUSH / Z_FULL_FLUSH).  3bz has no counterpart: it is strictly
 // sequential (:block-end -> :start-of-block, deflate.lisp:719-722).
-// Work split: tile = 16 KiB of one stream = 16 rows of 1 KiB; lane j of row r owns the 16 positions
+// Work split: tile = 64 KiB of one stream = 64 rows of 1 KiB; lane j of row r owns the 16 positions
 // starting at tile + r*1024 + j*16, so a row is one fully coalesced 1 KiB read.
 // ================================================================================================
 struct K0Params {
@@ -872,6 +872,661 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
   P.res[idx] = r;
 }
 #undef K1_CHECK
+
+// ================================================================================================
+// K1g — Huffman decode to tokens, a GANG of G lanes per item (intra-block parallel decode).
+//
+// With one lane per item, K1's run time is one item's serial chain of ~1.1 us per token, no matter how
+// many items there are (measured: 6.4 ms for 256 MiB and 7.2 ms for 1 GiB of 16 KiB segments).  Here G
+// lanes share one item.  The gang leader parses the block header and builds the code into the gang's
+// LDS; then the block is decoded in ROUNDS: lane g speculatively decodes the sub-range
+// [P + g*SUB, P + (g+1)*SUB) of the bitstream, starting OVL bits early so that — Huffman codes being
+// self-synchronising — it is almost always on a true token boundary by the time its sub-range begins.
+// A lane's tokens count only if it started recording exactly where its predecessor stopped
+// (start_g == end_{g-1}, and lane 0 starts at the known-good P): that equality is exact, a lane that
+// starts at a true boundary decodes the true sequence, so there are no false positives.  The valid
+// prefix of lanes is committed (token runs compacted from per-lane staging into the item's contiguous
+// token stream — K2 and the host see exactly what the lane-per-item kernel produces), P moves to the
+// last valid lane's end, and the next round starts.  A mis-synchronised lane only shortens a round.
+// ================================================================================================
+constexpr u32 KG_SUB = 2048;            // bits of bitstream per lane per round
+constexpr u32 KG_OVL = 512;             // run-up bits before a lane's sub-range
+constexpr u32 KG_STAGE = KG_SUB + 64;   // staged token words per lane per round (words <= bits)
+
+struct GangTables {  // per gang, in LDS; written by the leader, read by all G lanes
+  u8 lsym8[288];
+  u32 lbit8[9];
+  u16 ldlt[16];
+  u8 dsym8[32];
+  u16 ddlt[16];
+  u32 llim[16];  // [0..14] left-aligned limits, [15] shortest code length
+  u32 dlim[16];
+  u16 tmp[32];
+};
+enum { GM_HEADER = 0, GM_BLOCK = 1, GM_DONE = 2 };
+struct GangState {  // per gang, in LDS; owned by the leader
+  u64 P;            // GM_BLOCK: bit position of the next token; GM_HEADER: of the next block header
+  u64 T;            // token words committed so far
+  u64 produced;     // octets those tokens produce
+  u64 blk_pos, blk_prod, blk_tok;
+  u64 fail_pos;
+  i32 status;
+  u32 mode, bfinal, deficit, tables, land, tr0, tr1, tr_have, pad;
+  u32 rounds, valid_lanes;  // diagnostics: rounds run and lanes committed (efficiency = valid_lanes / (G*rounds))
+};
+template <int G>
+struct KgLds {
+  GangTables gt[64 / G];
+  GangState gs[64 / G];
+  u32 inbuf[K1_INBUF][64];
+};
+
+struct K1gParams {
+  const u8* in_base;
+  u16* tok;       // final token pool (as K1Params::tok)
+  u16* stage;     // n_workgroups * 64 * KG_STAGE words of per-lane staging
+  const Item* items;
+  SegResult* res;
+  const u64* markers;
+  u8* scratch;    // n_items * K1_SCRATCH
+  u32 n_markers;
+  u32 n_items;
+};
+
+struct __attribute__((packed, aligned(2))) U16x8 {  // eight token words at 2-octet alignment
+  uint4 v;
+};
+
+// leader-only canonical build into the gang's tables (same rules as build_canon)
+TBZ_DEV i32 build_canon_g(const u8* lens, u32 n, u16* tmp, u16* dlt, u8* sym8, u32* bit8, u32 nbit8, u32* lim) {
+  for (int L = 0; L < 16; L++) tmp[L] = 0;
+  for (u32 i = 0; i < n; i++) {
+    u32 l = lens[i];
+    if (l) tmp[l] = (u16)(tmp[l] + 1);
+  }
+  u32 used = 0, code = 0, off = 0, prev = 0, min_len = 0;
+  i32 left = 1, err = 0;
+  for (int L = 1; L < 16; L++) {
+    u32 c = tmp[L];
+    left <<= 1;
+    if ((i32)c > left && !err) err = E_OVERSUB;
+    left -= (i32)c;
+    used += c;
+    if (c && !min_len) min_len = L;
+    code = (code + prev) << 1;
+    prev = c;
+    tmp[L] = (u16)off;
+    dlt[L] = (u16)(off - code);
+    lim[L - 1] = (code + c) << (16 - L);
+    off += c;
+  }
+  lim[15] = min_len;
+  if (!err && left > 0 && used > 1) err = E_INCOMPLETE;
+  if (err) return err;
+  for (u32 k = 0; k < nbit8; k++) bit8[k] = 0;
+  for (u32 i = 0; i < n; i++) {
+    u32 l = lens[i];
+    if (!l) continue;
+    u32 slot = tmp[l];
+    tmp[l] = (u16)(slot + 1);
+    sym8[slot] = (u8)i;
+    if (i >= 256) bit8[slot >> 5] |= 1u << (slot & 31);
+  }
+  return 0;
+}
+
+// decode one symbol with the limits in registers and the lists in the gang's LDS
+TBZ_DEV u32 canon_decode_g(u32 pk, const Canon& cn, const u16* dlt, const u8* sym8, const u32* bit8, u32 cap, u32& sym) {
+  u32 r16 = tbz_brev32(pk) >> 16;
+  u32 L = 1;
+#pragma unroll
+  for (int k = 0; k < 15; k++) L += r16 >= cn.lim[k] ? 1u : 0u;
+  u32 slot = ((r16 >> (16 - (L & 15))) + dlt[L & 15]) & 0xffff;
+  slot = slot < cap ? slot : 0;
+  u32 s = sym8[slot];
+  if (bit8) s |= ((bit8[slot >> 5] >> (slot & 31)) & 1u) << 8;
+  sym = s;
+  return L;
+}
+
+#define KG_CHECK(p0)                 \
+  do {                               \
+    if (st.br.pos > st.end_bit) {    \
+      st.fail_pos = (p0);            \
+      return SEG_UNDERRUN;           \
+    }                                \
+    if (st.br.pos > st.limit_bit) {  \
+      st.fail_pos = (p0);            \
+      return SEG_OVERSHOOT;          \
+    }                                \
+  } while (0)
+
+TBZ_DEV i32 kg_build_fixed(GangTables& gt, u8* sc) {
+  u8* lens = sc + K1_SC_LENS;
+  for (u32 i = 0; i < 320; i++) lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5;
+  i32 e = build_canon_g(lens, 288, gt.tmp, gt.ldlt, gt.lsym8, gt.lbit8, 9, gt.llim);
+  if (e) return e;
+  return build_canon_g(lens + 288, 32, gt.tmp, gt.ddlt, gt.dsym8, nullptr, 0, gt.dlim);
+}
+
+// leader: :dynamic-huffman-block … :dht-len-table-data (deflate.lisp:577-669)
+TBZ_DEV i32 kg_dynamic_header(GangTables& gt, K1State& st, u8* sc) {
+  const u64 p0 = st.br.pos;
+  u32 pk = br_peek(st.br);
+  u32 hlit = (pk & 31) + 257, hdist = ((pk >> 5) & 31) + 1, hclen = ((pk >> 10) & 15) + 4;
+  br_skip(st.br, 14);
+  KG_CHECK(p0);
+  u8* lens = sc + K1_SC_LENS;
+  for (u32 i = 0; i < 19; i++) lens[i] = 0;
+  for (u32 i = 0; i < hclen; i++) {
+    u32 v = br_peek(st.br) & 7;
+    br_skip(st.br, 3);
+    lens[c_cl_order[i]] = (u8)v;
+  }
+  KG_CHECK(p0);
+  // the code-length code borrows the distance alphabet's slots (the distance code is built last)
+  i32 e = build_canon_g(lens, 19, gt.tmp, gt.ddlt, gt.dsym8, nullptr, 0, gt.dlim);
+  if (e) return e;
+  Canon ccl;
+  for (int k = 0; k < 15; k++) ccl.lim[k] = gt.dlim[k];
+  ccl.min_len = gt.dlim[15];
+  const u32 n = hlit + hdist;
+  u32 i = 0, last = 0xff;
+  while (i < n) {
+    const u64 ps = st.br.pos;
+    pk = br_peek(st.br);
+    u32 sym;
+    u32 L = canon_decode_g(pk, ccl, gt.ddlt, gt.dsym8, nullptr, 32, sym);
+    if (L > 15) {
+      if (st.br.pos + ccl.min_len > st.end_bit) {
+        st.fail_pos = ps;
+        return SEG_UNDERRUN;
+      }
+      return E_INVALID_CODE;
+    }
+    u32 xb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
+    u32 x = tbz_bfe(pk, L, xb);
+    br_skip(st.br, L + xb);
+    KG_CHECK(ps);
+    if (sym < 16) {
+      lens[i++] = (u8)sym;
+      last = sym;
+    } else {
+      u32 rep, val;
+      if (sym == 16) {
+        if (last >= 16) return E_REPEAT_NO_PREV;
+        rep = 3 + x;
+        val = last;
+      } else {
+        rep = (sym == 17 ? 3 : 11) + x;
+        val = 0;
+        last = 0;
+      }
+      if (i + rep > n) return E_REPEAT_OVERRUN;
+      for (u32 k = 0; k < rep; k++) lens[i + k] = (u8)val;
+      i += rep;
+    }
+  }
+  e = build_canon_g(lens, hlit, gt.tmp, gt.ldlt, gt.lsym8, gt.lbit8, 9, gt.llim);
+  if (e) return e;
+  return build_canon_g(lens + hlit, hdist, gt.tmp, gt.ddlt, gt.dsym8, nullptr, 0, gt.dlim);
+}
+#undef KG_CHECK
+
+// what one lane reports for one round
+enum { RF_STOP = 0, RF_EOB, RF_LIMIT, RF_CODE_LIT, RF_CODE_DIST, RF_SYM, RF_JUNK };
+struct RoundOut {
+  u64 c;     // bit position where the lane started recording (~0: never did)
+  u64 e;     // RF_STOP: start of the first token at/after `stop`; RF_EOB: bit after the end-of-block code;
+             // failures: start of the failing token
+  u64 aux;   // failures: bit position reached inside the failing token
+  u32 n;     // token words staged
+  u32 out;   // octets they produce
+  i32 mdef;  // max over recorded matches of (distance - octets this lane produced before the match)
+  u32 flag;
+};
+
+// One lane's share of a round: decode from `start`, record tokens whose start is >= rec_from, stop at
+// the first token start >= stop (or end-of-block / failure).  Same token loop as k1_decode_block.
+TBZ_DEV void kg_lane_round(const GangTables& gt, BitReader& B, const Canon& ll, const Canon& ld, u64 start,
+                           u64 rec_from, u64 stop, u64 lim64, u16* stage, RoundOut& ro) {
+  const u32 lane = tbz_lane();
+  enum { RUN = 0, AT_STOP, DONE_EOB, FAIL_LIMIT, FAIL_CODE_LIT, FAIL_CODE_DIST, FAIL_SYM };
+  B.bw = 1ull << 62;
+  br_seek(B, start);
+  bool rec = false;
+  u64 c = ~0ull;
+  u32 n = 0, out = 0;
+  i32 mdef = -(1 << 30);
+  for (;;) {
+    br_refill(B);
+    u32 lo = B.lo, hi = B.hi, nx = B.nx, o = B.o;
+    u32 k = 3;
+    i32 rem = lim64 <= B.pos ? 0 : ((lim64 - B.pos) > 0x7fffff00ull ? 0x7fffff00 : (i32)(lim64 - B.pos));
+    const i32 rem_start = rem;
+    i32 rem_tok = rem;
+    const u32 rec_rel = rec_from <= B.pos ? 0u : ((rec_from - B.pos) > 0x7fffff00ull ? 0x7fffff00u : (u32)(rec_from - B.pos));
+    const u32 stop_rel = stop <= B.pos ? 0u : ((stop - B.pos) > 0x7fffff00ull ? 0x7fffff00u : (u32)(stop - B.pos));
+    u32 why = RUN;
+#define KG_SKIP(nb)                  \
+  do {                               \
+    o += (nb);                       \
+    rem -= (i32)(nb);                \
+    const u32 nw_ = B.buf[k][lane];  \
+    const bool ge_ = o >= 32;        \
+    o = ge_ ? o - 32 : o;            \
+    lo = ge_ ? hi : lo;              \
+    hi = ge_ ? nx : hi;              \
+    nx = ge_ ? nw_ : nx;             \
+    k += ge_ ? 1u : 0u;              \
+  } while (0)
+    for (u32 it = 0; it < K1_PHASE && k < K1_INBUF - 3; it++) {
+      rem_tok = rem;
+      const u32 rel = (u32)(rem_start - rem);
+      if (rel >= stop_rel) { why = AT_STOP; break; }
+      if (!rec && rel >= rec_rel) {
+        rec = true;
+        c = B.pos + rel;
+      }
+      u32 pk = tbz_alignbit(hi, lo, o);
+      u32 sym;
+      u32 L = canon_decode_g(pk, ll, gt.ldlt, gt.lsym8, gt.lbit8, 288, sym);
+      if (L > 15) { why = FAIL_CODE_LIT; break; }
+      if (sym < 256) {
+        KG_SKIP(L);
+        if (rem < 0) { why = FAIL_LIMIT; break; }
+        if (rec) {
+          stage[n] = (u16)sym;
+          n += 1;
+          out += 1;
+        }
+      } else if (sym == 256) {
+        KG_SKIP(L);
+        if (rem < 0) { why = FAIL_LIMIT; break; }
+        why = DONE_EOB;
+        break;
+      } else {
+        if (sym > 285) {
+          KG_SKIP(L);
+          why = rem < 0 ? FAIL_LIMIT : FAIL_SYM;
+          break;
+        }
+        u32 base, X;
+        len_base_extra(sym - 257, base, X);
+        u32 len = base + tbz_bfe(pk, L, X);
+        KG_SKIP(L + X);
+        u32 pd = tbz_alignbit(hi, lo, o);
+        u32 ds;
+        u32 DL = canon_decode_g(pd, ld, gt.ddlt, gt.dsym8, nullptr, 32, ds);
+        if (DL > 15) { why = FAIL_CODE_DIST; break; }
+        if (ds > 29) {
+          KG_SKIP(DL);
+          why = rem < 0 ? FAIL_LIMIT : FAIL_SYM;
+          break;
+        }
+        u32 dbase, DX;
+        dist_base_extra(ds, dbase, DX);
+        u32 dist = dbase + tbz_bfe(pd, DL, DX);
+        KG_SKIP(DL + DX);
+        if (rem < 0) { why = FAIL_LIMIT; break; }
+        if (rec) {
+          i32 d = (i32)dist - (i32)out;
+          mdef = d > mdef ? d : mdef;
+          stage[n] = (u16)(TOK_MATCH | (len - 3));
+          stage[n + 1] = (u16)(dist - 1);
+          n += 2;
+          out += len;
+        }
+      }
+    }
+#undef KG_SKIP
+    u32 used = (u32)(rem_start - rem);
+    u32 tok_bits = (u32)(rem_tok - rem);
+    B.pos += used;
+    B.wi += k - 3;
+    B.lo = lo;
+    B.hi = hi;
+    B.nx = nx;
+    B.o = o;
+    if (why == RUN) continue;
+    ro.aux = B.pos;
+    ro.e = B.pos - tok_bits;
+    ro.flag = why == AT_STOP ? RF_STOP : why == DONE_EOB ? RF_EOB : why == FAIL_LIMIT ? RF_LIMIT
+              : why == FAIL_CODE_LIT ? RF_CODE_LIT : why == FAIL_CODE_DIST ? RF_CODE_DIST : RF_SYM;
+    if (why == DONE_EOB) ro.e = B.pos;
+    break;
+  }
+  if (!rec) {  // ended (end-of-block / failure) during the run-up: nothing of this lane can be valid
+    c = ~0ull;
+    ro.flag = RF_JUNK;
+  }
+  ro.c = c;
+  ro.n = n;
+  ro.out = out;
+  ro.mdef = mdef;
+}
+
+// leader: what follows a block (deflate.lisp:719-722 + the container trailers + landing rules)
+TBZ_DEV void kg_block_end(GangState& gs, K1State& st, const Item& it, const K1gParams& P, u32 fmt, bool fixup) {
+  st.br.bw = 1ull << 62;
+  br_seek(st.br, gs.P);
+  if (gs.bfinal) {
+    gs.status = SEG_FINAL;
+    br_skip(st.br, (u32)((0 - st.br.pos) & 7));
+    if (fmt == 1) {
+      if (st.br.pos + 32 <= st.end_bit) {
+        u32 v = br_peek(st.br);
+        br_skip(st.br, 32);
+        gs.tr0 = (v >> 24) | ((v >> 8) & 0xff00) | ((v << 8) & 0xff0000) | (v << 24);
+        gs.tr_have = 2;
+      }
+    } else if (fmt == 2) {
+      if (st.br.pos + 32 <= st.end_bit) {
+        gs.tr0 = br_peek(st.br);
+        br_skip(st.br, 32);
+        gs.tr_have = 1;
+        if (st.br.pos + 32 <= st.end_bit) {
+          gs.tr1 = br_peek(st.br);
+          br_skip(st.br, 32);
+          gs.tr_have = 2;
+        }
+      }
+    } else {
+      gs.tr_have = 2;
+    }
+    gs.P = st.br.pos;
+    gs.mode = GM_DONE;
+    return;
+  }
+  if (!fixup) {
+    if (gs.P == st.limit_bit) {
+      gs.status = SEG_LANDED;
+      gs.mode = GM_DONE;
+      return;
+    }
+  } else if ((gs.P & 7) == 0) {
+    u64 b = gs.P >> 3;
+    u32 lo = 0, hi = P.n_markers;
+    while (lo < hi) {
+      u32 mid = (lo + hi) >> 1;
+      if (P.markers[mid] < b) lo = mid + 1; else hi = mid;
+    }
+    if (lo < P.n_markers && P.markers[lo] == b) {
+      gs.land = lo;
+      gs.status = SEG_LANDED;
+      gs.mode = GM_DONE;
+      return;
+    }
+  }
+  gs.mode = GM_HEADER;
+}
+
+// leader: block header at gs.P (deflate.lisp:518-573); stored blocks are handled completely here
+TBZ_DEV void kg_leader_header(GangTables& gt, GangState& gs, K1State& st, const Item& it, const K1gParams& P,
+                              u16* tok0, u8* sc, u32 fmt, bool fixup) {
+  st.br.bw = 1ull << 62;
+  br_seek(st.br, gs.P);
+  gs.blk_pos = gs.P;
+  gs.blk_prod = gs.produced;
+  gs.blk_tok = gs.T;
+  u32 pk = br_peek(st.br);
+  br_skip(st.br, 3);
+  if (st.br.pos > st.end_bit) { gs.fail_pos = gs.blk_pos; gs.status = SEG_UNDERRUN; gs.mode = GM_DONE; return; }
+  if (st.br.pos > st.limit_bit) { gs.status = SEG_OVERSHOOT; gs.mode = GM_DONE; return; }
+  gs.bfinal = pk & 1;
+  const u32 btype = (pk >> 1) & 3;
+  if (btype == 0) {
+    br_skip(st.br, (u32)((0 - st.br.pos) & 7));
+    const u64 ph = st.br.pos;
+    u32 ln = br_peek(st.br);
+    br_skip(st.br, 32);
+    if (st.br.pos > st.end_bit) { gs.fail_pos = ph; gs.status = SEG_UNDERRUN; gs.mode = GM_DONE; return; }
+    u32 LEN = ln & 0xffff, NLEN = ln >> 16;
+    if (NLEN != ((~LEN) & 0xffff)) { gs.status = E_STORED_LEN; gs.mode = GM_DONE; return; }
+    u64 byte0 = st.br.pos >> 3;
+    if ((byte0 + LEN) * 8 > st.limit_bit) { gs.status = SEG_OVERSHOOT; gs.mode = GM_DONE; return; }
+    u64 avail = it.end_byte - byte0;
+    u32 ncopy = avail < LEN ? (u32)avail : LEN;
+    if (ncopy) {
+      u16* t = tok0 + gs.T;
+      t[0] = (u16)(TOK_STORED | (ncopy & 0x3fff));
+      t[1] = (u16)((ncopy >> 14) | ((u32)(byte0 & 0x1fff) << 2));
+      t[2] = (u16)((byte0 >> 13) & 0x7fff);
+      t[3] = (u16)((byte0 >> 28) & 0x7fff);
+      gs.T += 4;
+      gs.produced += ncopy;
+    }
+    if (ncopy < LEN) { gs.fail_pos = (byte0 + ncopy) * 8; gs.status = SEG_UNDERRUN; gs.mode = GM_DONE; return; }
+    gs.P = (byte0 + LEN) * 8;
+    kg_block_end(gs, st, it, P, fmt, fixup);
+    return;
+  }
+  if (btype == 3) { gs.status = E_BTYPE; gs.mode = GM_DONE; return; }
+  i32 e = 0;
+  if (btype == 1) {
+    if (gs.tables != 1) e = kg_build_fixed(gt, sc);
+    gs.tables = 1;
+  } else {
+    e = kg_dynamic_header(gt, st, sc);
+    gs.tables = 2;
+  }
+  if (e) {
+    gs.status = e;
+    gs.fail_pos = st.fail_pos;
+    gs.mode = GM_DONE;
+    return;
+  }
+  gs.P = st.br.pos;
+  gs.mode = GM_BLOCK;
+}
+
+template <int G>
+TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
+  constexpr u32 NG = 64 / G;
+  const u32 lane = tbz_lane();
+  const u32 gang = lane / G, g = lane % G, base = lane - g;
+  const bool leader = g == 0;
+  const u32 idx = tbz_block() * NG + gang;
+  const bool have = idx < P.n_items;
+  GangTables& gt = S.gt[gang];
+  GangState& gs = S.gs[gang];
+  Item it{};
+  if (have) it = P.items[idx];
+  const u32 fmt = (it.flags >> ITEM_FMT_SHIFT) & 3;
+  const bool fixup = (it.flags & ITEM_FIXUP) != 0;
+  u8* sc = P.scratch + (u64)(have ? idx : 0) * K1_SCRATCH;
+  u16* tok0 = P.tok + it.start_bit;
+  u16* stage = P.stage + ((u64)tbz_block() * 64 + lane) * KG_STAGE;
+  K1State st;
+  br_init(st.br, P.in_base, it.end_byte, S.inbuf);
+  st.end_bit = it.end_byte * 8;
+  st.limit_bit = fixup ? ~0ull : it.limit_bit;
+  st.produced = 0;
+  st.deficit = 0;
+  st.tok0 = tok0;
+  st.tok = tok0;
+  st.fail_pos = it.start_bit;
+  const u64 lim64 = st.end_bit < st.limit_bit ? st.end_bit : st.limit_bit;
+
+  if (leader) {
+    gs.P = it.start_bit;
+    gs.T = 0;
+    gs.produced = 0;
+    gs.blk_pos = it.start_bit;
+    gs.blk_prod = 0;
+    gs.blk_tok = 0;
+    gs.fail_pos = it.start_bit;
+    gs.status = 0;
+    gs.mode = have ? GM_HEADER : GM_DONE;
+    gs.bfinal = 0;
+    gs.deficit = 0;
+    gs.tables = 0;
+    gs.land = 0xFFFFFFFFu;
+    gs.tr0 = gs.tr1 = gs.tr_have = 0;
+    gs.rounds = gs.valid_lanes = 0;
+    if (have && (it.flags & ITEM_HEAD)) {
+      br_seek(st.br, it.start_bit);
+      i32 e = k1_container_header(st, fmt);
+      if (e) {
+        gs.status = e;
+        gs.fail_pos = st.fail_pos;
+        gs.mode = GM_DONE;
+      }
+      gs.P = st.br.pos;
+    }
+  }
+
+  for (;;) {
+    tbz_sync();
+    if (tbz_ballot(gs.mode != GM_DONE) == 0) break;
+    // ---- H: leaders whose gang is between blocks parse the next header / build the next code
+    if (leader && gs.mode == GM_HEADER) kg_leader_header(gt, gs, st, it, P, tok0, sc, fmt, fixup);
+    tbz_sync();
+    // ---- R: one round for the gangs that are inside a Huffman block
+    const bool inblk = gs.mode == GM_BLOCK;
+    const u64 Pb = gs.P;
+    RoundOut ro;
+    ro.c = ~0ull;
+    ro.e = 0;
+    ro.aux = 0;
+    ro.n = 0;
+    ro.out = 0;
+    ro.mdef = -(1 << 30);
+    ro.flag = RF_JUNK;
+    if (inblk) {
+      Canon ll, ld;
+#pragma unroll
+      for (int k = 0; k < 15; k++) {
+        ll.lim[k] = gt.llim[k];
+        ld.lim[k] = gt.dlim[k];
+      }
+      ll.min_len = gt.llim[15];
+      ld.min_len = gt.dlim[15];
+      const u64 s_g = Pb + (u64)g * KG_SUB;
+      const u64 start = (g == 0 || s_g < Pb + KG_OVL) ? Pb : s_g - KG_OVL;
+      kg_lane_round(gt, st.br, ll, ld, start, g == 0 ? Pb : s_g, s_g + KG_SUB, lim64, stage, ro);
+    }
+    // ---- chain validation: lane g counts iff it began recording exactly where lane g-1 stopped
+    const u32 pe_lo = tbz_wave_shr1((u32)ro.e), pe_hi = tbz_wave_shr1((u32)(ro.e >> 32));
+    const u64 prev_e = ((u64)pe_hi << 32) | pe_lo;
+    const u32 prev_flag = tbz_wave_shr1(ro.flag);
+    const bool link = inblk && ro.flag != RF_JUNK && (g == 0 || (ro.c == prev_e && prev_flag == RF_STOP));
+    const u64 okm = tbz_ballot(link);
+    constexpr u64 GMASK = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1);
+    const u64 gm = (okm >> base) & GMASK;
+    const u32 v = gm == GMASK ? (u32)G : (u32)__builtin_ctzll(~gm);  // valid lanes of my gang
+    const bool valid = g < v;
+    const u32 nn = valid ? ro.n : 0, oo = valid ? ro.out : 0;
+    const u32 in_n = tbz_wave_incl_scan_u32(nn), in_o = tbz_wave_incl_scan_u32(oo);
+    const u32 bn = tbz_shfl(in_n, base ? (int)base - 1 : 0), bo = tbz_shfl(in_o, base ? (int)base - 1 : 0);
+    const u32 base_n = base ? bn : 0, base_o = base ? bo : 0;
+    const u32 D = in_n - nn - base_n, PO = in_o - oo - base_o;
+    const u32 tot_n = tbz_shfl(in_n, (int)(base + G - 1)) - base_n;
+    const u32 tot_o = tbz_shfl(in_o, (int)(base + G - 1)) - base_o;
+    // ---- commit: compact the valid runs into the item's contiguous token stream
+    if (valid) {
+      // 16-octet chunks, four loads in flight before their stores (an element-wise loop would be one
+      // memory round trip per token: the compiler must assume dst may alias stage)
+      u16* dst16 = tok0 + gs.T + D;
+      U16x8* dst = (U16x8*)dst16;
+      const uint4* src = (const uint4*)stage;  // the lane's staging area is 16-octet aligned
+      const u32 nfull = ro.n >> 3;
+      for (u32 c0 = 0; c0 < nfull; c0 += 4) {
+        uint4 v0 = src[c0], v1, v2, v3;
+        if (c0 + 1 < nfull) v1 = src[c0 + 1];
+        if (c0 + 2 < nfull) v2 = src[c0 + 2];
+        if (c0 + 3 < nfull) v3 = src[c0 + 3];
+        dst[c0].v = v0;
+        if (c0 + 1 < nfull) dst[c0 + 1].v = v1;
+        if (c0 + 2 < nfull) dst[c0 + 2].v = v2;
+        if (c0 + 3 < nfull) dst[c0 + 3].v = v3;
+      }
+      const u32 rest = ro.n & 7;  // never write past the run: the next word belongs to the next lane's run
+      if (rest) {
+        uint4 t = src[nfull];
+        u32 w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (u32 k = 0; k < 7; k++)
+          if (k < rest) dst16[nfull * 8 + k] = (u16)(w[k >> 1] >> ((k & 1) * 16));
+      }
+    }
+    // history check material: largest (distance - octets produced before the match) over the round
+    u64 hb = gs.produced + PO;
+    i32 hbase = hb > (1u << 30) ? (1 << 30) : (i32)hb;
+    i32 cand = (valid && ro.mdef > -(1 << 29)) ? ro.mdef - hbase : -(1 << 30);
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) {
+      i32 t = (i32)tbz_shfl_xor((u32)cand, m);
+      cand = t > cand ? t : cand;
+    }
+    const u32 lv = base + (v ? v - 1 : 0);
+    const u64 e_last = tbz_shfl64(ro.e, (int)lv), aux_last = tbz_shfl64(ro.aux, (int)lv);
+    const u32 flag_last = tbz_shfl(ro.flag, (int)lv);
+    tbz_sync();
+    if (leader && inblk) {
+      gs.rounds += 1;
+      gs.valid_lanes += v;
+      gs.T += tot_n;
+      gs.produced += tot_o;
+      if (cand > 0 && (u32)cand > gs.deficit) gs.deficit = (u32)cand;
+      if (flag_last == RF_STOP) {
+        gs.P = e_last;
+      } else if (flag_last == RF_EOB) {
+        gs.P = e_last;
+        kg_block_end(gs, st, it, P, fmt, fixup);
+      } else if (flag_last == RF_LIMIT) {
+        gs.fail_pos = e_last;
+        gs.status = aux_last > st.end_bit ? SEG_UNDERRUN : SEG_OVERSHOOT;
+        gs.mode = GM_DONE;
+      } else if (flag_last == RF_SYM) {
+        gs.status = E_INVALID_CODE;
+        gs.mode = GM_DONE;
+      } else {  // unassigned bit pattern: error unless the input ends inside the bits the reference needs
+        u32 need = flag_last == RF_CODE_LIT ? gt.llim[15] : gt.dlim[15];
+        if (aux_last + need > st.end_bit) {
+          gs.fail_pos = e_last;
+          gs.status = SEG_UNDERRUN;
+        } else {
+          gs.status = E_INVALID_CODE;
+        }
+        gs.mode = GM_DONE;
+      }
+    }
+  }
+
+  if (leader && have) {
+    SegResult r;
+    if (gs.status == SEG_OVERSHOOT) {
+      r.end_bit = gs.blk_pos;
+      r.out_bytes = gs.blk_prod;
+      r.tok_words = gs.blk_tok;
+    } else {
+      r.end_bit = gs.status == SEG_UNDERRUN ? gs.fail_pos : gs.P;
+      r.out_bytes = gs.produced;
+      r.tok_words = gs.T;
+    }
+    r.status = gs.status;
+    r.max_deficit = gs.deficit;
+    r.trailer0 = gs.tr0;
+    r.trailer1 = gs.tr1;
+    r.trailer_have = gs.tr_have;
+    r.land_marker = gs.land;
+    r.reserved = ((u64)gs.rounds << 32) | gs.valid_lanes;
+    P.res[idx] = r;
+  }
+}
+
+#define TBZ_K1G_KERNEL(G)                                   \
+  TBZ_KERNEL void tbz_k1g##G##_huff_decode(K1gParams P) {   \
+    TBZ_SHARED KgLds<G> S;                                  \
+    k1g_body<G>(P, S);                                      \
+  }
+TBZ_K1G_KERNEL(4)
+TBZ_K1G_KERNEL(8)
+TBZ_K1G_KERNEL(16)
+TBZ_K1G_KERNEL(32)
+TBZ_K1G_KERNEL(64)
+#undef TBZ_K1G_KERNEL
 
 // ================================================================================================
 // K2 — LZ77 resolve: tokens -> LDS ring window -> coalesced 16-byte stores.  One wave per group.

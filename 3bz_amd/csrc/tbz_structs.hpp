@@ -85,8 +85,8 @@ struct CkPartial {
   uint32_t b;  // adler: sum of (len-i)*octet mod 65521 crc: unused
 };
 
-constexpr uint32_t CK_CHUNK = 64u << 10;   // octets per checksum workgroup
-constexpr uint32_t SCAN_TILE = 16u << 10;  // octets per marker-scan workgroup
+constexpr uint32_t CK_CHUNK = 256u << 10;  // octets per checksum workgroup
+constexpr uint32_t SCAN_TILE = 64u << 10;  // octets per marker-scan workgroup
 
 // crc constants table layout (u32 words), filled by the host at context creation
 constexpr uint32_t CRC_T = 0;         // 256: classic reflected table (checksums.lisp:177-193)

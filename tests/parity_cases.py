@@ -318,8 +318,8 @@ def case_device_buffers(eng, n=64 << 10):
 def case_checksum_kernels(eng):
     """K4/K5 against the oracle's adler32/ub64 and crc32/table incl. the chaining convention"""
     rng = random.Random(5)
-    base = bytes(rng.getrandbits(8) for _ in range(70_000)) + b"\xff" * 70_000
-    for n in (0, 1, 3, 4, 255, 256, 257, 1023, 65535, 65536, 65537, 131072 + 5, len(base)):
+    base = (bytes(rng.getrandbits(8) for _ in range(70_000)) + b"\xff" * 70_000) * 5  # 700 000: several 256 KiB chunks
+    for n in (0, 1, 3, 4, 255, 256, 257, 1023, 65535, 65536, 65537, 131072 + 5, 262144, 262145, 524288 + 77, len(base) - 8):
         for mis in (0, 1, 7):
             if n + mis > len(base):
                 continue

@@ -15,11 +15,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=["auto", "gang8", "gang64", "lane"])
+def eng(request):
+    """the three K1 flavours (TBZ_K1_MODE is read when a context is created)"""
     subprocess.check_call(["make", "-C", EMU_DIR, "libtbz_emu.so"], stdout=subprocess.DEVNULL)
     T = importlib.import_module("3bz_amd")
+    if request.param != "auto":
+        os.environ["TBZ_K1_MODE"] = request.param
     e = T.Engine(0, lib_path=os.path.join(EMU_DIR, "libtbz_emu.so"))
+    os.environ.pop("TBZ_K1_MODE", None)
     yield e
     e.close()
 

@@ -226,7 +226,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   std::vector<StreamPlan> sp(n);
   std::vector<uint64_t> h_off(n), h_len(n);
   std::vector<uint32_t> tile_first(n + 1);
-  uint64_t in_extent = 0, tiles = 0;
+  uint64_t in_extent = 0, tiles = 0, in_total_bits = 0;
   for (size_t s = 0; s < n; s++) {
     sp[s].in_off = in_offs[s];
     sp[s].in_len = in_lens[s];
@@ -235,6 +235,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     h_off[s] = in_offs[s];
     h_len[s] = in_lens[s];
     in_extent = std::max(in_extent, in_offs[s] + in_lens[s]);
+    in_total_bits += in_lens[s] * 8;
     tile_first[s] = (uint32_t)tiles;
     tiles += (in_lens[s] + SCAN_TILE - 1) / SCAN_TILE;
     if (tiles > 0x7fffffffu) return TBZ_E_ARG;
@@ -304,14 +305,17 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   if ((r = ensure(ctx, ctx->d_tok, (size_t)in_extent * 16 + 64))) return r;
   if ((r = upload(ctx, ctx->d_items, items))) return r;
   if ((r = ensure(ctx, ctx->d_res, items.size() * sizeof(SegResult)))) return r;
-  // K1 flavour.  One lane per item is bound by ONE item's serial chain (~1.1 us per token) until there
-  // are enough items to saturate instruction issue (~64 Ki lanes on an MI355X: measured equal at 65 536
-  // items); below that a gang of 8 (4) lanes per item shortens the chain 8x (4x) for ~25 % more work.
+  // K1 flavour.  One lane per item is bound by ONE item's serial chain (~1.1 us per token) and decodes
+  // without lookup tables; a gang of G lanes shares one item and one set of LDS tables.  G follows the
+  // average item size (a lane should get at least ~2 Kibit of bitstream per round); only batches of
+  // many tiny items (table set-up would dominate) stay with one lane per item.
   auto k1_gang = [&](size_t n_it) -> int {
     if (ctx->k1_mode) return ctx->k1_mode;
-    int G = 1;
-    while (G < 64 && n_it * (size_t)G * 2 <= 65536) G <<= 1;  // keep items x G around the chip's 64 Ki lanes
-    return G == 2 ? 4 : G;
+    uint64_t avg_bits = n_it ? in_total_bits / n_it : 0;
+    if (avg_bits < 8192 && n_it >= 16384) return 1;
+    int G = 8;
+    while (G < 64 && avg_bits > (uint64_t)G * 3072) G <<= 1;
+    return G;
   };
   auto items_per_wg = [](size_t n_it) {  // lane-per-item flavour: spread few items over all CUs
     u32 ipw = 64;
@@ -328,12 +332,12 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       return 0;
     }
     size_t per = 64 / G, nwg = (n_it + per - 1) / per;
-    int rr = ensure(ctx, ctx->d_stage, nwg * 64 * (size_t)KG_STAGE * 2);
+    // staging pool: addressed by bit position like the token pool
+    int rr = ensure(ctx, ctx->d_stage, (size_t)in_extent * 16 + (size_t)KG_STAGE_SLACK * 2);
     if (rr) return rr;
     K1gParams kg{(const u8*)d_in, (u16*)ctx->d_tok.p, (u16*)ctx->d_stage.p, d_items, d_res,
-                 (const u64*)ctx->d_markers.p, (u8*)ctx->d_scratch.p, (u32)markers.size(), (u32)n_it};
+                 (const u64*)ctx->d_markers.p, (u32)markers.size(), (u32)n_it};
     switch (G) {
-      case 4: TBZ_LAUNCH(tbz_k1g4_huff_decode, nwg, ctx->stream, kg); break;
       case 8: TBZ_LAUNCH(tbz_k1g8_huff_decode, nwg, ctx->stream, kg); break;
       case 16: TBZ_LAUNCH(tbz_k1g16_huff_decode, nwg, ctx->stream, kg); break;
       case 32: TBZ_LAUNCH(tbz_k1g32_huff_decode, nwg, ctx->stream, kg); break;
@@ -675,7 +679,7 @@ int tbz_ctx_create(int device_id, tbz_ctx** out_ctx) {
     if (!strcmp(m, "lane")) ctx->k1_mode = 1;
     else if (!strncmp(m, "gang", 4)) {
       int g = atoi(m + 4);
-      if (g == 4 || g == 8 || g == 16 || g == 32 || g == 64) ctx->k1_mode = g;
+      if (g == 8 || g == 16 || g == 32 || g == 64) ctx->k1_mode = g;
     }
   }
   *out_ctx = ctx;

@@ -876,34 +876,59 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
 // ================================================================================================
 // K1g — Huffman decode to tokens, a GANG of G lanes per item (intra-block parallel decode).
 //
-// With one lane per item, K1's run time is one item's serial chain of ~1.1 us per token, no matter how
-// many items there are (measured: 6.4 ms for 256 MiB and 7.2 ms for 1 GiB of 16 KiB segments).  Here G
-// lanes share one item.  The gang leader parses the block header and builds the code into the gang's
-// LDS; then the block is decoded in ROUNDS: lane g speculatively decodes the sub-range
-// [P + g*SUB, P + (g+1)*SUB) of the bitstream, starting OVL bits early so that — Huffman codes being
-// self-synchronising — it is almost always on a true token boundary by the time its sub-range begins.
-// A lane's tokens count only if it started recording exactly where its predecessor stopped
-// (start_g == end_{g-1}, and lane 0 starts at the known-good P): that equality is exact, a lane that
-// starts at a true boundary decodes the true sequence, so there are no false positives.  The valid
-// prefix of lanes is committed (token runs compacted from per-lane staging into the item's contiguous
-// token stream — K2 and the host see exactly what the lane-per-item kernel produces), P moves to the
-// last valid lane's end, and the next round starts.  A mis-synchronised lane only shortens a round.
+// With one lane per item, K1's run time is one item's serial chain of ~1.1 us per token, and a lane
+// cannot afford lookup tables (64 private tables do not fit the LDS).  Here G lanes share one item
+// and ONE set of tables in the gang's LDS:
+//   * the gang leader parses the block header (code lengths decoded through a 7-bit table);
+//   * all G lanes build the canonical codes together (per-lane symbol chunks, packed 16-bit
+//     counters, a gang prefix sum for the canonical ranks) and fill direct-lookup tables
+//     (KG_TBL-bit for literal/length, KG_TBD-bit for distance; longer codes take a compare-count
+//     path over the few remaining limits);
+//   * the block is decoded in ROUNDS: lane g speculatively decodes the sub-range
+//     [P + g*SUB, P + (g+1)*SUB) of the bitstream, starting OVL bits early so that — Huffman codes
+//     being self-synchronising — it is almost always on a true token boundary by the time its
+//     sub-range begins.  A lane's tokens count only if it started recording exactly where its
+//     predecessor stopped (start_g == end_{g-1}; lane 0 starts at the known-good P): that equality
+//     is exact, a lane that starts at a true boundary decodes the true sequence, so there are no
+//     false positives.  The valid prefix of lanes is committed (token runs compacted from the
+//     position-addressed staging pool into the item's contiguous token stream — K2 and the host see
+//     exactly what the lane-per-item kernel produces), P moves to the last valid lane's end, and the
+//     next round starts.  A mis-synchronised lane only shortens a round.
+// SUB adapts to what is left of the item (the next marker is where the segment is expected to end),
+// so a 16 KiB-segment item is one round.
 // ================================================================================================
-constexpr u32 KG_SUB = 2048;            // bits of bitstream per lane per round
+#ifndef KG_EXP
+#define KG_EXP 0
+#endif
+constexpr u32 KG_TBL = 9;               // index bits of the literal/length lookup table (first level)
+constexpr u32 KG_TBD = 8;               // index bits of the distance lookup table (first level)
+constexpr u32 KG_LPOOL = 352;           // second-level entries (codes longer than the index); zlib's ENOUGH bound is 340
+constexpr u32 KG_DPOOL = 128;           //   … if a code needs more, its long codes take the exact (slow) step instead
+constexpr u32 KG_SUB_MIN = 1024;        // bits of bitstream per lane per round
+constexpr u32 KG_SUB_MAX = 8192;
 constexpr u32 KG_OVL = 512;             // run-up bits before a lane's sub-range
-constexpr u32 KG_STAGE = KG_SUB + 64;   // staged token words per lane per round (words <= bits)
+constexpr u32 KG_STAGE_SLACK = 16384;   // words of slack at the end of the staging pool
 
-struct GangTables {  // per gang, in LDS; written by the leader, read by all G lanes
-  u8 lsym8[288];
-  u32 lbit8[9];
-  u16 ldlt[16];
-  u8 dsym8[32];
-  u16 ddlt[16];
-  u32 llim[16];  // [0..14] left-aligned limits, [15] shortest code length
+// lookup entries (u16).  bits 0-3: code length; 0 = not a symbol:
+//     whole entry 0          unassigned pattern, or a long code without a second-level table -> exact step
+//     otherwise              bits 4-6 = b, bits 7-15 = off: the symbol is at pool[off + next b stream bits]
+//   lit/len:  bits 4-11 literal octet | (length base - 3);  bits 12-15: 0 literal, 8+X match with X extra
+//             bits, 7 end of block, 6 symbol 286/287
+//   distance: bits 4-8 distance symbol
+struct GangTables {  // per gang, in LDS
+  u16 lfast[(1u << KG_TBL) + KG_LPOOL];
+  u16 dfast[(1u << KG_TBD) + KG_DPOOL];  // while a header is parsed: octets 0-127 the code-length code's 7-bit
+                                         // table, octets 128-447 the code lengths (the table is filled last)
+  u16 lsym[288];            // lit/len symbols in canonical order
+  u8 dsym[32];
+  u32 llim[16];             // [0..14] left-aligned limits, [15] shortest code length
   u32 dlim[16];
-  u16 tmp[32];
+  u16 ldlt[16];             // slot in canonical order = (code of length L) + dlt[L]  (mod 2^16)
+  u16 ddlt[16];
 };
-enum { GM_HEADER = 0, GM_BLOCK = 1, GM_DONE = 2 };
+static_assert(((1u << KG_TBD) + KG_DPOOL) * 2 >= 448, "dfast doubles as header scratch");
+TBZ_DEV u8* kg_lens(GangTables& gt) { return (u8*)gt.dfast + 128; }
+enum { GM_HEADER = 0, GM_BUILD = 1, GM_BLOCK = 2, GM_DONE = 3 };
 struct GangState {  // per gang, in LDS; owned by the leader
   u64 P;            // GM_BLOCK: bit position of the next token; GM_HEADER: of the next block header
   u64 T;            // token words committed so far
@@ -911,8 +936,10 @@ struct GangState {  // per gang, in LDS; owned by the leader
   u64 blk_pos, blk_prod, blk_tok;
   u64 fail_pos;
   i32 status;
-  u32 mode, bfinal, deficit, tables, land, tr0, tr1, tr_have, pad;
+  u32 mode, bfinal, deficit, tables, land, tr0, tr1, tr_have;
+  u32 hlit, hdist, fixed;   // GM_BUILD: alphabet sizes; fixed: the lanes write the fixed code lengths first
   u32 rounds, valid_lanes;  // diagnostics: rounds run and lanes committed (efficiency = valid_lanes / (G*rounds))
+  u32 pad;
 };
 template <int G>
 struct KgLds {
@@ -924,11 +951,10 @@ struct KgLds {
 struct K1gParams {
   const u8* in_base;
   u16* tok;       // final token pool (as K1Params::tok)
-  u16* stage;     // n_workgroups * 64 * KG_STAGE words of per-lane staging
+  u16* stage;     // staging pool, addressed by bit position like the token pool (+ KG_STAGE_SLACK words)
   const Item* items;
   SegResult* res;
   const u64* markers;
-  u8* scratch;    // n_items * K1_SCRATCH
   u32 n_markers;
   u32 n_items;
 };
@@ -937,17 +963,68 @@ struct __attribute__((packed, aligned(2))) U16x8 {  // eight token words at 2-oc
   uint4 v;
 };
 
-// leader-only canonical build into the gang's tables (same rules as build_canon)
-TBZ_DEV i32 build_canon_g(const u8* lens, u32 n, u16* tmp, u16* dlt, u8* sym8, u32* bit8, u32 nbit8, u32* lim) {
-  for (int L = 0; L < 16; L++) tmp[L] = 0;
-  for (u32 i = 0; i < n; i++) {
-    u32 l = lens[i];
-    if (l) tmp[l] = (u16)(tmp[l] + 1);
+// position the reader at `pos` with a freshly loaded window
+TBZ_DEV void br_seek_fill(BitReader& b, u64 pos) {
+  b.wi = (pos + b.bias) >> 5;
+  br_refill(b);
+  br_seek(b, pos);
+}
+// keep the words br_skip will want inside the window
+TBZ_DEV void br_ensure(BitReader& b) {
+  if (b.wi + 4 > b.bw + K1_INBUF) br_refill(b);
+}
+
+TBZ_DEV u32 kg_lit_entry(u32 sym, u32 L) {
+  u32 base, X;
+  len_base_extra((sym - 257) & 31, base, X);
+  u32 m = L | ((base - 3) << 4) | ((8 | X) << 12);
+  return sym < 256 ? (L | (sym << 4)) : sym == 256 ? (L | (7u << 12)) : sym > 285 ? (L | (6u << 12)) : m;
+}
+
+// Canonical code of one alphabet built by the G lanes of a gang (same acceptance rules as build_canon:
+// huffman-tree.lisp:112-122), plus its two-level lookup table.  EVERY lane of the wave calls this (it
+// contains wave collectives); a gang that is not building passes n = 0 and touches nothing.
+template <int G, u32 TB, u32 POOL, bool LIT, typename SymT>
+TBZ_DEV i32 kg_build(const u8* lens, u32 n, SymT* sorted, u32* lim, u16* dlt, u16* fast, u32 g, u32 base) {
+  const bool leader = g == 0;
+  // 1. per-lane chunk of symbols: counts per code length, two 16-bit counters per word
+  const u32 ch = (n + G - 1) / G;
+  const u32 i0 = g * ch;
+  const u32 i1 = i0 + ch < n ? i0 + ch : n;
+  u32 own[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) own[k] = 0;
+  for (u32 i = i0; i < i1; i++) {
+    const u32 l = lens[i];
+    const u32 inc = l ? 1u << ((l & 1) * 16) : 0u;
+    const u32 w = l >> 1;
+#pragma unroll
+    for (int k = 0; k < 8; k++) own[k] += w == (u32)k ? inc : 0u;
   }
+  // 2. gang prefix sums: symbols of each length in the chunks before mine, and the totals
+  u32 inc_[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) inc_[k] = own[k];
+#pragma unroll
+  for (u32 d = 1; d < (u32)G; d <<= 1) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const u32 t = tbz_shfl_up(inc_[k], d);
+      inc_[k] += g >= d ? t : 0u;
+    }
+  }
+  u32 tot[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) tot[k] = tbz_shfl(inc_[k], (int)(base + G - 1));
+  // 3. canonical parameters (every lane computes them; the leader publishes what the decoders read)
   u32 used = 0, code = 0, off = 0, prev = 0, min_len = 0;
   i32 left = 1, err = 0;
+  u32 offp[8], limr[15];
+#pragma unroll
+  for (int k = 0; k < 8; k++) offp[k] = 0;
+#pragma unroll
   for (int L = 1; L < 16; L++) {
-    u32 c = tmp[L];
+    const u32 c = (tot[L >> 1] >> ((L & 1) * 16)) & 0xffffu;
     left <<= 1;
     if ((i32)c > left && !err) err = E_OVERSUB;
     left -= (i32)c;
@@ -955,38 +1032,111 @@ TBZ_DEV i32 build_canon_g(const u8* lens, u32 n, u16* tmp, u16* dlt, u8* sym8, u
     if (c && !min_len) min_len = L;
     code = (code + prev) << 1;
     prev = c;
-    tmp[L] = (u16)off;
-    dlt[L] = (u16)(off - code);
-    lim[L - 1] = (code + c) << (16 - L);
+    offp[L >> 1] |= off << ((L & 1) * 16);
+    limr[L - 1] = (code + c) << (16 - L);
+    if (leader && n) {
+      dlt[L] = (u16)(off - code);
+      lim[L - 1] = limr[L - 1];
+    }
     off += c;
   }
-  lim[15] = min_len;
+  if (leader && n) lim[15] = min_len;
   if (!err && left > 0 && used > 1) err = E_INCOMPLETE;
-  if (err) return err;
-  for (u32 k = 0; k < nbit8; k++) bit8[k] = 0;
-  for (u32 i = 0; i < n; i++) {
-    u32 l = lens[i];
-    if (!l) continue;
-    u32 slot = tmp[l];
-    tmp[l] = (u16)(slot + 1);
-    sym8[slot] = (u8)i;
-    if (i >= 256) bit8[slot >> 5] |= 1u << (slot & 31);
-  }
-  return 0;
-}
-
-// decode one symbol with the limits in registers and the lists in the gang's LDS
-TBZ_DEV u32 canon_decode_g(u32 pk, const Canon& cn, const u16* dlt, const u8* sym8, const u32* bit8, u32 cap, u32& sym) {
-  u32 r16 = tbz_brev32(pk) >> 16;
-  u32 L = 1;
+  const bool ok = n != 0 && err == 0;
+  // 4. canonical order: slot = first slot of the length + same-length symbols before this one
+  u32 nxt[8];
 #pragma unroll
-  for (int k = 0; k < 15; k++) L += r16 >= cn.lim[k] ? 1u : 0u;
-  u32 slot = ((r16 >> (16 - (L & 15))) + dlt[L & 15]) & 0xffff;
-  slot = slot < cap ? slot : 0;
-  u32 s = sym8[slot];
-  if (bit8) s |= ((bit8[slot >> 5] >> (slot & 31)) & 1u) << 8;
-  sym = s;
-  return L;
+  for (int k = 0; k < 8; k++) nxt[k] = offp[k] + inc_[k] - own[k];
+  if (ok) {
+    for (u32 i = i0; i < i1; i++) {
+      const u32 l = lens[i];
+      if (!l) continue;
+      const u32 w = l >> 1, sh = (l & 1) * 16;
+      u32 v = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) v = w == (u32)k ? nxt[k] : v;
+#pragma unroll
+      for (int k = 0; k < 8; k++) nxt[k] += w == (u32)k ? (1u << sh) : 0u;
+      sorted[(v >> sh) & 0xffffu] = (SymT)i;
+    }
+  }
+  // 5. second-level sizes: a prefix whose codes are longer than TB bits gets 2^(longest - TB) pool entries.
+  //    Lane g owns the left-aligned (MSB-first) prefixes [g*R, (g+1)*R); long prefixes are the ones at or
+  //    above the first value no code of <= TB bits reaches.
+  constexpr u32 R = (1u << TB) / G;
+  constexpr u32 SH = 16 - TB;
+  const u32 r0 = g * R;
+  u32 need = 0;
+  if (ok) {
+    for (u32 j = g; j < POOL; j += G) fast[(1u << TB) + j] = 0;
+    for (u32 t = 0; t < R; t++) {
+      const u32 r16 = (r0 + t) << SH;
+      if (r16 < limr[TB - 1]) continue;
+      const u32 last = r16 | ((1u << SH) - 1);
+      u32 Lm = TB + 1;
+#pragma unroll
+      for (u32 q = TB; q < 15; q++) Lm += last >= limr[q] ? 1u : 0u;
+      if (Lm <= 15) need += 1u << (Lm - TB);
+    }
+  }
+  u32 pin = need;
+#pragma unroll
+  for (u32 d = 1; d < (u32)G; d <<= 1) {
+    const u32 t = tbz_shfl_up(pin, d);
+    pin += g >= d ? t : 0u;
+  }
+  const u32 ptot = tbz_shfl(pin, (int)(base + G - 1));
+  const bool two = ptot <= POOL;  // else: no second level, long codes go through the exact step
+  tbz_sync();
+  // 6. first level: symbols are monotone in the prefix, so one compare-count decode serves a run of entries
+  if (ok) {
+    u32 r = r0, end_r = r, entry = 0, poff = pin - need;
+    for (u32 t = 0; t < R; t++, r++) {
+      if (r >= end_r) {
+        const u32 r16 = r << SH;
+        u32 L = 1;
+#pragma unroll
+        for (int k = 0; k < 15; k++) L += r16 >= limr[k] ? 1u : 0u;
+        if (L <= TB) {
+          const u32 slot = ((r16 >> (16 - L)) + dlt[L]) & 0xffffu;
+          const u32 sym = sorted[slot < n ? slot : 0];
+          entry = LIT ? kg_lit_entry(sym, L) : (L | (sym << 4));
+          end_r = ((r >> (TB - L)) + 1) << (TB - L);
+        } else {
+          const u32 last = r16 | ((1u << SH) - 1);
+          u32 Lm = TB + 1;
+#pragma unroll
+          for (u32 q = TB; q < 15; q++) Lm += last >= limr[q] ? 1u : 0u;
+          entry = 0;
+          if (L <= 15 && Lm <= 15) {
+            if (two) entry = ((Lm - TB) << 4) | (poff << 7);
+            poff += 1u << (Lm - TB);
+          }
+          end_r = r + 1;
+        }
+      }
+      fast[tbz_brev32(r) >> (32 - TB)] = (u16)entry;
+    }
+  }
+  tbz_sync();
+  // 7. second level, spread over the lanes by canonical slot
+  if (ok && two) {
+    const u32 kfirst = (offp[(TB + 1) >> 1] >> (((TB + 1) & 1) * 16)) & 0xffffu;  // symbols with codes <= TB bits
+    for (u32 k = kfirst + g; k < used; k += G) {
+      u32 L = TB + 1;
+#pragma unroll
+      for (u32 q = TB + 2; q < 16; q++) L += k >= ((offp[q >> 1] >> ((q & 1) * 16)) & 0xffffu) ? 1u : 0u;
+      const u32 cd = (k - dlt[L]) & 0xffffu;
+      const u32 e1 = fast[tbz_brev32(cd >> (L - TB)) >> (32 - TB)];
+      if (e1 == 0) continue;
+      const u32 b = (e1 >> 4) & 7, po = e1 >> 7, xl = L - TB;
+      const u32 j0 = tbz_brev32(cd & ((1u << xl) - 1)) >> (32 - xl);
+      const u32 sym = sorted[k];
+      const u32 entry = LIT ? kg_lit_entry(sym, L) : (L | (sym << 4));
+      for (u32 j = j0; j < (1u << b); j += 1u << xl) fast[(1u << TB) + po + j] = (u16)entry;
+    }
+  }
+  return n ? err : 0;
 }
 
 #define KG_CHECK(p0)                 \
@@ -1001,51 +1151,69 @@ TBZ_DEV u32 canon_decode_g(u32 pk, const Canon& cn, const u16* dlt, const u8* sy
     }                                \
   } while (0)
 
-TBZ_DEV i32 kg_build_fixed(GangTables& gt, u8* sc) {
-  u8* lens = sc + K1_SC_LENS;
-  for (u32 i = 0; i < 320; i++) lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5;
-  i32 e = build_canon_g(lens, 288, gt.tmp, gt.ldlt, gt.lsym8, gt.lbit8, 9, gt.llim);
-  if (e) return e;
-  return build_canon_g(lens + 288, 32, gt.tmp, gt.ddlt, gt.dsym8, nullptr, 0, gt.dlim);
-}
-
-// leader: :dynamic-huffman-block … :dht-len-table-data (deflate.lisp:577-669)
-TBZ_DEV i32 kg_dynamic_header(GangTables& gt, K1State& st, u8* sc) {
+// leader: :dynamic-huffman-block … :dht-len-table-data (deflate.lisp:577-669): leaves the code lengths
+// in kg_lens(gt) and the alphabet sizes in gs.hlit / gs.hdist
+TBZ_DEV i32 kg_dynamic_header(GangTables& gt, GangState& gs, K1State& st) {
   const u64 p0 = st.br.pos;
   u32 pk = br_peek(st.br);
-  u32 hlit = (pk & 31) + 257, hdist = ((pk >> 5) & 31) + 1, hclen = ((pk >> 10) & 15) + 4;
+  const u32 hlit = (pk & 31) + 257, hdist = ((pk >> 5) & 31) + 1, hclen = ((pk >> 10) & 15) + 4;
   br_skip(st.br, 14);
   KG_CHECK(p0);
-  u8* lens = sc + K1_SC_LENS;
+  u8* lens = kg_lens(gt);
   for (u32 i = 0; i < 19; i++) lens[i] = 0;
   for (u32 i = 0; i < hclen; i++) {
-    u32 v = br_peek(st.br) & 7;
+    const u32 v = br_peek(st.br) & 7;
     br_skip(st.br, 3);
     lens[c_cl_order[i]] = (u8)v;
   }
   KG_CHECK(p0);
-  // the code-length code borrows the distance alphabet's slots (the distance code is built last)
-  i32 e = build_canon_g(lens, 19, gt.tmp, gt.ddlt, gt.dsym8, nullptr, 0, gt.dlim);
-  if (e) return e;
-  Canon ccl;
-  for (int k = 0; k < 15; k++) ccl.lim[k] = gt.dlim[k];
-  ccl.min_len = gt.dlim[15];
+  // the code-length code: canonical codes of <= 7 bits -> 128-entry table (len | sym << 3; 0 = unassigned)
+  u8* cl = (u8*)gt.dfast;
+  u16* cnt = gt.lfast;        // scratch: the lit/len table is filled after the header
+  u16* nextc = gt.lfast + 8;
+  for (int L = 0; L < 8; L++) cnt[L] = 0;
+  for (u32 i = 0; i < 19; i++) cnt[lens[i]] += 1;
+  u32 used = 0, code = 0, prev = 0, cl_min = 0;
+  i32 left = 1, err = 0;
+  for (int L = 1; L < 8; L++) {
+    const u32 c = cnt[L];
+    left <<= 1;
+    if ((i32)c > left && !err) err = E_OVERSUB;
+    left -= (i32)c;
+    used += c;
+    if (c && !cl_min) cl_min = L;
+    code = (code + prev) << 1;
+    prev = c;
+    nextc[L] = (u16)code;
+  }
+  if (!err && left > 0 && used > 1) err = E_INCOMPLETE;
+  if (err) return err;
+  for (u32 j = 0; j < 128; j += 4) *(u32*)(cl + j) = 0;
+  for (u32 i = 0; i < 19; i++) {
+    const u32 l = lens[i];
+    if (!l) continue;
+    const u32 cd = nextc[l];
+    nextc[l] = (u16)(cd + 1);
+    const u32 rev = tbz_brev32(cd) >> (32 - l);
+    for (u32 j = rev; j < 128; j += 1u << l) cl[j] = (u8)(l | (i << 3));
+  }
   const u32 n = hlit + hdist;
   u32 i = 0, last = 0xff;
   while (i < n) {
+    br_ensure(st.br);
     const u64 ps = st.br.pos;
     pk = br_peek(st.br);
-    u32 sym;
-    u32 L = canon_decode_g(pk, ccl, gt.ddlt, gt.dsym8, nullptr, 32, sym);
-    if (L > 15) {
-      if (st.br.pos + ccl.min_len > st.end_bit) {
+    const u32 e = cl[pk & 127];
+    const u32 L = e & 7, sym = e >> 3;
+    if (L == 0) {  // unassigned pattern: error unless the input ends inside the root index
+      if (st.br.pos + cl_min > st.end_bit) {
         st.fail_pos = ps;
         return SEG_UNDERRUN;
       }
       return E_INVALID_CODE;
     }
-    u32 xb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
-    u32 x = tbz_bfe(pk, L, xb);
+    const u32 xb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
+    const u32 x = tbz_bfe(pk, L, xb);
     br_skip(st.br, L + xb);
     KG_CHECK(ps);
     if (sym < 16) {
@@ -1067,9 +1235,9 @@ TBZ_DEV i32 kg_dynamic_header(GangTables& gt, K1State& st, u8* sc) {
       i += rep;
     }
   }
-  e = build_canon_g(lens, hlit, gt.tmp, gt.ldlt, gt.lsym8, gt.lbit8, 9, gt.llim);
-  if (e) return e;
-  return build_canon_g(lens + hlit, hdist, gt.tmp, gt.ddlt, gt.dsym8, nullptr, 0, gt.dlim);
+  gs.hlit = hlit;
+  gs.hdist = hdist;
+  return 0;
 }
 #undef KG_CHECK
 
@@ -1085,122 +1253,225 @@ struct RoundOut {
   i32 mdef;  // max over recorded matches of (distance - octets this lane produced before the match)
   u32 flag;
 };
+struct __attribute__((packed, aligned(2))) U32at2 {  // two token words stored at once
+  u32 v;
+};
 
-// One lane's share of a round: decode from `start`, record tokens whose start is >= rec_from, stop at
-// the first token start >= stop (or end-of-block / failure).  Same token loop as k1_decode_block.
-TBZ_DEV void kg_lane_round(const GangTables& gt, BitReader& B, const Canon& ll, const Canon& ld, u64 start,
-                           u64 rec_from, u64 stop, u64 lim64, u16* stage, RoundOut& ro) {
+// The hot loop.  Decodes tokens from the reader's position until a token starts at or after `target`
+// (returns 0), or the next token is anything but a plain literal / valid match inside the limit
+// (returns 1 with the reader AT that token; kg_exact_step sorts it out).  Same phase structure as
+// k1_decode_block (window reload, then at most K1_PHASE tokens out of LDS with 32-bit state), but the
+// iteration is straight-line code: both table lookups, the window advance and one 32-bit token store
+// are unconditional, only second-level lookups (long codes) branch.
+template <bool REC>
+TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, u16* stage, u32 cap, u32& n_, u32& out_,
+                    i32& mdef_) {
   const u32 lane = tbz_lane();
-  enum { RUN = 0, AT_STOP, DONE_EOB, FAIL_LIMIT, FAIL_CODE_LIT, FAIL_CODE_DIST, FAIL_SYM };
-  B.bw = 1ull << 62;
-  br_seek(B, start);
-  bool rec = false;
-  u64 c = ~0ull;
-  u32 n = 0, out = 0;
-  i32 mdef = -(1 << 30);
+  u32 n = n_, out = out_;
+  i32 mdef = mdef_;
+  u32 ret;
   for (;;) {
     br_refill(B);
     u32 lo = B.lo, hi = B.hi, nx = B.nx, o = B.o;
     u32 k = 3;
     i32 rem = lim64 <= B.pos ? 0 : ((lim64 - B.pos) > 0x7fffff00ull ? 0x7fffff00 : (i32)(lim64 - B.pos));
-    const i32 rem_start = rem;
-    i32 rem_tok = rem;
-    const u32 rec_rel = rec_from <= B.pos ? 0u : ((rec_from - B.pos) > 0x7fffff00ull ? 0x7fffff00u : (u32)(rec_from - B.pos));
-    const u32 stop_rel = stop <= B.pos ? 0u : ((stop - B.pos) > 0x7fffff00ull ? 0x7fffff00u : (u32)(stop - B.pos));
-    u32 why = RUN;
-#define KG_SKIP(nb)                  \
-  do {                               \
-    o += (nb);                       \
-    rem -= (i32)(nb);                \
-    const u32 nw_ = B.buf[k][lane];  \
-    const bool ge_ = o >= 32;        \
-    o = ge_ ? o - 32 : o;            \
-    lo = ge_ ? hi : lo;              \
-    hi = ge_ ? nx : hi;              \
-    nx = ge_ ? nw_ : nx;             \
-    k += ge_ ? 1u : 0u;              \
-  } while (0)
-    for (u32 it = 0; it < K1_PHASE && k < K1_INBUF - 3; it++) {
-      rem_tok = rem;
-      const u32 rel = (u32)(rem_start - rem);
-      if (rel >= stop_rel) { why = AT_STOP; break; }
-      if (!rec && rel >= rec_rel) {
-        rec = true;
-        c = B.pos + rel;
-      }
-      u32 pk = tbz_alignbit(hi, lo, o);
-      u32 sym;
-      u32 L = canon_decode_g(pk, ll, gt.ldlt, gt.lsym8, gt.lbit8, 288, sym);
-      if (L > 15) { why = FAIL_CODE_LIT; break; }
-      if (sym < 256) {
-        KG_SKIP(L);
-        if (rem < 0) { why = FAIL_LIMIT; break; }
-        if (rec) {
-          stage[n] = (u16)sym;
-          n += 1;
-          out += 1;
-        }
-      } else if (sym == 256) {
-        KG_SKIP(L);
-        if (rem < 0) { why = FAIL_LIMIT; break; }
-        why = DONE_EOB;
+    u32 tgt = target <= B.pos ? 0u : ((target - B.pos) > 0x7fffff00ull ? 0x7fffff00u : (u32)(target - B.pos));
+    if (REC && n + 2 * K1_PHASE > cap) tgt = 0;  // staging region nearly full: end the lane's run here
+    u32 rel = 0, it = 0;
+    bool bad = false;
+    const u32* wp = &B.buf[3][lane];  // next window word (64 words = one slot apart)
+    // NOTE: conditions are combined with & and | on purpose — && / || / ?: on side-effect-free terms
+    // become exec-mask branches here, and every branch costs the whole wave scalar work
+    bool go = (K1_INBUF >= 5) & (rel < tgt);
+    while (go) {
+      const u32 x1 = wp[0], x2 = wp[64];
+      const u32 pk = tbz_alignbit(hi, lo, o);
+      u32 e = gt.lfast[pk & ((1u << KG_TBL) - 1)];
+      if (((e & 15) == 0) & (e != 0)) e = gt.lfast[(1u << KG_TBL) + (e >> 7) + tbz_bfe(pk, KG_TBL, (e >> 4) & 7)];
+      const u32 L = e & 15;
+      const bool isM = e >= 0x8000u;
+      const u32 X = (e >> 12) & (isM ? 7u : 0u);
+      const u32 lenx = ((e >> 4) & 0xffu) + tbz_bfe(pk, L, X);  // literal octet, or match length - 3
+      const u32 n1 = L + X, o2 = o + n1;
+      const u32 pa = tbz_alignbit(hi, lo, o2 & 31), pb = tbz_alignbit(nx, hi, o2 & 31);
+      const u32 pd = o2 < 32 ? pa : pb;
+      u32 ed = gt.dfast[pd & ((1u << KG_TBD) - 1)];
+      if (isM & ((ed & 15) == 0) & (ed != 0)) ed = gt.dfast[(1u << KG_TBD) + (ed >> 7) + tbz_bfe(pd, KG_TBD, (ed >> 4) & 7)];
+      const u32 DL = ed & 15, ds = (ed >> 4) & 31;
+      const u32 de = ds >> 1;                       // RFC 1951 distance base / extra bits, as dist_base_extra
+      const u32 DX = ds < 4 ? 0u : de - 1;
+      const u32 dbase = ds < 4 ? ds + 1 : 1 + ((2 + (ds & 1)) << ((de - 1) & 15));
+      const u32 dist = dbase + tbz_bfe(pd, DL, DX);
+      const u32 nbits = isM ? n1 + DL + DX : L;
+      const bool okm = (DL != 0) & (ds < 30), okl = e < 0x1000u;
+      const i32 rem2 = rem - (i32)nbits;
+      const bool good = (L != 0) & (isM ? okm : okl) & (rem2 >= 0);
+      if (!good) {
+        bad = true;
         break;
-      } else {
-        if (sym > 285) {
-          KG_SKIP(L);
-          why = rem < 0 ? FAIL_LIMIT : FAIL_SYM;
-          break;
-        }
-        u32 base, X;
-        len_base_extra(sym - 257, base, X);
-        u32 len = base + tbz_bfe(pk, L, X);
-        KG_SKIP(L + X);
-        u32 pd = tbz_alignbit(hi, lo, o);
-        u32 ds;
-        u32 DL = canon_decode_g(pd, ld, gt.ddlt, gt.dsym8, nullptr, 32, ds);
-        if (DL > 15) { why = FAIL_CODE_DIST; break; }
-        if (ds > 29) {
-          KG_SKIP(DL);
-          why = rem < 0 ? FAIL_LIMIT : FAIL_SYM;
-          break;
-        }
-        u32 dbase, DX;
-        dist_base_extra(ds, dbase, DX);
-        u32 dist = dbase + tbz_bfe(pd, DL, DX);
-        KG_SKIP(DL + DX);
-        if (rem < 0) { why = FAIL_LIMIT; break; }
-        if (rec) {
-          i32 d = (i32)dist - (i32)out;
-          mdef = d > mdef ? d : mdef;
-          stage[n] = (u16)(TOK_MATCH | (len - 3));
-          stage[n + 1] = (u16)(dist - 1);
-          n += 2;
-          out += len;
-        }
       }
+      rem = rem2;
+      rel += nbits;
+      o += nbits;  // < 96: the window advances by up to two words
+      const u32 adv = o >> 5;
+      o &= 31;
+      const u32 nlo = adv == 0 ? lo : adv == 1 ? hi : nx;
+      const u32 nhi = adv == 0 ? hi : adv == 1 ? nx : x1;
+      const u32 nnx = adv == 0 ? nx : adv == 1 ? x1 : x2;
+      lo = nlo;
+      hi = nhi;
+      nx = nnx;
+      k += adv;
+      wp += adv * 64;
+      if (REC) {
+        // literal: 0x00bb (the high half is overwritten by the next token); match: head | payload << 16
+#if KG_EXP != 4
+        ((U32at2*)(stage + n))->v = isM ? (TOK_MATCH | lenx | ((dist - 1) << 16)) : lenx;
+#endif
+        const i32 d = (i32)dist - (i32)out;
+        mdef = isM & (d > mdef) ? d : mdef;
+        n += isM ? 2u : 1u;
+        out += isM ? lenx + 3 : 1u;
+      }
+      it++;
+      go = (it < K1_PHASE) & (k + 2 <= K1_INBUF) & (rel < tgt);
     }
-#undef KG_SKIP
-    u32 used = (u32)(rem_start - rem);
-    u32 tok_bits = (u32)(rem_tok - rem);
-    B.pos += used;
+    B.pos += rel;
     B.wi += k - 3;
     B.lo = lo;
     B.hi = hi;
     B.nx = nx;
     B.o = o;
-    if (why == RUN) continue;
+    if (bad) { ret = 1; break; }
+    if (rel >= tgt) { ret = 0; break; }
+  }
+  n_ = n;
+  out_ = out;
+  mdef_ = mdef;
+  return ret;
+}
+
+// full compare-count decode out of the gang's canonical lists (cold path)
+TBZ_DEV u32 kg_canon_lds(u32 pk, const u32* lim, const u16* dlt, u32 cap, u32& slot) {
+  const u32 r16 = tbz_brev32(pk) >> 16;
+  u32 L = 1;
+  for (int k = 0; k < 15; k++) L += r16 >= lim[k] ? 1u : 0u;
+  u32 sl = ((r16 >> (16 - (L & 15))) + dlt[L & 15]) & 0xffffu;
+  slot = sl < cap ? sl : 0;
+  return L;
+}
+
+// The exact step: decode ONE token at the reader's position the long way (no lookup tables), with the
+// reference's failure rules.  Returns 0 if it was a literal or match inside the limit (consumed, and
+// recorded when `rec`); otherwise fills ro.flag / ro.e / ro.aux and returns 1.
+TBZ_DEV u32 kg_exact_step(const GangTables& gt, BitReader& B, u64 lim64, bool rec, u16* stage, u32& n, u32& out, i32& mdef,
+                          RoundOut& ro) {
+  const u64 p0 = B.pos;
+  br_seek_fill(B, p0);
+  const u32 pk = br_peek(B);
+  u32 slot;
+  const u32 L = kg_canon_lds(pk, gt.llim, gt.ldlt, 288, slot);
+  ro.e = p0;
+  if (L > 15) {
+    ro.flag = RF_CODE_LIT;
+    ro.aux = p0;
+    return 1;
+  }
+  const u32 sym = gt.lsym[slot];
+  if (sym <= 256 || sym > 285) {
+    br_skip(B, L);
     ro.aux = B.pos;
-    ro.e = B.pos - tok_bits;
-    ro.flag = why == AT_STOP ? RF_STOP : why == DONE_EOB ? RF_EOB : why == FAIL_LIMIT ? RF_LIMIT
-              : why == FAIL_CODE_LIT ? RF_CODE_LIT : why == FAIL_CODE_DIST ? RF_CODE_DIST : RF_SYM;
-    if (why == DONE_EOB) ro.e = B.pos;
-    break;
+    if (B.pos > lim64) {
+      ro.flag = RF_LIMIT;
+      return 1;
+    }
+    if (sym == 256) {
+      ro.flag = RF_EOB;
+      ro.e = B.pos;
+      return 1;
+    }
+    if (sym > 285) {  // 286/287 are coded but may not be used (huffman-tree.lisp:176-177)
+      ro.flag = RF_SYM;
+      return 1;
+    }
+    if (rec) {
+      stage[n] = (u16)sym;
+      n += 1;
+      out += 1;
+    }
+    return 0;
   }
-  if (!rec) {  // ended (end-of-block / failure) during the run-up: nothing of this lane can be valid
-    c = ~0ull;
+  u32 base, X;
+  len_base_extra(sym - 257, base, X);
+  const u32 len = base + tbz_bfe(pk, L, X);
+  br_skip(B, L + X);
+  const u32 pd = br_peek(B);
+  const u32 DL = kg_canon_lds(pd, gt.dlim, gt.ddlt, 32, slot);
+  ro.aux = B.pos;
+  if (DL > 15) {
+    ro.flag = RF_CODE_DIST;
+    return 1;
+  }
+  const u32 ds = gt.dsym[slot];
+  if (ds > 29) {  // 30/31 (huffman-tree.lisp:172-175)
+    br_skip(B, DL);
+    ro.aux = B.pos;
+    ro.flag = B.pos > lim64 ? RF_LIMIT : RF_SYM;
+    return 1;
+  }
+  u32 dbase, DX;
+  dist_base_extra(ds, dbase, DX);
+  const u32 dist = dbase + tbz_bfe(pd, DL, DX);
+  br_skip(B, DL + DX);
+  ro.aux = B.pos;
+  if (B.pos > lim64) {
+    ro.flag = RF_LIMIT;
+    return 1;
+  }
+  if (rec) {
+    const i32 d = (i32)dist - (i32)out;
+    mdef = d > mdef ? d : mdef;
+    stage[n] = (u16)(TOK_MATCH | (len - 3));
+    stage[n + 1] = (u16)(dist - 1);
+    n += 2;
+    out += len;
+  }
+  return 0;
+}
+
+// One lane's share of a round: decode from `start`; tokens that start before rec_from are the run-up
+// (not recorded), the ones from there to the first token start >= stop are staged.
+TBZ_DEV void kg_lane_round(const GangTables& gt, BitReader& B, u64 start, u64 rec_from, u64 stop, u64 lim64,
+                           u16* stage, u32 cap, RoundOut& ro) {
+  u32 n = 0, out = 0;
+  i32 mdef = -(1 << 30);
+  br_seek_fill(B, start);
+  bool junk = false;
+  while (B.pos < rec_from) {  // run-up
+    if (kg_span<false>(gt, B, rec_from, lim64, stage, cap, n, out, mdef) == 0) break;
+    if (kg_exact_step(gt, B, lim64, false, stage, n, out, mdef, ro)) {
+      junk = true;  // ended (end-of-block / failure) during the run-up: nothing of this lane can be valid
+      break;
+    }
+  }
+  ro.c = ~0ull;
+  ro.n = 0;
+  ro.out = 0;
+  ro.mdef = mdef;
+  if (junk) {
     ro.flag = RF_JUNK;
+    return;
   }
-  ro.c = c;
+  ro.c = B.pos;
+  for (;;) {
+    if (kg_span<true>(gt, B, stop, lim64, stage, cap, n, out, mdef) == 0) {
+      ro.flag = RF_STOP;
+      ro.e = B.pos;
+      ro.aux = B.pos;
+      break;
+    }
+    if (kg_exact_step(gt, B, lim64, true, stage, n, out, mdef, ro)) break;
+  }
   ro.n = n;
   ro.out = out;
   ro.mdef = mdef;
@@ -1208,10 +1479,9 @@ TBZ_DEV void kg_lane_round(const GangTables& gt, BitReader& B, const Canon& ll, 
 
 // leader: what follows a block (deflate.lisp:719-722 + the container trailers + landing rules)
 TBZ_DEV void kg_block_end(GangState& gs, K1State& st, const Item& it, const K1gParams& P, u32 fmt, bool fixup) {
-  st.br.bw = 1ull << 62;
-  br_seek(st.br, gs.P);
   if (gs.bfinal) {
     gs.status = SEG_FINAL;
+    br_seek_fill(st.br, gs.P);
     br_skip(st.br, (u32)((0 - st.br.pos) & 7));
     if (fmt == 1) {
       if (st.br.pos + 32 <= st.end_bit) {
@@ -1261,11 +1531,11 @@ TBZ_DEV void kg_block_end(GangState& gs, K1State& st, const Item& it, const K1gP
   gs.mode = GM_HEADER;
 }
 
-// leader: block header at gs.P (deflate.lisp:518-573); stored blocks are handled completely here
+// leader: block header at gs.P (deflate.lisp:518-573); stored blocks are handled completely here,
+// Huffman blocks leave the gang in GM_BUILD (or GM_BLOCK when the fixed code is already loaded)
 TBZ_DEV void kg_leader_header(GangTables& gt, GangState& gs, K1State& st, const Item& it, const K1gParams& P,
-                              u16* tok0, u8* sc, u32 fmt, bool fixup) {
-  st.br.bw = 1ull << 62;
-  br_seek(st.br, gs.P);
+                              u16* tok0, u32 fmt, bool fixup) {
+  br_seek_fill(st.br, gs.P);
   gs.blk_pos = gs.P;
   gs.blk_prod = gs.produced;
   gs.blk_tok = gs.T;
@@ -1302,22 +1572,30 @@ TBZ_DEV void kg_leader_header(GangTables& gt, GangState& gs, K1State& st, const 
     return;
   }
   if (btype == 3) { gs.status = E_BTYPE; gs.mode = GM_DONE; return; }
-  i32 e = 0;
   if (btype == 1) {
-    if (gs.tables != 1) e = kg_build_fixed(gt, sc);
-    gs.tables = 1;
-  } else {
-    e = kg_dynamic_header(gt, st, sc);
-    gs.tables = 2;
+    gs.P = st.br.pos;
+    if (gs.tables == 1) {
+      gs.mode = GM_BLOCK;
+    } else {
+      gs.tables = 1;
+      gs.fixed = 1;
+      gs.hlit = 288;
+      gs.hdist = 32;
+      gs.mode = GM_BUILD;
+    }
+    return;
   }
+  const i32 e = kg_dynamic_header(gt, gs, st);
+  gs.tables = 2;
   if (e) {
     gs.status = e;
     gs.fail_pos = st.fail_pos;
     gs.mode = GM_DONE;
     return;
   }
+  gs.fixed = 0;
   gs.P = st.br.pos;
-  gs.mode = GM_BLOCK;
+  gs.mode = GM_BUILD;
 }
 
 template <int G>
@@ -1334,9 +1612,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
   if (have) it = P.items[idx];
   const u32 fmt = (it.flags >> ITEM_FMT_SHIFT) & 3;
   const bool fixup = (it.flags & ITEM_FIXUP) != 0;
-  u8* sc = P.scratch + (u64)(have ? idx : 0) * K1_SCRATCH;
   u16* tok0 = P.tok + it.start_bit;
-  u16* stage = P.stage + ((u64)tbz_block() * 64 + lane) * KG_STAGE;
   K1State st;
   br_init(st.br, P.in_base, it.end_byte, S.inbuf);
   st.end_bit = it.end_byte * 8;
@@ -1363,9 +1639,10 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     gs.tables = 0;
     gs.land = 0xFFFFFFFFu;
     gs.tr0 = gs.tr1 = gs.tr_have = 0;
+    gs.hlit = gs.hdist = gs.fixed = 0;
     gs.rounds = gs.valid_lanes = 0;
     if (have && (it.flags & ITEM_HEAD)) {
-      br_seek(st.br, it.start_bit);
+      br_seek_fill(st.br, it.start_bit);
       i32 e = k1_container_header(st, fmt);
       if (e) {
         gs.status = e;
@@ -1379,9 +1656,37 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
   for (;;) {
     tbz_sync();
     if (tbz_ballot(gs.mode != GM_DONE) == 0) break;
-    // ---- H: leaders whose gang is between blocks parse the next header / build the next code
-    if (leader && gs.mode == GM_HEADER) kg_leader_header(gt, gs, st, it, P, tok0, sc, fmt, fixup);
+    // ---- H: leaders whose gang is between blocks parse the next header
+    if (leader && gs.mode == GM_HEADER) kg_leader_header(gt, gs, st, it, P, tok0, fmt, fixup);
+#if KG_EXP == 3
+    if (leader) { gs.mode = GM_DONE; if (gs.status == 0) gs.status = E_BTYPE; }
+#endif
     tbz_sync();
+    // ---- B: gangs with a new code build it together (wave-uniform branch: collectives inside)
+    const bool building = gs.mode == GM_BUILD;
+    if (tbz_ballot(building) != 0) {
+      const u32 nl = building ? gs.hlit : 0, nd = building ? gs.hdist : 0;
+      if (building && gs.fixed)  // fixed code lengths: huffman-tree.lisp:89-97
+        for (u32 i = g; i < 320; i += G) kg_lens(gt)[i] = (u8)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5);
+      tbz_sync();
+      const i32 e1 = kg_build<G, KG_TBL, KG_LPOOL, true, u16>(kg_lens(gt), nl, gt.lsym, gt.llim, gt.ldlt, gt.lfast, g, base);
+      const i32 e2 = kg_build<G, KG_TBD, KG_DPOOL, false, u8>(kg_lens(gt) + nl, nd, gt.dsym, gt.dlim, gt.ddlt, gt.dfast, g, base);
+      tbz_sync();
+      if (leader && building) {
+        const i32 e = e1 ? e1 : e2;
+        if (e) {
+          gs.status = e;
+          gs.mode = GM_DONE;
+        } else {
+          gs.mode = GM_BLOCK;
+        }
+      }
+      tbz_sync();
+    }
+#if KG_EXP == 2
+    if (leader) { gs.mode = GM_DONE; if (gs.status == 0) gs.status = E_BTYPE; }
+    tbz_sync();
+#endif
     // ---- R: one round for the gangs that are inside a Huffman block
     const bool inblk = gs.mode == GM_BLOCK;
     const u64 Pb = gs.P;
@@ -1393,18 +1698,18 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     ro.out = 0;
     ro.mdef = -(1 << 30);
     ro.flag = RF_JUNK;
+    u16* stage = P.stage;
     if (inblk) {
-      Canon ll, ld;
-#pragma unroll
-      for (int k = 0; k < 15; k++) {
-        ll.lim[k] = gt.llim[k];
-        ld.lim[k] = gt.dlim[k];
-      }
-      ll.min_len = gt.llim[15];
-      ld.min_len = gt.dlim[15];
-      const u64 s_g = Pb + (u64)g * KG_SUB;
-      const u64 start = (g == 0 || s_g < Pb + KG_OVL) ? Pb : s_g - KG_OVL;
-      kg_lane_round(gt, st.br, ll, ld, start, g == 0 ? Pb : s_g, s_g + KG_SUB, lim64, stage, ro);
+      // sub-range per lane: what is left of the item split evenly (the next marker is where it should end)
+      const u64 remb = lim64 > Pb ? lim64 - Pb : 0;
+      const u64 per = (remb + G - 1) / G;
+      u32 sub = per >= KG_SUB_MAX ? KG_SUB_MAX : (u32)per;
+      sub = (sub + 63) & ~63u;
+      sub = sub < KG_SUB_MIN ? KG_SUB_MIN : sub;
+      const u64 s_g = Pb + (u64)g * sub;
+      const u64 start = g == 0 ? Pb : s_g - KG_OVL;
+      stage = P.stage + (s_g & ~7ull);  // private region [s_g, s_g + sub), 16-octet aligned for the commit copy
+      kg_lane_round(gt, st.br, start, s_g, s_g + sub, lim64, stage, sub - 8, ro);
     }
     // ---- chain validation: lane g counts iff it began recording exactly where lane g-1 stopped
     const u32 pe_lo = tbz_wave_shr1((u32)ro.e), pe_hi = tbz_wave_shr1((u32)(ro.e >> 32));
@@ -1424,12 +1729,16 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     const u32 tot_n = tbz_shfl(in_n, (int)(base + G - 1)) - base_n;
     const u32 tot_o = tbz_shfl(in_o, (int)(base + G - 1)) - base_o;
     // ---- commit: compact the valid runs into the item's contiguous token stream
+#if KG_EXP == 1
+    if (false) {
+#else
     if (valid) {
+#endif
       // 16-octet chunks, four loads in flight before their stores (an element-wise loop would be one
       // memory round trip per token: the compiler must assume dst may alias stage)
       u16* dst16 = tok0 + gs.T + D;
       U16x8* dst = (U16x8*)dst16;
-      const uint4* src = (const uint4*)stage;  // the lane's staging area is 16-octet aligned
+      const uint4* src = (const uint4*)stage;
       const u32 nfull = ro.n >> 3;
       for (u32 c0 = 0; c0 < nfull; c0 += 4) {
         uint4 v0 = src[c0], v1, v2, v3;
@@ -1521,7 +1830,6 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     TBZ_SHARED KgLds<G> S;                                  \
     k1g_body<G>(P, S);                                      \
   }
-TBZ_K1G_KERNEL(4)
 TBZ_K1G_KERNEL(8)
 TBZ_K1G_KERNEL(16)
 TBZ_K1G_KERNEL(32)

@@ -336,6 +336,22 @@ def case_checksum_kernels(eng):
             eng.free(d)
 
 
+def case_deep_codes(eng, n_tokens=12000):
+    """hand-built dynamic blocks with 15-bit codes on most tokens (second-level table lookups), and a
+    distance code whose long prefixes need more second-level entries than the engine's pool holds (its
+    long codes take the exact step); whole, truncated inside long codes, and with a short output buffer"""
+    for ov in (False, True):
+        s, p = K.deep_code_stream(n_tokens=n_tokens, seed=11 + ov, dist_overflow=ov)
+        assert zlib.decompressobj(-15).decompress(s) == p
+        w = assert_same(eng, s, "deflate", len(p), what="deep codes ov=%d" % ov)
+        assert w["flag"] == "finished" and w["bytes"] == p
+        assert_same(eng, s, "deflate", len(p) // 3, what="deep codes, short buffer ov=%d" % ov)
+        for cut in (len(s) - 1, len(s) // 2, len(s) // 2 + 1, 300, 115, 114, 113):
+            assert_same(eng, s, "deflate", len(p), end=cut, what="deep codes cut at %d ov=%d" % (cut, ov))
+        z = zlib.compress(p[:50000], 6)  # same octets through zlib's own (shallow) codes, as a container stream
+        assert_same(eng, z, "zlib", 50000, what="deep plain via zlib")
+
+
 ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,
              case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_device_buffers,
-             case_checksum_kernels]
+             case_checksum_kernels, case_deep_codes]

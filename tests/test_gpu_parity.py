@@ -13,7 +13,7 @@ from tools import corpus as K
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["auto", "gang4", "gang16", "lane"])
+@pytest.fixture(scope="module", params=["auto", "gang8", "gang32", "lane"])
 def eng(request):
     """auto picks wide gangs (32/64 lanes per item) for these sizes; the other K1 flavours are forced through TBZ_K1_MODE"""
     T = importlib.import_module("3bz_amd")

@@ -272,6 +272,125 @@ class FixedHuffmanWriter(BitWriter):
         self.sym(256)
 
 
+def canonical_codes(lens):
+    """RFC 1951 §3.2.2 canonical code values for a list of code lengths (0 = unused)"""
+    cnt = [0] * 16
+    for l in lens:
+        cnt[l] += 1
+    cnt[0] = 0
+    nxt, code = [0] * 16, 0
+    for L in range(1, 16):
+        code = (code + cnt[L - 1]) << 1
+        nxt[L] = code
+    out = []
+    for l in lens:
+        out.append(nxt[l] if l else 0)
+        if l:
+            nxt[l] += 1
+    return out
+
+
+class DynamicHuffmanWriter(BitWriter):
+    """emit BTYPE=2 blocks from EXPLICIT code lengths (test streams whose codes a compressor would never
+    choose: 15-bit codes everywhere, distance codes that overflow a decoder's second-level table ...).
+    The code-length code is fixed: symbols 0..12 get 4 bits, 13..18 get 5 bits (complete), no repeat codes."""
+
+    def __init__(self, lit_lens, dist_lens):
+        super().__init__()
+        assert 257 <= len(lit_lens) <= 286 and 1 <= len(dist_lens) <= 30
+        self.lit_lens, self.dist_lens = list(lit_lens), list(dist_lens)
+        self.lit_codes, self.dist_codes = canonical_codes(self.lit_lens), canonical_codes(self.dist_lens)
+        self.cl_lens = [4] * 13 + [5] * 6
+        self.cl_codes = canonical_codes(self.cl_lens)
+
+    def begin_block(self, final=False):
+        self.bits(1 if final else 0, 1)
+        self.bits(2, 2)
+        self.bits(len(self.lit_lens) - 257, 5)
+        self.bits(len(self.dist_lens) - 1, 5)
+        self.bits(19 - 4, 4)
+        for sym in (16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15):
+            self.bits(self.cl_lens[sym], 3)
+        for l in self.lit_lens + self.dist_lens:
+            self.code(self.cl_codes[l], self.cl_lens[l])
+
+    def sym(self, s):
+        assert self.lit_lens[s], s
+        self.code(self.lit_codes[s], self.lit_lens[s])
+
+    def literal(self, b):
+        self.sym(b)
+
+    def match(self, length, dist):
+        li = max(i for i in range(29) if _LEN_BASE[i] <= length) if length < 258 else 28
+        self.sym(257 + li)
+        if _LEN_EXTRA[li]:
+            self.bits(length - _LEN_BASE[li], _LEN_EXTRA[li])
+        di = max(i for i in range(30) if _DIST_BASE[i] <= dist)
+        assert self.dist_lens[di], di
+        self.code(self.dist_codes[di], self.dist_lens[di])
+        if _DIST_EXTRA[di]:
+            self.bits(dist - _DIST_BASE[di], _DIST_EXTRA[di])
+
+    def end_block(self):
+        self.sym(256)
+
+
+def deep_code_stream(n_tokens=40000, seed=7, dist_overflow=False, blocks=3):
+    """Raw deflate stream of dynamic blocks whose codes are as deep as RFC 1951 allows.
+    lit/len: 16 symbols coded with lengths 1,2,...,14,15,15 (literals, end-of-block and five length symbols),
+    used UNIFORMLY, so most tokens carry codes longer than any first-level lookup table.
+    distance: the same shape over 16 symbols, or (dist_overflow) lengths 1..7 plus two 8-bit prefixes that
+    each run down to 15 bits - 256 second-level entries, more than the engine's pool holds.
+    Returns (stream, plain)."""
+    rng = np.random.default_rng([seed, 0xDEE9])
+    lit_syms = [ord(c) for c in "etaoinshrd"] + [256, 257, 260, 266, 275, 285]
+    order = rng.permutation(16)
+    chain = list(range(1, 15)) + [15, 15]
+    lit_lens = [0] * 286
+    for k, i in enumerate(order):
+        lit_lens[lit_syms[i]] = chain[k]
+    if dist_overflow:
+        dl = list(range(1, 8)) + [9, 10, 11, 12, 13, 14, 15, 15] * 2  # 23 symbols, complete
+    else:
+        dl = chain[:]
+    dperm = rng.permutation(len(dl))
+    dist_lens = [0] * len(dl)
+    for k, i in enumerate(dperm):
+        dist_lens[i] = dl[k]
+    w = DynamicHuffmanWriter(lit_lens, dist_lens)
+    out = bytearray()
+    lits = [s for s in lit_syms if s < 256]
+    lens_ = {257: (3, 3), 260: (6, 6), 266: (13, 14), 275: (51, 58), 285: (258, 258)}
+    for b in range(blocks):
+        w.begin_block(final=(b == blocks - 1))
+        for t in range(n_tokens // blocks):
+            s = lit_syms[int(rng.integers(0, 16))]
+            if s == 256:
+                continue
+            if s < 256 or len(out) < 4:
+                if s >= 256:
+                    s = lits[t % len(lits)]
+                w.literal(s)
+                out.append(s)
+                continue
+            lo, hi = lens_[s]
+            length = int(rng.integers(lo, hi + 1))
+            for _ in range(64):  # a distance symbol that is coded and reaches no further than the history
+                di = int(rng.integers(0, len(dist_lens)))
+                if dist_lens[di] and _DIST_BASE[di] <= min(len(out), 32768):
+                    break
+            else:
+                di = next(i for i in range(len(dist_lens)) if dist_lens[i] and _DIST_BASE[i] <= len(out))
+            hi_d = min(_DIST_BASE[di] + (1 << _DIST_EXTRA[di]) - 1, len(out), 32768)
+            dist = int(rng.integers(_DIST_BASE[di], hi_d + 1))
+            w.match(length, dist)
+            _lz_apply(out, length, dist)
+        w.end_block()
+    w.align()
+    return w.getvalue(), bytes(out)
+
+
 def _lz_apply(out, length, dist):
     """reference LZ77 semantics for building the expected plaintext (pure Python, byte-exact)"""
     start = len(out) - dist

@@ -3,7 +3,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import numpy as np, torch
 from tools import corpus as K
 T = importlib.import_module("3bz_amd")
-U = 256 << 20
+U = int(os.environ.get("EXP_MIB", "256")) << 20
 s, p, a = K.zlib_flush_stream(U, workers=16, want_plain=False)
 d_in = torch.from_numpy(np.frombuffer(s, dtype=np.uint8).copy()).cuda()
 d_out = torch.empty(U + 64, dtype=torch.uint8, device="cuda")

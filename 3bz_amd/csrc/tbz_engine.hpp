@@ -531,7 +531,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     for (size_t gi = 0; gi < h_groups.size(); gi++) {
       uint64_t tot = 0;
       for (uint32_t k = 0; k < h_groups[gi].seg_count; k++) tot += h_segs[h_groups[gi].seg_first + k].out_bytes;
-      if (tot + 16 <= K2_SMALL_MAX) {
+      if (tot + K2_SLACK <= K2_SMALL_MAX) {
         order_small.push_back((uint32_t)gi);
         max_small = std::max(max_small, tot);
       } else {
@@ -545,7 +545,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
                 (const u32*)ctx->d_order.p, (const u8*)d_in, (u8*)d_out, 0, 0};
     if (!order_small.empty()) {
       k2.n_groups = (u32)order_small.size();
-      k2.win_bytes = (u32)((max_small + 16 + 255) & ~255ull);
+      k2.win_bytes = (u32)((max_small + K2_SLACK + 255) & ~255ull);
       TBZ_LAUNCH_DYN(tbz_k2_lz77_small, order_small.size(), k2.win_bytes + 2 * K2_TOKBUF, ctx->stream, k2);
     }
     if (!order_big.empty()) {

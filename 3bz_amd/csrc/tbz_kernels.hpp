@@ -1068,7 +1068,9 @@ TBZ_DEV i32 kg_build(const u8* lens, u32 n, SymT* sorted, u32* lim, u16* dlt, u1
   const u32 r0 = g * R;
   u32 need = 0;
   if (ok) {
+#pragma nounroll
     for (u32 j = g; j < POOL; j += G) fast[(1u << TB) + j] = 0;
+#pragma nounroll
     for (u32 t = 0; t < R; t++) {
       const u32 r16 = (r0 + t) << SH;
       if (r16 < limr[TB - 1]) continue;
@@ -1091,6 +1093,7 @@ TBZ_DEV i32 kg_build(const u8* lens, u32 n, SymT* sorted, u32* lim, u16* dlt, u1
   // 6. first level: symbols are monotone in the prefix, so one compare-count decode serves a run of entries
   if (ok) {
     u32 r = r0, end_r = r, entry = 0, poff = pin - need;
+#pragma nounroll
     for (u32 t = 0; t < R; t++, r++) {
       if (r >= end_r) {
         const u32 r16 = r << SH;
@@ -1667,6 +1670,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     if (tbz_ballot(building) != 0) {
       const u32 nl = building ? gs.hlit : 0, nd = building ? gs.hdist : 0;
       if (building && gs.fixed)  // fixed code lengths: huffman-tree.lisp:89-97
+#pragma nounroll
         for (u32 i = g; i < 320; i += G) kg_lens(gt)[i] = (u8)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5);
       tbz_sync();
       const i32 e1 = kg_build<G, KG_TBL, KG_LPOOL, true, u16>(kg_lens(gt), nl, gt.lsym, gt.llim, gt.ldlt, gt.lfast, g, base);
@@ -1825,8 +1829,8 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
   }
 }
 
-#define TBZ_K1G_KERNEL(G)                                   \
-  TBZ_KERNEL void tbz_k1g##G##_huff_decode(K1gParams P) {   \
+#define TBZ_K1G_KERNEL(G)                                          \
+  TBZ_KERNEL_OCC(3) void tbz_k1g##G##_huff_decode(K1gParams P) {   \
     TBZ_SHARED KgLds<G> S;                                  \
     k1g_body<G>(P, S);                                      \
   }
@@ -1851,9 +1855,21 @@ TBZ_K1G_KERNEL(64)
 constexpr u32 K2_WIN = 36864;   // 32 KiB history + one batch span + slack; multiple of 16
 constexpr u32 K2_SPAN = 3072;   // max octets one batch may produce (cut otherwise)
 constexpr u32 K2_FLUSH = 8192;  // flush the ring to HBM every this many octets
-constexpr u32 K2_SHORT = 8;     // matches up to this length are copied by their own lane
-constexpr u32 K2_TOKBUF = 1024; // token words staged in LDS per load (one memory round trip per ~16 batches)
-constexpr u32 K2_SMALL_MAX = 32768;  // groups producing at most this much (incl. 16 octets slack) take the linear path
+constexpr u32 K2_SHORT = 16;    // matches up to this length are copied by their own lane
+constexpr u32 K2_TCH = 512;     // token words per staged chunk: one 16-octet load per lane
+constexpr u32 K2_TOKBUF = 2 * K2_TCH;  // LDS token ring: the chunk in use + the next one (prefetched a chunk ahead)
+constexpr u32 K2_SLACK = 48;    // window octets past a group's output: alignment (16) + room for 16-octet reads
+constexpr u32 K2_SMALL_MAX = 32768;  // groups producing at most this much (incl. K2_SLACK) take the linear path
+
+// LDS accepts any octet address for 2/4/8-octet accesses on gfx950
+struct __attribute__((packed, aligned(1))) K2U64 { u64 v; };
+struct __attribute__((packed, aligned(1))) K2U32 { u32 v; };
+struct __attribute__((packed, aligned(1))) K2U16 { u16 v; };
+TBZ_DEV u64 k2_ld64(const u8* p) { return ((const K2U64*)p)->v; }
+TBZ_DEV u32 k2_ld32(const u8* p) { return ((const K2U32*)p)->v; }
+TBZ_DEV void k2_st64(u8* p, u64 v) { ((K2U64*)p)->v = v; }
+TBZ_DEV void k2_st32(u8* p, u32 v) { ((K2U32*)p)->v = v; }
+TBZ_DEV void k2_st16(u8* p, u32 v) { ((K2U16*)p)->v = (u16)v; }
 
 struct K2Params {
   const u16* tok;
@@ -1903,7 +1919,13 @@ template <bool LINEAR>
 TBZ_DEV void k2_copy_coop(u8* win, u32 rd, u32 dd, u32 l) {
   const u32 lane = tbz_lane();
   u32 rs = LINEAR ? (rd >= dd ? rd - dd : 0) : (rd >= dd ? rd - dd : rd + K2_WIN - dd);
-  if (dd >= l) {  // disjoint: plain strided copy
+  if (dd >= l) {  // disjoint
+    if (LINEAR || (rs + l <= K2_WIN && rd + l <= K2_WIN)) {  // 4-octet pieces, then the tail
+      const u32 np = l >> 2;
+      for (u32 j = lane; j < np; j += 64) k2_st32(win + rd + 4 * j, k2_ld32(win + rs + 4 * j));
+      if (lane < (l & 3)) win[rd + 4 * np + lane] = win[rs + 4 * np + lane];
+      return;
+    }
     for (u32 j = lane; j < l; j += 64) {
       u8 b = win[ring<LINEAR>(rs + j)];
       win[ring<LINEAR>(rd + j)] = b;
@@ -1935,18 +1957,28 @@ TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks) {
   for (u32 s = 0; s < g.seg_count && pos < clip; s++) {
     const Seg sg = P.segs[g.seg_first + s];
     u64 p = 0;
-    u64 tb = ~0ull;  // segment-relative index of tks[0]; ~0 = nothing staged
+    // token ring: chunk c (words [c*K2_TCH, (c+1)*K2_TCH) of the segment) lives in ring half c & 1.  The
+    // chunk after the one in use is already on its way in registers, so a batch never waits on memory
+    // except at the start of a segment.
+    const u16* tsrc = P.tok + sg.tok_index;
+    u32 cur = 0;
+    uint4 pre{};
+    tbz_sync();
+    if ((u64)lane * 8 < sg.tok_words) *(uint4*)(tks + lane * 8) = ((const U16x8*)(tsrc + lane * 8))->v;
+    if ((u64)K2_TCH + lane * 8 < sg.tok_words) pre = ((const U16x8*)(tsrc + K2_TCH + lane * 8))->v;
+    tbz_sync();
     while (p < sg.tok_words && pos < clip) {
       u64 left = sg.tok_words - p;
       u32 n = left < 64 ? (u32)left : 64;
-      if (tb == ~0ull || p + n > tb + K2_TOKBUF) {  // stage the next K2_TOKBUF words, coalesced
+      if ((p + n - 1) / K2_TCH > cur) {  // the batch reaches into the next chunk: land it, fetch the one after
+        cur += 1;
         tbz_sync();
-        tb = p;
-        u64 cnt = left < K2_TOKBUF ? left : K2_TOKBUF;
-        for (u32 k = lane; k < (u32)cnt; k += 64) tks[k] = P.tok[sg.tok_index + p + k];
+        *(uint4*)(tks + (cur & 1) * K2_TCH + lane * 8) = pre;
+        const u64 nx0 = (u64)(cur + 1) * K2_TCH + lane * 8;
+        if (nx0 < sg.tok_words) pre = ((const U16x8*)(tsrc + nx0))->v;
         tbz_sync();
       }
-      u32 w = lane < n ? tks[(u32)(p - tb) + lane] : 0;
+      u32 w = lane < n ? tks[((u32)p + lane) & (K2_TOKBUF - 1)] : 0;
       const u64 valid = n == 64 ? ~0ull : ((1ull << n) - 1);
       u64 hb = tbz_ballot((w & 0x8000u) != 0) & valid;        // heads (payload words have bit 15 clear)
       u64 sb = tbz_ballot((w & 0xC000u) == 0xC000u) & valid;  // stored-run heads
@@ -2010,20 +2042,31 @@ TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks) {
         bool ready = (pend & lane_bit) && need <= hwm;
         u64 rdy = tbz_ballot(ready);
         u64 longs = tbz_ballot(ready && len > K2_SHORT);
-        if (ready && len <= K2_SHORT) {
-          // own-lane copy.  An overlapping match repeats its dist-octet pattern, so every source octet
-          // is final already: read all of them first (independent LDS reads, one wait), then write.
-          u8 b[K2_SHORT];
-          u32 jj = 0;
-#pragma unroll
-          for (u32 j = 0; j < K2_SHORT; j++) {
-            b[j] = j < len ? win[ring<LINEAR>(rs + jj)] : 0;
-            jj++;
-            if (jj == dist) jj = 0;
+        const bool own = ready && len <= K2_SHORT;
+        // octet-addressed wide LDS accesses: a disjoint match is one or two reads and two (overlapping)
+        // writes that cover exactly [rd, rd + len)
+        const bool fast = own && dist >= len && (LINEAR || (rs + 16 <= K2_WIN && rd + 16 <= K2_WIN));
+        if (fast) {
+          if (len >= 9) {
+            const u64 a = k2_ld64(win + rs), b = k2_ld64(win + rs + len - 8);
+            k2_st64(win + rd, a);
+            k2_st64(win + rd + len - 8, b);
+          } else if (len >= 4) {
+            const u64 a = k2_ld64(win + rs);
+            k2_st32(win + rd, (u32)a);
+            k2_st32(win + rd + len - 4, (u32)(a >> ((len - 4) * 8)));
+          } else {
+            const u32 a = k2_ld32(win + rs);
+            k2_st16(win + rd, a);
+            win[rd + 2] = (u8)(a >> 16);
           }
-#pragma unroll
-          for (u32 j = 0; j < K2_SHORT; j++)
-            if (j < len) win[ring<LINEAR>(rd + j)] = b[j];
+        } else if (own) {
+          // overlapping (the match repeats its dist-octet pattern, all of it final already) or at the ring's seam
+          u32 jj = 0;
+          for (u32 j = 0; j < len; j++) {
+            win[ring<LINEAR>(rd + j)] = win[ring<LINEAR>(rs + jj)];
+            jj = jj + 1 == dist ? 0 : jj + 1;
+          }
         }
         while (longs) {
           u32 i = (u32)tbz_ffs64(longs) - 1;
@@ -2050,7 +2093,7 @@ TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks) {
 
 TBZ_KERNEL void tbz_k2_lz77(K2Params P) {
   TBZ_SHARED __attribute__((aligned(16))) u8 win[K2_WIN];
-  TBZ_SHARED u16 tks[K2_TOKBUF];
+  TBZ_SHARED __attribute__((aligned(16))) u16 tks[K2_TOKBUF];
   if (tbz_block() >= P.n_groups) return;
   k2_body<false>(P, win, tks);
 }

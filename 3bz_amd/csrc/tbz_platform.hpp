@@ -17,6 +17,7 @@
 #define TBZ_DEV __device__ __forceinline__
 #define TBZ_DEV_NOINLINE __device__ __noinline__
 #define TBZ_KERNEL extern "C" __global__ __launch_bounds__(64)
+#define TBZ_KERNEL_OCC(w) extern "C" __global__ __launch_bounds__(64, w)  // at least w waves per SIMD
 #define TBZ_SHARED __shared__
 #define TBZ_CONSTANT __constant__
 #define TBZ_RESTRICT __restrict__

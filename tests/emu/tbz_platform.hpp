@@ -27,6 +27,7 @@
 #define TBZ_DEV static inline
 #define TBZ_DEV_NOINLINE static
 #define TBZ_KERNEL static
+#define TBZ_KERNEL_OCC(w) static
 #define TBZ_SHARED static
 #define TBZ_CONSTANT static const
 #define TBZ_RESTRICT

@@ -1855,13 +1855,14 @@ TBZ_K1G_KERNEL(64)
 constexpr u32 K2_WIN = 36864;   // 32 KiB history + one batch span + slack; multiple of 16
 constexpr u32 K2_SPAN = 3072;   // max octets one batch may produce (cut otherwise)
 constexpr u32 K2_FLUSH = 8192;  // flush the ring to HBM every this many octets
-constexpr u32 K2_SHORT = 16;    // matches up to this length are copied by their own lane
+constexpr u32 K2_SHORT = 32;    // matches up to this length are copied by their own lane
 constexpr u32 K2_TCH = 512;     // token words per staged chunk: one 16-octet load per lane
 constexpr u32 K2_TOKBUF = 2 * K2_TCH;  // LDS token ring: the chunk in use + the next one (prefetched a chunk ahead)
-constexpr u32 K2_SLACK = 48;    // window octets past a group's output: alignment (16) + room for 16-octet reads
+constexpr u32 K2_SLACK = 64;    // window octets past a group's output: alignment (16) + room for wide reads
 constexpr u32 K2_SMALL_MAX = 32768;  // groups producing at most this much (incl. K2_SLACK) take the linear path
 
-// LDS accepts any octet address for 2/4/8-octet accesses on gfx950
+// LDS accepts any octet address for 2/4/8/16-octet accesses on gfx950
+struct __attribute__((packed, aligned(1))) K2U128 { u64 lo, hi; };
 struct __attribute__((packed, aligned(1))) K2U64 { u64 v; };
 struct __attribute__((packed, aligned(1))) K2U32 { u32 v; };
 struct __attribute__((packed, aligned(1))) K2U16 { u16 v; };
@@ -1943,6 +1944,66 @@ TBZ_DEV void k2_copy_coop(u8* win, u32 rd, u32 dd, u32 l) {
   }
 }
 
+// Multi-round resolution of one batch's matches (at most one per lane).  `pend` = lanes holding an
+// unresolved match; dofs = octet offset of the match inside the batch, whose first octet sits at
+// window index rpos.  A match is ready when the part of its source that it does not produce itself
+// lies below the high-water mark (the offset of the first unresolved match; everything below is
+// final).  The first unresolved match is always ready, so every round makes progress.
+template <bool LINEAR>
+TBZ_DEV void k2_resolve(u8* win, u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) {
+  const u32 lane = tbz_lane();
+  const u64 lane_bit = 1ull << lane;
+  // the part of the source a match does not write itself ends at dofs - dist + min(len, dist)
+  const i32 need = (i32)dofs - (i32)dist + (i32)(len < dist ? len : dist);
+  const u32 rd = ring<LINEAR>(rpos + dofs);
+  const u32 rs = LINEAR ? (rd >= dist ? rd - dist : 0) : (rd >= dist ? rd - dist : rd + K2_WIN - dist);
+  const u64 longm = tbz_ballot(len > K2_SHORT);
+  // octet-addressed wide LDS accesses: a disjoint match is one or two reads and two (overlapping)
+  // writes that cover exactly [rd, rd + len)
+  const bool fastable = len <= K2_SHORT && dist >= len && (LINEAR || (rs + 32 <= K2_WIN && rd + 32 <= K2_WIN));
+  tbz_sync();
+  while (pend) {
+    const u32 first = (u32)tbz_ffs64(pend) - 1;
+    const i32 hwm = (i32)tbz_readlane(dofs, first);
+    const bool ready = (pend & lane_bit) && need <= hwm;
+    const u64 rdy = tbz_ballot(ready);
+    u64 longs = rdy & longm;
+    if (ready && fastable) {
+      if (len >= 17) {
+        const K2U128 a = *(const K2U128*)(win + rs), b = *(const K2U128*)(win + rs + len - 16);
+        *(K2U128*)(win + rd) = a;
+        *(K2U128*)(win + rd + len - 16) = b;
+      } else if (len >= 9) {
+        const u64 a = k2_ld64(win + rs), b = k2_ld64(win + rs + len - 8);
+        k2_st64(win + rd, a);
+        k2_st64(win + rd + len - 8, b);
+      } else if (len >= 4) {
+        const u64 a = k2_ld64(win + rs);
+        k2_st32(win + rd, (u32)a);
+        k2_st32(win + rd + len - 4, (u32)(a >> ((len - 4) * 8)));
+      } else {
+        const u32 a = k2_ld32(win + rs);
+        k2_st16(win + rd, a);
+        win[rd + 2] = (u8)(a >> 16);
+      }
+    } else if (ready && len <= K2_SHORT) {
+      // overlapping (the match repeats its dist-octet pattern, all of it final already) or at the ring's seam
+      u32 jj = 0;
+      for (u32 j = 0; j < len; j++) {
+        win[ring<LINEAR>(rd + j)] = win[ring<LINEAR>(rs + jj)];
+        jj = jj + 1 == dist ? 0 : jj + 1;
+      }
+    }
+    while (longs) {
+      const u32 i = (u32)tbz_ffs64(longs) - 1;
+      longs &= longs - 1;
+      k2_copy_coop<LINEAR>(win, tbz_readlane(rd, i), tbz_readlane(dist, i), tbz_readlane(len, i));
+    }
+    pend &= ~rdy;
+    tbz_sync();
+  }
+}
+
 template <bool LINEAR>
 TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks) {
   const u32 lane = tbz_lane();
@@ -1968,9 +2029,9 @@ TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks) {
     if ((u64)K2_TCH + lane * 8 < sg.tok_words) pre = ((const U16x8*)(tsrc + K2_TCH + lane * 8))->v;
     tbz_sync();
     while (p < sg.tok_words && pos < clip) {
-      u64 left = sg.tok_words - p;
-      u32 n = left < 64 ? (u32)left : 64;
-      if ((p + n - 1) / K2_TCH > cur) {  // the batch reaches into the next chunk: land it, fetch the one after
+      const u64 left = sg.tok_words - p;
+      const u32 n2 = left < 128 ? (u32)left : 128;
+      if ((p + n2 - 1) / K2_TCH > cur) {  // the batch reaches into the next chunk: land it, fetch the one after
         cur += 1;
         tbz_sync();
         *(uint4*)(tks + (cur & 1) * K2_TCH + lane * 8) = pre;
@@ -1978,107 +2039,104 @@ TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks) {
         if (nx0 < sg.tok_words) pre = ((const U16x8*)(tsrc + nx0))->v;
         tbz_sync();
       }
-      u32 w = lane < n ? tks[((u32)p + lane) & (K2_TOKBUF - 1)] : 0;
-      const u64 valid = n == 64 ? ~0ull : ((1ull << n) - 1);
-      u64 hb = tbz_ballot((w & 0x8000u) != 0) & valid;        // heads (payload words have bit 15 clear)
-      u64 sb = tbz_ballot((w & 0xC000u) == 0xC000u) & valid;  // stored-run heads
-      u64 mb = hb & ~sb;                                      // match heads
-      if (sb & 1) {
-        // ---- stored run at the front of the batch: cooperative copy input -> window, flushing as we go
-        if (n < 4) break;  // malformed (never produced by K1)
-        u32 w1 = tbz_readlane(w, 1), w2 = tbz_readlane(w, 2), w3 = tbz_readlane(w, 3), w0 = tbz_readlane(w, 0);
-        u64 cnt = (w0 & 0x3fff) | ((u64)(w1 & 3) << 14);
-        u64 src = ((u64)(w1 >> 2) & 0x1fff) | ((u64)w2 << 13) | ((u64)w3 << 28);
-        while (cnt) {
-          u32 c = cnt < 4096 ? (u32)cnt : 4096;
-          tbz_sync();
-          for (u32 j = lane; j < c; j += 64) win[ring<LINEAR>(rpos + j)] = P.in_base[src + j];
-          tbz_sync();
-          pos += c;
-          rpos = ring<LINEAR>(rpos + c);
-          src += c;
-          cnt -= c;
-          if (!LINEAR && (pos - flushed >= K2_FLUSH || pos >= clip)) {
-            u64 upto = pos >= clip ? pos : ((pos + a0) & ~15ull) - a0;
-            if (upto > flushed) {
-              k2_flush<LINEAR>(win, outp, flushed, upto, clip, a0);
-              flushed = upto;
+      // ---- two words per lane: words 2*lane and 2*lane+1 of the batch
+      const bool va = 2 * lane < n2, vb = 2 * lane + 1 < n2;
+      const u32 a = va ? tks[((u32)p + 2 * lane) & (K2_TOKBUF - 1)] : 0;
+      const u32 b = vb ? tks[((u32)p + 2 * lane + 1) & (K2_TOKBUF - 1)] : 0;
+      if (tbz_ballot((a & 0xC000u) == 0xC000u || (b & 0xC000u) == 0xC000u) == 0) {
+        // ---- no stored run in sight.  A word with bit 15 set is a match head and the word after it its
+        // distance (bit 15 clear), so heads need no context; a lane holds at most one match.
+        const bool ha = (a & 0x8000u) != 0, hb = (b & 0x8000u) != 0;
+        const bool hav = ha && vb;                 // head with its distance word inside the batch
+        const bool hbv = hb && 2 * lane + 2 < n2;
+        const bool pa = tbz_wave_shr1(hb ? 1u : 0u) != 0;  // word a is the previous lane's distance word
+        const bool la = va && !ha && !pa, lb = vb && !hb && !ha;
+        const u32 len_a = hav ? (a & 0xff) + 3 : (la ? 1u : 0u);
+        const u32 len_b = hbv ? (b & 0xff) + 3 : (lb ? 1u : 0u);
+        const u32 sum = len_a + len_b;
+        const u32 incl = tbz_wave_incl_scan_u32(sum);
+        // words this lane accounts for: its own (0..2) plus, for a head in word b, the distance word after
+        const u32 cw = (ha && !vb) ? 0u : !vb ? 1u : (hb && !hbv) ? 1u : hbv ? 3u : 2u;
+        u32 nl = (n2 + 1) >> 1;  // lanes holding words
+        if (!LINEAR) {           // the ring must not be overrun inside one batch
+          const u64 over = tbz_ballot(incl > K2_SPAN);
+          const u32 lok = over ? (u32)tbz_ffs64(over) - 1 : 64u;
+          nl = nl < lok ? nl : lok;
+        }
+        const u32 last = nl - 1;  // nl >= 1: one lane produces at most 259 octets
+        const u32 m = 2 * last + tbz_readlane(cw, last);
+        if (m == 0) break;  // malformed token stream (never produced by K1)
+        const u32 total = tbz_readlane(incl, last);
+        const bool act = lane <= last;
+        const u32 oa = incl - sum, ob = oa + len_a;
+        if (la && act) win[ring<LINEAR>(rpos + oa)] = (u8)a;
+        if (lb && act) win[ring<LINEAR>(rpos + ob)] = (u8)b;
+        const u32 na = tbz_wave_shl1(a);  // next lane's word a: the distance word of a head in b
+        const bool hasm = (hav || hbv) && act;
+        const u32 len = hav ? len_a : len_b;
+        const u32 dist = ((hav ? b : na) & 0x7fffu) + 1;
+        k2_resolve<LINEAR>(win, tbz_ballot(hasm), rpos, hav ? oa : ob, hasm ? len : 0u, dist);
+        pos += total;
+        rpos = ring<LINEAR>(rpos + total);
+        p += m;
+      } else {
+        // ---- a stored run within reach: one word per lane, up to the run (or the run itself)
+        const u32 n = left < 64 ? (u32)left : 64;
+        const u32 w = lane < n ? tks[((u32)p + lane) & (K2_TOKBUF - 1)] : 0;
+        const u64 valid = n == 64 ? ~0ull : ((1ull << n) - 1);
+        u64 hbm = tbz_ballot((w & 0x8000u) != 0) & valid;        // heads (payload words have bit 15 clear)
+        u64 sb = tbz_ballot((w & 0xC000u) == 0xC000u) & valid;   // stored-run heads
+        u64 mb = hbm & ~sb;                                      // match heads
+        if (sb & 1) {
+          // stored run at the front of the batch: cooperative copy input -> window, flushing as we go
+          if (n < 4) break;  // malformed (never produced by K1)
+          u32 w1 = tbz_readlane(w, 1), w2 = tbz_readlane(w, 2), w3 = tbz_readlane(w, 3), w0 = tbz_readlane(w, 0);
+          u64 cnt = (w0 & 0x3fff) | ((u64)(w1 & 3) << 14);
+          u64 src = ((u64)(w1 >> 2) & 0x1fff) | ((u64)w2 << 13) | ((u64)w3 << 28);
+          while (cnt) {
+            u32 c = cnt < 4096 ? (u32)cnt : 4096;
+            tbz_sync();
+            for (u32 j = lane; j < c; j += 64) win[ring<LINEAR>(rpos + j)] = P.in_base[src + j];
+            tbz_sync();
+            pos += c;
+            rpos = ring<LINEAR>(rpos + c);
+            src += c;
+            cnt -= c;
+            if (!LINEAR && (pos - flushed >= K2_FLUSH || pos >= clip)) {
+              u64 upto = pos >= clip ? pos : ((pos + a0) & ~15ull) - a0;
+              if (upto > flushed) {
+                k2_flush<LINEAR>(win, outp, flushed, upto, clip, a0);
+                flushed = upto;
+              }
             }
+            if (pos >= clip) break;
           }
-          if (pos >= clip) break;
+          p += 4;
+          continue;
         }
-        p += 4;
-        continue;
+        // everything before the first stored head
+        u32 n_eff = sb ? (u32)tbz_ffs64(sb) - 1 : n;
+        const u64 veff = n_eff == 64 ? ~0ull : ((1ull << n_eff) - 1);
+        mb &= veff;
+        u64 pm = (mb << 1);               // payload (distance) words
+        u64 lits = veff & ~mb & ~pm;
+        u64 cut_ok = (lits | pm) & veff;  // a batch may end after a literal or after a distance word
+        bool head = (mb & lane_bit) != 0, islit = (lits & lane_bit) != 0;
+        u32 len = head ? (w & 0xff) + 3 : (islit ? 1u : 0u);
+        u32 incl = tbz_wave_incl_scan_u32(len);
+        u64 ok = LINEAR ? cut_ok : (tbz_ballot(incl <= K2_SPAN) & cut_ok);
+        if (ok == 0) break;  // malformed token stream (never produced by K1)
+        u32 m = 64 - (u32)__builtin_clzll(ok);
+        u32 total = tbz_readlane(incl, m - 1);
+        const u64 act = m == 64 ? ~0ull : ((1ull << m) - 1);
+        u32 dofs = incl - len;  // octet offset of this token inside the batch
+        u32 dist = (tbz_wave_shl1(w) & 0x7fffu) + 1;
+        if (islit && (act & lane_bit)) win[ring<LINEAR>(rpos + dofs)] = (u8)w;
+        k2_resolve<LINEAR>(win, mb & act, rpos, dofs, len, dist);
+        pos += total;
+        rpos = ring<LINEAR>(rpos + total);
+        p += m;
       }
-      // ---- ordinary batch: everything before the first stored head
-      u32 n_eff = sb ? (u32)tbz_ffs64(sb) - 1 : n;
-      const u64 veff = n_eff == 64 ? ~0ull : ((1ull << n_eff) - 1);
-      mb &= veff;
-      u64 pm = (mb << 1);               // payload (distance) words
-      u64 lits = veff & ~mb & ~pm;
-      u64 cut_ok = (lits | pm) & veff;  // a batch may end after a literal or after a distance word
-      bool head = (mb & lane_bit) != 0, islit = (lits & lane_bit) != 0;
-      u32 len = head ? (w & 0xff) + 3 : (islit ? 1u : 0u);
-      u32 incl = tbz_wave_incl_scan_u32(len);
-      // the ring must not be overrun inside one batch; a linear window holds the whole group anyway
-      u64 ok = LINEAR ? cut_ok : (tbz_ballot(incl <= K2_SPAN) & cut_ok);
-      if (ok == 0) break;  // malformed token stream (never produced by K1)
-      u32 m = 64 - (u32)__builtin_clzll(ok);
-      u32 total = tbz_readlane(incl, m - 1);
-      const u64 act = m == 64 ? ~0ull : ((1ull << m) - 1);
-      u32 dofs = incl - len;  // octet offset of this token inside the batch
-      u32 dist = (tbz_wave_shl1(w) & 0x7fffu) + 1;
-      if (islit && (act & lane_bit)) win[ring<LINEAR>(rpos + dofs)] = (u8)w;
-      // multi-round resolution
-      u64 pend = mb & act;
-      // the part of the source a match does not write itself ends at dofs - dist + min(len, dist)
-      i32 need = (i32)dofs - (i32)dist + (i32)(len < dist ? len : dist);
-      u32 rd = ring<LINEAR>(rpos + dofs);
-      u32 rs = LINEAR ? (rd >= dist ? rd - dist : 0) : (rd >= dist ? rd - dist : rd + K2_WIN - dist);
-      tbz_sync();
-      while (pend) {
-        u32 first = (u32)tbz_ffs64(pend) - 1;
-        i32 hwm = (i32)tbz_readlane(dofs, first);
-        bool ready = (pend & lane_bit) && need <= hwm;
-        u64 rdy = tbz_ballot(ready);
-        u64 longs = tbz_ballot(ready && len > K2_SHORT);
-        const bool own = ready && len <= K2_SHORT;
-        // octet-addressed wide LDS accesses: a disjoint match is one or two reads and two (overlapping)
-        // writes that cover exactly [rd, rd + len)
-        const bool fast = own && dist >= len && (LINEAR || (rs + 16 <= K2_WIN && rd + 16 <= K2_WIN));
-        if (fast) {
-          if (len >= 9) {
-            const u64 a = k2_ld64(win + rs), b = k2_ld64(win + rs + len - 8);
-            k2_st64(win + rd, a);
-            k2_st64(win + rd + len - 8, b);
-          } else if (len >= 4) {
-            const u64 a = k2_ld64(win + rs);
-            k2_st32(win + rd, (u32)a);
-            k2_st32(win + rd + len - 4, (u32)(a >> ((len - 4) * 8)));
-          } else {
-            const u32 a = k2_ld32(win + rs);
-            k2_st16(win + rd, a);
-            win[rd + 2] = (u8)(a >> 16);
-          }
-        } else if (own) {
-          // overlapping (the match repeats its dist-octet pattern, all of it final already) or at the ring's seam
-          u32 jj = 0;
-          for (u32 j = 0; j < len; j++) {
-            win[ring<LINEAR>(rd + j)] = win[ring<LINEAR>(rs + jj)];
-            jj = jj + 1 == dist ? 0 : jj + 1;
-          }
-        }
-        while (longs) {
-          u32 i = (u32)tbz_ffs64(longs) - 1;
-          longs &= longs - 1;
-          k2_copy_coop<LINEAR>(win, tbz_readlane(rd, i), tbz_readlane(dist, i), tbz_readlane(len, i));
-        }
-        pend &= ~rdy;
-        tbz_sync();
-      }
-      pos += total;
-      rpos = ring<LINEAR>(rpos + total);
-      p += m;
       if (!LINEAR && pos - flushed >= K2_FLUSH) {
         u64 upto = ((pos + a0) & ~15ull) - a0;  // keep the unaligned tail in the ring
         if (upto > flushed) {

@@ -32,7 +32,14 @@ using i64 = int64_t;
 TBZ_DEV u32 tbz_lane() { return threadIdx.x; }
 TBZ_DEV u32 tbz_block() { return blockIdx.x; }
 TBZ_DEV u32 tbz_nblocks() { return gridDim.x; }
-TBZ_DEV void tbz_sync() { __syncthreads(); }
+// Workgroup == one wavefront, and a wave's LDS (and vector-memory) instructions execute in issue order, so
+// "all lanes' earlier accesses are visible to all lanes' later ones" needs no s_barrier and no s_waitcnt:
+// a wavefront-scope fence (compiler ordering only) is the whole synchronisation.  In particular it does
+// not drain vmcnt, so prefetches and stores stay in flight across it.
+TBZ_DEV void tbz_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 TBZ_DEV u64 tbz_ballot(bool p) { return __ballot(p); }
 TBZ_DEV u32 tbz_shfl(u32 v, int src) { return (u32)__shfl((int)v, src, 64); }
 TBZ_DEV u32 tbz_shfl_up(u32 v, unsigned d) { return (u32)__shfl_up((int)v, d, 64); }

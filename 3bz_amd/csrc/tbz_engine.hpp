@@ -42,10 +42,14 @@ struct tbz_ctx {
   std::string err;
   tbz_timings tim{};
   uint64_t gang_rounds = 0, gang_valid = 0;  // diagnostics of the last call (K1g)
+  bool host_layout = false;  // env TBZ_HOST_LAYOUT=1: always chain / lay out on the host (tests force both paths)
+  void* h_pin = nullptr;     // pinned host scratch for small read-backs
+  size_t h_pin_cap = 0;
   int k1_mode = 0;  // 0 auto, 1 lane-per-item, 4..64 gang of that many lanes (env TBZ_K1_MODE; tests force each)
   // device pools (grow-only)
   tbz::DevBuf d_str_off, d_str_len, d_tile_first, d_tile_counts, d_tile_offsets, d_markers, d_items, d_res,
-      d_tok, d_scratch, d_stage, d_segs, d_groups, d_order, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
+      d_tok, d_scratch, d_stage, d_segs, d_groups, d_order, d_k3_fi, d_k3_ni, d_k3_oo, d_k3_oc, d_k3_sums, d_k3_flags,
+      d_k3_gscan, d_k3_gne, d_k3_streams, d_k3_glob, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
       d_out_stage;
 };
 
@@ -237,7 +241,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     in_extent = std::max(in_extent, in_offs[s] + in_lens[s]);
     in_total_bits += in_lens[s] * 8;
     tile_first[s] = (uint32_t)tiles;
-    tiles += (in_lens[s] + SCAN_TILE - 1) / SCAN_TILE;
+    // tiles are 64 KiB of memory starting at the stream's first octet rounded down to 16 (see K0)
+    tiles += ((((uintptr_t)d_in + in_offs[s]) & 15) + in_lens[s] + SCAN_TILE - 1) / SCAN_TILE;
     if (tiles > 0x7fffffffu) return TBZ_E_ARG;
   }
   tile_first[n] = (uint32_t)tiles;
@@ -345,16 +350,131 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     }
     return 0;
   };
+  // K3 (layout on the device when every item simply lands on its successor): its stream tables go up before
+  // K1 so that nothing but two tiny kernels and a 16-byte read-back stand between K1 and the decision
+  const bool try_simple = !ctx->host_layout && !items.empty();
+  const u32 k3_tiles = (u32)((items.size() + K3_TILE - 1) / K3_TILE);
+  K3Params k3{};
+  if (try_simple) {
+    std::vector<uint32_t> fi(n), ni(n);
+    std::vector<uint64_t> oo(n), oc(n);
+    for (size_t s = 0; s < n; s++) {
+      fi[s] = sp[s].first_item;
+      ni[s] = sp[s].n_items;
+      oo[s] = sp[s].out_off;
+      oc[s] = size_only ? 0 : sp[s].out_cap;
+    }
+    if ((r = upload(ctx, ctx->d_k3_fi, fi))) return r;
+    if ((r = upload(ctx, ctx->d_k3_ni, ni))) return r;
+    if ((r = upload(ctx, ctx->d_k3_oo, oo))) return r;
+    if ((r = upload(ctx, ctx->d_k3_oc, oc))) return r;
+    if ((r = ensure(ctx, ctx->d_k3_sums, 3 * (size_t)(k3_tiles + 1) * 8))) return r;
+    if ((r = ensure(ctx, ctx->d_k3_flags, 3 * (size_t)k3_tiles * 8))) return r;
+    if ((r = ensure(ctx, ctx->d_k3_gscan, items.size() * 8))) return r;
+    if ((r = ensure(ctx, ctx->d_k3_gne, items.size() * 4))) return r;
+    if ((r = ensure(ctx, ctx->d_segs, items.size() * sizeof(Seg)))) return r;
+    if ((r = ensure(ctx, ctx->d_groups, items.size() * sizeof(Group)))) return r;
+    if ((r = ensure(ctx, ctx->d_k3_streams, (n + 1) * sizeof(K3Stream)))) return r;
+    if ((r = ensure(ctx, ctx->d_k3_glob, sizeof(K3Global)))) return r;
+    size_t pin = sizeof(K3Global) + (n + 1) * sizeof(K3Stream);
+    if (pin > ctx->h_pin_cap) {
+      if (ctx->h_pin) TBZ_HIP(hipHostFree(ctx->h_pin));
+      ctx->h_pin = nullptr;
+      ctx->h_pin_cap = 0;
+      TBZ_HIP(hipHostMalloc(&ctx->h_pin, pin * 2));
+      ctx->h_pin_cap = pin * 2;
+    }
+    k3 = K3Params{(const Item*)ctx->d_items.p, (const SegResult*)ctx->d_res.p, (const u32*)ctx->d_k3_fi.p,
+                  (const u32*)ctx->d_k3_ni.p, (const u64*)ctx->d_k3_oo.p, (const u64*)ctx->d_k3_oc.p,
+                  (u64*)ctx->d_k3_sums.p, (u64*)ctx->d_k3_flags.p, (u64*)ctx->d_k3_gscan.p, (u32*)ctx->d_k3_gne.p,
+                  (Seg*)ctx->d_segs.p, (Group*)ctx->d_groups.p, (K3Stream*)ctx->d_k3_streams.p,
+                  (K3Global*)ctx->d_k3_glob.p, (u32)items.size(), k3_tiles, (u32)n};
+  }
   if ((r = record(ctx, 2))) return r;
   if ((r = launch_k1((const Item*)ctx->d_items.p, (SegResult*)ctx->d_res.p, items.size()))) return r;
   TBZ_HIP(hipGetLastError());
   if ((r = record(ctx, 3))) return r;
   ctx->tim.huff_launches = 1;
+  bool simple = false;
+  K3Global* h_glob = (K3Global*)ctx->h_pin;
+  K3Stream* h_k3s = (K3Stream*)((char*)ctx->h_pin + sizeof(K3Global));
+  if (try_simple) {
+    TBZ_LAUNCH(tbz_k3_tile_sums, k3_tiles, ctx->stream, k3);
+    TBZ_LAUNCH(tbz_k3_scan_tiles, 1, ctx->stream, k3);
+    TBZ_HIP(hipMemcpyAsync(h_glob, ctx->d_k3_glob.p, sizeof(K3Global), hipMemcpyDeviceToHost, ctx->stream));
+    TBZ_HIP(hipStreamSynchronize(ctx->stream));
+    simple = h_glob->not_simple == 0;
+  }
+  // what a stream reports once its status is known (both layout paths)
+  auto fill_result = [&](size_t s, int32_t status, uint32_t nseg) {
+    StreamPlan& S = sp[s];
+    tbz_result& R = results[s];
+    // 3bz decodes front to back: it reports overflow as soon as a token does not fit, before it
+    // could meet a later error / underrun
+    uint64_t cap = S.out_cap;
+    bool overflow = S.total_out > cap;
+    if (overflow) status = TBZ_OUTPUT_OVERFLOW;
+    R.status = status;
+    R.segments = nseg;
+    R.out_total = S.total_out;
+    R.out_len = overflow ? cap : S.total_out;
+    R.in_consumed = S.saw_final ? (S.in_end_bit / 8 - S.in_off) : 0;
+    R.trailer_check = S.trailer0;
+    R.trailer_isize = S.trailer1;
+    if (S.saw_final) R.flags |= 2;
+    if (status < 0) R.out_len = 0;  // reference signals an error: no partial-result contract
+    return status;
+  };
+  float huff_ms = 0;
+  if (simple) {
+    // ---------------------------------------------------------------- device layout + K2, host reads n+1 records
+    TBZ_LAUNCH(tbz_k3_scan_items, k3_tiles, ctx->stream, k3);
+    TBZ_LAUNCH(tbz_k3_emit, k3_tiles, ctx->stream, k3);
+    TBZ_HIP(hipMemcpyAsync(h_k3s, ctx->d_k3_streams.p, (n + 1) * sizeof(K3Stream), hipMemcpyDeviceToHost, ctx->stream));
+    TBZ_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
+    if ((r = record(ctx, 4))) return r;
+    if (!size_only) {
+      if (!d_out) return TBZ_E_ARG;
+      const u32 n_it = (u32)items.size();
+      K2Params k2{(const u16*)ctx->d_tok.p, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, nullptr,
+                  (const u8*)d_in, (u8*)d_out, n_it, 0, 0};
+      if (h_glob->n_big < n_it) {
+        k2.win_bytes = (u32)((h_glob->max_small + K2_SLACK + 255) & ~255ull);
+        k2.cls = h_glob->n_big ? 1 : 0;
+        TBZ_LAUNCH_DYN(tbz_k2_lz77_small, n_it, k2.win_bytes + 2 * K2_TOKBUF, ctx->stream, k2);
+      }
+      if (h_glob->n_big) {
+        k2.win_bytes = 0;
+        k2.cls = h_glob->n_big < n_it ? 2 : 0;
+        TBZ_LAUNCH(tbz_k2_lz77, n_it, ctx->stream, k2);
+      }
+      TBZ_HIP(hipGetLastError());
+    }
+    if ((r = record(ctx, 5))) return r;
+    TBZ_HIP(hipEventSynchronize(ctx->ev[7]));  // the stream records are here; K2 keeps running
+    huff_ms = elapsed(ctx, 2, 3);
+    ctx->tim.huff_ms = huff_ms;
+    ctx->tim.token_words = h_k3s[n].tok_words;
+    ctx->tim.n_segments = ctx->tim.n_groups = h_k3s[n].nonempty;
+    for (size_t s = 0; s < n; s++) {
+      StreamPlan& S = sp[s];
+      const K3Stream& k = h_k3s[s];
+      S.total_out = k.total_out;
+      S.saw_final = true;
+      S.trailer0 = k.last.trailer0;
+      S.trailer1 = k.last.trailer1;
+      S.trailer_have = k.last.trailer_have;
+      S.in_end_bit = k.last.end_bit;
+      S.status = TBZ_FINISHED;
+      S.done = true;
+      fill_result(s, TBZ_FINISHED, (uint32_t)k.nonempty);
+    }
+  } else {
   std::vector<SegResult> res(items.size());
   TBZ_HIP(hipMemcpyAsync(res.data(), ctx->d_res.p, res.size() * sizeof(SegResult), hipMemcpyDeviceToHost,
                          ctx->stream));
   TBZ_HIP(hipStreamSynchronize(ctx->stream));
-  float huff_ms = elapsed(ctx, 2, 3);
+  huff_ms = elapsed(ctx, 2, 3);
 
   // ---------------------------------------------------------------- chain walk (+ fix-up rounds)
   std::vector<SegHost> segs;
@@ -477,23 +597,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       if (h.deficit && (uint64_t)h.deficit > produced && status >= 0) status = TBZ_E_DISTANCE;
       produced += h.seg.out_bytes;
     }
-    // 3bz decodes front to back: it reports overflow as soon as a token does not fit, before it
-    // could meet a later error / underrun
-    uint64_t cap = S.out_cap;
-    bool overflow = S.total_out > cap;
-    if (overflow) status = TBZ_OUTPUT_OVERFLOW;
-    R.status = status;
-    R.segments = (uint32_t)v.size();
-    R.out_total = S.total_out;
-    R.out_len = overflow ? cap : S.total_out;
-    R.in_consumed = S.saw_final ? (S.in_end_bit / 8 - S.in_off) : 0;
-    R.trailer_check = S.trailer0;
-    R.trailer_isize = S.trailer1;
-    if (S.saw_final) R.flags |= 2;
-    if (status < 0) {
-      R.out_len = 0;
-      continue;  // reference signals an error: no partial-result contract
-    }
+    status = fill_result(s, status, (uint32_t)v.size());
+    if (status < 0) continue;  // reference signals an error: no partial-result contract
     if (size_only) continue;
     // groups: a segment that needs history (or continues a repaired block) joins its predecessor
     uint64_t o = 0;
@@ -542,7 +647,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     order.insert(order.end(), order_big.begin(), order_big.end());
     if ((r = upload(ctx, ctx->d_order, order))) return r;
     K2Params k2{(const u16*)ctx->d_tok.p, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p,
-                (const u32*)ctx->d_order.p, (const u8*)d_in, (u8*)d_out, 0, 0};
+                (const u32*)ctx->d_order.p, (const u8*)d_in, (u8*)d_out, 0, 0, 0};
     if (!order_small.empty()) {
       k2.n_groups = (u32)order_small.size();
       k2.win_bytes = (u32)((max_small + K2_SLACK + 255) & ~255ull);
@@ -557,6 +662,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     TBZ_HIP(hipGetLastError());
   }
   if ((r = record(ctx, 5))) return r;
+  }  // !simple
 
   // ---------------------------------------------------------------- K4 / K5 + trailer compare
   if (!size_only && format != TBZ_FORMAT_DEFLATE) {
@@ -600,6 +706,10 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   ctx->tim.lz_ms = elapsed(ctx, 4, 5);
   ctx->tim.cksum_ms = elapsed(ctx, 5, 6);
   ctx->tim.total_ms = elapsed(ctx, 0, 6);
+  if (getenv("TBZ_DEBUG") && !ctx->tim.fixup_rounds)
+    fprintf(stderr, "tbz: ms scan %.3f | items+upload %.3f | huff %.3f | results+walk+layout %.3f | lz %.3f | cksum %.3f\n",
+            elapsed(ctx, 0, 1), elapsed(ctx, 1, 2), elapsed(ctx, 2, 3), elapsed(ctx, 3, 4), elapsed(ctx, 4, 5),
+            elapsed(ctx, 5, 6));
   return 0;
 }
 
@@ -675,6 +785,7 @@ int tbz_ctx_create(int device_id, tbz_ctx** out_ctx) {
   }
   if ((e = hipMemcpy(ctx->d_crc_tab.p, t.data(), t.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
     return fail(e, "hipMemcpy");
+  if (const char* m = getenv("TBZ_HOST_LAYOUT")) ctx->host_layout = m[0] == '1';
   if (const char* m = getenv("TBZ_K1_MODE")) {
     if (!strcmp(m, "lane")) ctx->k1_mode = 1;
     else if (!strncmp(m, "gang", 4)) {
@@ -693,9 +804,12 @@ void tbz_ctx_destroy(tbz_ctx* ctx) {
   tbz::DevBuf* bufs[] = {&ctx->d_str_off, &ctx->d_str_len, &ctx->d_tile_first, &ctx->d_tile_counts,
                          &ctx->d_tile_offsets, &ctx->d_markers, &ctx->d_items, &ctx->d_res, &ctx->d_tok, &ctx->d_scratch, &ctx->d_stage, &ctx->d_order,
                          &ctx->d_segs, &ctx->d_groups, &ctx->d_ck_chunks, &ctx->d_ck_parts, &ctx->d_ck_streams,
-                         &ctx->d_ck_out, &ctx->d_crc_tab, &ctx->d_in_stage, &ctx->d_out_stage};
+                         &ctx->d_ck_out, &ctx->d_crc_tab, &ctx->d_in_stage, &ctx->d_out_stage, &ctx->d_k3_fi, &ctx->d_k3_ni,
+                         &ctx->d_k3_oo, &ctx->d_k3_oc, &ctx->d_k3_sums, &ctx->d_k3_flags, &ctx->d_k3_gscan, &ctx->d_k3_gne,
+                         &ctx->d_k3_streams, &ctx->d_k3_glob};
   for (auto* b : bufs)
     if (b->p) hipFree(b->p);
+  if (ctx->h_pin) hipHostFree(ctx->h_pin);
   for (auto& ev : ctx->ev)
     if (ev) hipEventDestroy(ev);
   if (ctx->stream) hipStreamDestroy(ctx->stream);

@@ -70,8 +70,11 @@ TBZ_DEV u32 load_u32_unaligned(const u32* TBZ_RESTRICT w, u64 idx, u64 nwords) {
 // K0 — marker scan.  A marker is the byte AFTER `00 00 FF FF` (the LEN/NLEN of an empty stored
 // block, which zlib emits for Z_SYNC_FLUSH / Z_FULL_FLUSH).  3bz has no counterpart: it is strictly
 // sequential (:block-end -> :start-of-block, deflate.lisp:719-722).
-// Work split: tile = 64 KiB of one stream = 64 rows of 1 KiB; lane j of row r owns the 16 positions
-// starting at tile + r*1024 + j*16, so a row is one fully coalesced 1 KiB read.
+// Work split: a tile is 64 KiB of MEMORY (16-octet aligned, so every load is an aligned dwordx4) =
+// 64 rows of 1 KiB; lane j of row r owns the 16 octets at tile + r*1024 + j*16, a row is one fully
+// coalesced 1 KiB read.  Four v_qsad_pk_u16_u8 compare the pattern against all 16 start positions
+// of a lane (the three octets of lookahead come from the next lane by DPP); a packed-min tree says
+// "no hit in these 16" in 10 more instructions, which is the answer for all but one row in eight.
 // ================================================================================================
 struct K0Params {
   const u8* in_base;
@@ -94,56 +97,54 @@ TBZ_DEV u32 k0_find_stream(const K0Params& P, u32 tile) {
   return lo;
 }
 
-// 16-bit mask of marker-pattern starts among the 16 positions [p0, p0+16) owned by this lane
-TBZ_DEV u32 k0_row_mask(const u32* TBZ_RESTRICT w, u64 mis, u64 p0, u64 s_begin, u64 s_end, u64 nwords) {
-  // position p is a hit iff bytes p..p+3 = 00 00 FF FF, p >= s_begin and p + 4 < s_end
-  if (p0 >= s_end) return 0;
-  u64 a = p0 + mis;  // byte index from the aligned base
-  u64 wi = a >> 2;
-  u32 W[6];
-#pragma unroll
-  for (int k = 0; k < 6; k++) W[k] = (wi + k) < nwords ? w[wi + k] : 0;
-  u32 m = 0;
-  u32 b0 = (u32)(a & 3);
-#pragma unroll
-  for (u32 k = 0; k < 16; k++) {
-    u32 b = b0 + k;
-    u32 sh = (b & 3) * 8;
-    u32 lo = W[b >> 2], hi = W[(b >> 2) + 1];
-    u32 v = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
-    if (v == 0xFFFF0000u && p0 + k + 4 < s_end) m |= 1u << k;
-  }
-  (void)s_begin;
-  return m;
-}
-
+// tiles of a stream start at its first octet's address rounded down to 16 (the host counts them the same way)
 struct K0Tile {
-  const u32* w;
-  u64 mis, nwords, s_begin, s_end, t_begin;
+  uintptr_t t0;          // address of the tile's first row (16-aligned)
+  uintptr_t s_lo, s_hi;  // addresses of the stream's first octet and one past its last
+  uintptr_t base;        // address of in_base (marker positions are relative to it)
 };
 TBZ_DEV K0Tile k0_tile(const K0Params& P) {
   K0Tile T;
-  u32 tile = tbz_block();
-  u32 s = k0_find_stream(P, tile);
-  u64 off = P.str_off[s], len = P.str_len[s];
-  uintptr_t base = (uintptr_t)P.in_base;
-  T.mis = base & 3;
-  T.w = (const u32*)(base - T.mis);
-  T.s_begin = off;
-  T.s_end = off + len;
-  T.nwords = (T.mis + T.s_end + 3) >> 2;
-  T.t_begin = off + (u64)(tile - P.tile_first[s]) * SCAN_TILE;
+  const u32 tile = tbz_block();
+  const u32 s = k0_find_stream(P, tile);
+  T.base = (uintptr_t)P.in_base;
+  T.s_lo = T.base + P.str_off[s];
+  T.s_hi = T.s_lo + P.str_len[s];
+  T.t0 = (T.s_lo & ~(uintptr_t)15) + (uintptr_t)(tile - P.tile_first[s]) * SCAN_TILE;
   return T;
 }
 
+// 16-bit mask of marker-pattern starts among the 16 octets at address c owned by this lane:
+// octet address q is a hit iff q..q+3 = 00 00 FF FF, q >= s_lo and q + 4 < s_hi
+TBZ_DEV u32 k0_row_mask(const K0Tile& T, uintptr_t c) {
+  const u32 lane = tbz_lane();
+  uint4 v{};
+  // an aligned 16-octet chunk that holds at least one octet of the stream lies inside a mapped page
+  if (c < T.s_hi && c + 16 > T.s_lo) v = *(const uint4*)c;
+  u32 nx = tbz_wave_shl1(v.x);
+  if (lane == 63 && c + 16 < T.s_hi) nx = *(const u32*)(c + 16);
+  const u32 ref = 0xFFFF0000u;
+  const u64 q0 = tbz_qsad4(((u64)v.y << 32) | v.x, ref), q1 = tbz_qsad4(((u64)v.z << 32) | v.y, ref);
+  const u64 q2 = tbz_qsad4(((u64)v.w << 32) | v.z, ref), q3 = tbz_qsad4(((u64)nx << 32) | v.w, ref);
+  u32 m0 = tbz_pk_min_u16((u32)q0, (u32)(q0 >> 32)), m1 = tbz_pk_min_u16((u32)q1, (u32)(q1 >> 32));
+  u32 m2 = tbz_pk_min_u16((u32)q2, (u32)(q2 >> 32)), m3 = tbz_pk_min_u16((u32)q3, (u32)(q3 >> 32));
+  m0 = tbz_pk_min_u16(tbz_pk_min_u16(m0, m1), tbz_pk_min_u16(m2, m3));
+  if ((m0 & 0xffffu) != 0 && (m0 >> 16) != 0) return 0;
+  u32 m = 0;
+  const u64 q[4] = {q0, q1, q2, q3};
+#pragma unroll
+  for (u32 k = 0; k < 16; k++) {
+    const uintptr_t a = c + k;
+    if (((q[k >> 2] >> (16 * (k & 3))) & 0xffffu) == 0 && a >= T.s_lo && a + 4 < T.s_hi) m |= 1u << k;
+  }
+  return m;
+}
+
 TBZ_KERNEL void tbz_k0_scan_count(K0Params P) {
-  K0Tile T = k0_tile(P);
+  const K0Tile T = k0_tile(P);
   const u32 lane = tbz_lane();
   u32 cnt = 0;
-  for (u32 r = 0; r < SCAN_TILE / 1024; r++) {
-    u64 p0 = T.t_begin + r * 1024 + lane * 16;
-    cnt += __builtin_popcount(k0_row_mask(T.w, T.mis, p0, T.s_begin, T.s_end, T.nwords));
-  }
+  for (u32 r = 0; r < SCAN_TILE / 1024; r++) cnt += __builtin_popcount(k0_row_mask(T, T.t0 + r * 1024 + lane * 16));
   u32 tot = (u32)wave_sum_u64(cnt);
   if (lane == 0) P.tile_counts[tbz_block()] = tot;
 }
@@ -162,19 +163,20 @@ TBZ_KERNEL void tbz_k0_scan_offsets(K0Params P) {
 }
 
 TBZ_KERNEL void tbz_k0_scan_emit(K0Params P) {
-  K0Tile T = k0_tile(P);
+  const K0Tile T = k0_tile(P);
   const u32 lane = tbz_lane();
   u32 base = P.tile_offsets[tbz_block()];
   for (u32 r = 0; r < SCAN_TILE / 1024; r++) {
-    u64 p0 = T.t_begin + r * 1024 + lane * 16;
-    u32 m = k0_row_mask(T.w, T.mis, p0, T.s_begin, T.s_end, T.nwords);
-    u32 c = __builtin_popcount(m);
-    u32 inc = wave_incl_scan_u32(c);
-    u32 o = base + inc - c;
+    const uintptr_t c = T.t0 + r * 1024 + lane * 16;
+    u32 m = k0_row_mask(T, c);
+    if (tbz_ballot(m != 0) == 0) continue;  // wave-uniform: nothing in this row
+    u32 n = __builtin_popcount(m);
+    u32 inc = wave_incl_scan_u32(n);
+    u32 o = base + inc - n;
     while (m) {
       u32 k = __builtin_ctz(m);
       m &= m - 1;
-      P.markers[o++] = p0 + k + 4;
+      P.markers[o++] = (u64)(c + k - T.base) + 4;
     }
     base += tbz_shfl(inc, 63);
   }
@@ -906,7 +908,10 @@ constexpr u32 KG_LPOOL = 352;           // second-level entries (codes longer th
 constexpr u32 KG_DPOOL = 128;           //   … if a code needs more, its long codes take the exact (slow) step instead
 constexpr u32 KG_SUB_MIN = 1024;        // bits of bitstream per lane per round
 constexpr u32 KG_SUB_MAX = 8192;
-constexpr u32 KG_OVL = 512;             // run-up bits before a lane's sub-range
+#ifndef KG_OVL_BITS
+#define KG_OVL_BITS 512
+#endif
+constexpr u32 KG_OVL = KG_OVL_BITS;             // run-up bits before a lane's sub-range
 constexpr u32 KG_STAGE_SLACK = 16384;   // words of slack at the end of the staging pool
 
 // lookup entries (u16).  bits 0-3: code length; 0 = not a symbol:
@@ -1879,8 +1884,9 @@ struct K2Params {
   const u32* order;   // group indices this launch handles
   const u8* in_base;  // source of stored runs
   u8* out_base;
-  u32 n_groups;       // entries in `order`
+  u32 n_groups;       // entries in `order` (order == nullptr: groups 0..n_groups-1, filtered by `cls`)
   u32 win_bytes;      // LINEAR launches: octets of the window (dynamic LDS = win_bytes + 2*K2_TOKBUF)
+  u32 cls;            // with order == nullptr: 1 = only groups that fit the linear window, 2 = only the others
 };
 
 // A group whose whole output fits the LDS window needs no ring: LINEAR = true keeps every octet of
@@ -2008,7 +2014,11 @@ template <bool LINEAR>
 TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks) {
   const u32 lane = tbz_lane();
   const u64 lane_bit = 1ull << lane;
-  const Group g = P.groups[P.order[tbz_block()]];
+  const Group g = P.groups[P.order ? P.order[tbz_block()] : tbz_block()];
+  if (!P.order && P.cls) {  // device-built tables (K3): one segment per group, sorted into launches by size here
+    const bool small = P.segs[g.seg_first].out_bytes + K2_SLACK <= K2_SMALL_MAX;
+    if ((P.cls == 1) != small) return;
+  }
   u8* outp = P.out_base + g.out_abs;
   const u32 a0 = (u32)((uintptr_t)outp & 15);
   const u64 clip = g.out_end > g.out_abs ? g.out_end - g.out_abs : 0;
@@ -2161,6 +2171,185 @@ TBZ_KERNEL void tbz_k2_lz77_small(K2Params P) {
   TBZ_DYN_SHARED(u8, dyn);
   if (tbz_block() >= P.n_groups) return;
   k2_body<true>(P, dyn, (u16*)(dyn + P.win_bytes));
+}
+
+// ================================================================================================
+// K3 — layout on the device for the common case.  After K1 the host must chain the items of each
+// stream (did item k land exactly on item k+1?), lay the segments out in the output and describe
+// the work to K2.  When every item of every stream simply LANDED on its successor, the last one
+// decoded the final block and no match reaches behind its own segment, that chain is the identity:
+// these kernels prove it, scan the segment sizes and write K2's Seg/Group tables themselves, so
+// the host reads back one small record per stream instead of walking 64 bytes per segment.
+// Anything else (false markers, repairs, sync-flush history, errors, underrun) -> glob.not_simple
+// and the host's general path decides.
+// ================================================================================================
+constexpr u32 K3_TILE = 1024;  // items per workgroup
+struct K3Stream {              // per stream, written by the device
+  u64 total_out, tok_words, nonempty;
+  SegResult last;              // result of the stream's last item (trailer, end position)
+};
+struct K3Global {
+  u32 not_simple, n_big;
+  u64 max_small;               // largest group that fits the linear K2 window
+};
+struct K3Params {
+  const Item* items;
+  const SegResult* res;
+  const u32* first_item;       // per stream
+  const u32* n_items_s;
+  const u64* out_off;
+  const u64* out_cap;
+  u64* tile_sums;              // [3][n_tiles + 1]: out_bytes, tok_words, nonempty; scanned in place
+  u64* tile_flags;             // [3][n_tiles]: not_simple, n_big, max_small
+  u64* gscan;                  // [n_items]: exclusive scan of out_bytes over ALL items
+  u32* gne;                    // [n_items]: exclusive scan of the non-empty flags
+  Seg* segs;
+  Group* groups;
+  K3Stream* streams;
+  K3Global* glob;
+  u32 n_items, n_tiles, n_streams;
+};
+
+TBZ_KERNEL void tbz_k3_tile_sums(K3Params P) {
+  const u32 lane = tbz_lane(), t = tbz_block();
+  u64 so = 0, sw = 0, sn = 0, bad = 0, nbig = 0, mx = 0;
+  for (u32 it = 0; it < K3_TILE / 64; it++) {
+    const u32 i = t * K3_TILE + it * 64 + lane;
+    if (i >= P.n_items) continue;
+    const SegResult q = P.res[i];
+    const u32 s = P.items[i].stream;
+    const bool last = i - P.first_item[s] == P.n_items_s[s] - 1;
+    const bool ok = q.status == (last ? SEG_FINAL : SEG_LANDED) && q.max_deficit == 0;
+    bad |= ok ? 0u : 1u;
+    so += q.out_bytes;
+    sw += q.tok_words;
+    sn += (q.out_bytes | q.tok_words) ? 1u : 0u;
+    const bool big = q.out_bytes + K2_SLACK > K2_SMALL_MAX;
+    nbig += big ? 1u : 0u;
+    mx = !big && q.out_bytes > mx ? q.out_bytes : mx;
+  }
+  so = wave_sum_u64(so);
+  sw = wave_sum_u64(sw);
+  sn = wave_sum_u64(sn);
+  bad = wave_sum_u64(bad);
+  nbig = wave_sum_u64(nbig);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const u64 o = tbz_shfl_xor64(mx, m);
+    mx = o > mx ? o : mx;
+  }
+  if (lane == 0) {
+    const u32 T1 = P.n_tiles + 1;
+    P.tile_sums[t] = so;
+    P.tile_sums[T1 + t] = sw;
+    P.tile_sums[2 * T1 + t] = sn;
+    P.tile_flags[t] = bad;
+    P.tile_flags[P.n_tiles + t] = nbig;
+    P.tile_flags[2 * P.n_tiles + t] = mx;
+  }
+}
+
+// single wave: exclusive scan of the tile sums, reduction of the flags
+TBZ_KERNEL void tbz_k3_scan_tiles(K3Params P) {
+  const u32 lane = tbz_lane();
+  const u32 T1 = P.n_tiles + 1;
+  for (u32 c = 0; c < 3; c++) {
+    u64 carry = 0;
+    for (u32 i = 0; i < P.n_tiles; i += 64) {
+      const u64 v = (i + lane) < P.n_tiles ? P.tile_sums[c * T1 + i + lane] : 0;
+      const u64 inc = wave_incl_scan_u64(v);
+      if ((i + lane) < P.n_tiles) P.tile_sums[c * T1 + i + lane] = carry + inc - v;
+      carry += tbz_shfl64(inc, 63);
+    }
+    if (lane == 0) P.tile_sums[c * T1 + P.n_tiles] = carry;
+  }
+  u64 bad = 0, nbig = 0, mx = 0;
+  for (u32 i = lane; i < P.n_tiles; i += 64) {
+    bad += P.tile_flags[i];
+    nbig += P.tile_flags[P.n_tiles + i];
+    const u64 m = P.tile_flags[2 * P.n_tiles + i];
+    mx = m > mx ? m : mx;
+  }
+  bad = wave_sum_u64(bad);
+  nbig = wave_sum_u64(nbig);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const u64 o = tbz_shfl_xor64(mx, m);
+    mx = o > mx ? o : mx;
+  }
+  if (lane == 0) {
+    K3Global gl;
+    gl.not_simple = bad ? 1u : 0u;
+    gl.n_big = (u32)nbig;
+    gl.max_small = mx;
+    *P.glob = gl;
+  }
+}
+
+// exclusive scans of out_bytes and of the non-empty flags over all items (tile prefix + in-tile scan in item order)
+TBZ_KERNEL void tbz_k3_scan_items(K3Params P) {
+  const u32 lane = tbz_lane(), t = tbz_block();
+  u64 carry = P.tile_sums[t];
+  u32 carry_ne = (u32)P.tile_sums[2 * (P.n_tiles + 1) + t];
+  for (u32 it = 0; it < K3_TILE / 64; it++) {
+    const u32 i = t * K3_TILE + it * 64 + lane;
+    u64 v = 0;
+    u32 ne = 0;
+    if (i < P.n_items) {
+      const SegResult q = P.res[i];
+      v = q.out_bytes;
+      ne = (q.out_bytes | q.tok_words) ? 1u : 0u;
+    }
+    const u64 inc = wave_incl_scan_u64(v);
+    const u32 inc_ne = wave_incl_scan_u32(ne);
+    if (i < P.n_items) {
+      P.gscan[i] = carry + inc - v;
+      P.gne[i] = carry_ne + inc_ne - ne;
+    }
+    carry += tbz_shfl64(inc, 63);
+    carry_ne += tbz_shfl(inc_ne, 63);
+  }
+}
+
+// one Seg and one Group per item; the lane of a stream's last item writes the stream's record
+TBZ_KERNEL void tbz_k3_emit(K3Params P) {
+  const u32 lane = tbz_lane(), t = tbz_block();
+  const u32 T1 = P.n_tiles + 1;
+  for (u32 it = 0; it < K3_TILE / 64; it++) {
+    const u32 i = t * K3_TILE + it * 64 + lane;
+    if (i >= P.n_items) continue;
+    const SegResult q = P.res[i];
+    const Item im = P.items[i];
+    const u32 s = im.stream, f = P.first_item[s];
+    const u64 rel = P.gscan[i] - P.gscan[f];
+    Seg sg;
+    sg.tok_index = im.start_bit;
+    sg.tok_words = q.tok_words;
+    sg.out_bytes = q.out_bytes;
+    P.segs[i] = sg;
+    Group g;
+    g.out_abs = P.out_off[s] + rel;
+    g.out_end = P.out_off[s] + P.out_cap[s];
+    g.seg_first = i;
+    g.seg_count = 1;
+    P.groups[i] = g;
+    if (i - f == P.n_items_s[s] - 1) {
+      K3Stream st;
+      st.total_out = rel + q.out_bytes;
+      st.tok_words = 0;   // token words are only totalled for the whole call (below)
+      st.nonempty = P.gne[i] - P.gne[f] + ((q.out_bytes | q.tok_words) ? 1u : 0u);
+      st.last = q;
+      P.streams[s] = st;
+    }
+  }
+  if (t == 0 && lane == 0) {  // whole-call totals ride in the slot after the last stream
+    K3Stream tot;
+    tot.total_out = P.tile_sums[P.n_tiles];
+    tot.tok_words = P.tile_sums[T1 + P.n_tiles];
+    tot.nonempty = P.tile_sums[2 * T1 + P.n_tiles];
+    tot.last = SegResult{};
+    P.streams[P.n_streams] = tot;
+  }
 }
 
 // ================================================================================================

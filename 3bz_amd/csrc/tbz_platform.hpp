@@ -69,6 +69,15 @@ TBZ_DEV u32 tbz_brev32(u32 v) { return __brev(v); }
 TBZ_DEV u32 tbz_clz32(u32 v) { return (u32)__clz((int)v); }
 TBZ_DEV u32 tbz_atomic_add_lds(u32* p, u32 v) { return atomicAdd(p, v); }
 
+// four sums of absolute differences of the 4 octets `ref` against s0's octets [j, j+4), j = 0..3, as
+// 4 x u16 (v_qsad_pk_u16_u8): a zero field is an exact 4-octet match at offset j
+TBZ_DEV u64 tbz_qsad4(u64 s0, u32 ref) { return __builtin_amdgcn_qsad_pk_u16_u8(s0, ref, 0ull); }
+// per-halfword unsigned minimum (v_pk_min_u16)
+typedef unsigned short tbz_us2 __attribute__((ext_vector_type(2)));
+TBZ_DEV u32 tbz_pk_min_u16(u32 a, u32 b) {
+  tbz_us2 r = __builtin_elementwise_min(__builtin_bit_cast(tbz_us2, a), __builtin_bit_cast(tbz_us2, b));
+  return __builtin_bit_cast(u32, r);
+}
 // 32 bits of the 64-bit value hi:lo starting at bit o (o < 32): one v_alignbit_b32
 TBZ_DEV u32 tbz_alignbit(u32 hi, u32 lo, u32 o) { return __builtin_amdgcn_alignbit(hi, lo, o); }
 // n bits of v starting at bit off (n = 0 gives 0): one v_bfe_u32

@@ -240,6 +240,23 @@ TBZ_DEV u32 tbz_brev32(u32 v) {
 TBZ_DEV u32 tbz_clz32(u32 v) { return v ? (u32)__builtin_clz(v) : 32; }
 TBZ_DEV u32 tbz_atomic_add_lds(u32* p, u32 v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
+TBZ_DEV u64 tbz_qsad4(u64 s0, u32 ref) {
+  u64 r = 0;
+  for (int j = 0; j < 4; j++) {
+    u32 sad = 0;
+    for (int k = 0; k < 4; k++) {
+      int a = (int)((s0 >> (8 * (j + k))) & 0xff), b = (int)((ref >> (8 * k)) & 0xff);
+      sad += (u32)(a > b ? a - b : b - a);
+    }
+    r |= (u64)(sad & 0xffff) << (16 * j);
+  }
+  return r;
+}
+TBZ_DEV u32 tbz_pk_min_u16(u32 a, u32 b) {
+  u32 lo = (a & 0xffff) < (b & 0xffff) ? (a & 0xffff) : (b & 0xffff);
+  u32 hi = (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16);
+  return lo | (hi << 16);
+}
 TBZ_DEV u32 tbz_alignbit(u32 hi, u32 lo, u32 o) { return (u32)(((((u64)hi) << 32) | lo) >> (o & 31)); }
 TBZ_DEV u32 tbz_bfe(u32 v, u32 off, u32 n) { return n ? ((v >> (off & 31)) & (n >= 32 ? ~0u : ((1u << n) - 1))) : 0; }
 TBZ_DEV u32 tbz_readlane(u32 v, u32 i) { return (u32)tbz_emu::xchg(v, i); }
@@ -285,7 +302,7 @@ static inline hipError_t hipGetDeviceCount(int* n) {
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) {
-  *p = malloc(n ? n : 1);
+  *p = malloc(((n ? n : 1) + 31) & ~(size_t)15);  // device allocations are at least 16-octet granular
   return *p ? hipSuccess : hipErrorOutOfMemory;
 }
 static inline hipError_t hipFree(void* p) {
@@ -318,6 +335,15 @@ static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
   e->t = std::chrono::steady_clock::now();
   return hipSuccess;
 }
+static inline hipError_t hipHostMalloc(void** p, size_t n) {
+  *p = malloc(n ? n : 1);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+static inline hipError_t hipHostFree(void* p) {
+  free(p);
+  return hipSuccess;
+}
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
   *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
   return hipSuccess;

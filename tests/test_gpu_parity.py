@@ -13,16 +13,19 @@ from tools import corpus as K
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["auto", "gang8", "gang32", "lane"])
+@pytest.fixture(scope="module", params=["auto", "hostlayout", "gang8", "gang32", "lane"])
 def eng(request):
     """auto picks wide gangs (32/64 lanes per item) for these sizes; the other K1 flavours are forced through TBZ_K1_MODE"""
     T = importlib.import_module("3bz_amd")
     path = T._lib.default_path()
     assert os.path.exists(path), "lib3bz_amd.so missing: run __graft_entry__.build() (no CPU fallback exists)"
-    if request.param != "auto":
+    if request.param == "hostlayout":  # chain walk + layout on the host even when the device could do it (K3)
+        os.environ["TBZ_HOST_LAYOUT"] = "1"
+    elif request.param != "auto":
         os.environ["TBZ_K1_MODE"] = request.param
     e = T.Engine(0)
     os.environ.pop("TBZ_K1_MODE", None)
+    os.environ.pop("TBZ_HOST_LAYOUT", None)
     yield e
     e.close()
 

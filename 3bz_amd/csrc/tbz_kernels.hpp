@@ -55,6 +55,17 @@ TBZ_DEV u32 wave_xor_u32(u32 v) {
   return v;
 }
 
+// LDS accepts any octet address for 2/4/8/16-octet accesses on gfx950
+struct __attribute__((packed, aligned(1))) K2U128 { u64 lo, hi; };
+struct __attribute__((packed, aligned(1))) K2U64 { u64 v; };
+struct __attribute__((packed, aligned(1))) K2U32 { u32 v; };
+struct __attribute__((packed, aligned(1))) K2U16 { u16 v; };
+TBZ_DEV u64 k2_ld64(const u8* p) { return ((const K2U64*)p)->v; }
+TBZ_DEV u32 k2_ld32(const u8* p) { return ((const K2U32*)p)->v; }
+TBZ_DEV void k2_st64(u8* p, u64 v) { ((K2U64*)p)->v = v; }
+TBZ_DEV void k2_st32(u8* p, u32 v) { ((K2U32*)p)->v = v; }
+TBZ_DEV void k2_st16(u8* p, u32 v) { ((K2U16*)p)->v = (u16)v; }
+
 // 4 octets at byte index `idx` of a 4-byte aligned word array, never touching a word at or beyond
 // `nwords` (words past the end read as 0)
 TBZ_DEV u32 load_u32_unaligned(const u32* TBZ_RESTRICT w, u64 idx, u64 nwords) {
@@ -1207,6 +1218,70 @@ TBZ_DEV i32 kg_dynamic_header(GangTables& gt, GangState& gs, K1State& st) {
   }
   const u32 n = hlit + hdist;
   u32 i = 0, last = 0xff;
+  {
+    // Fast pass: the same decode on 32-bit window state (as the token loop), repeats stored eight at a
+    // time, no per-symbol position checks.  Anything unusual — unassigned pattern, a repeat error,
+    // running past the end / the limit — abandons it, and the exact loop below redoes the header.
+    const BitReader save = st.br;
+    const u32 lane = tbz_lane();
+    const u64 lim64 = st.end_bit < st.limit_bit ? st.end_bit : st.limit_bit;
+    BitReader& B = st.br;
+    bool slow = false;
+    while (i < n && !slow) {
+      br_refill(B);
+      u32 lo = B.lo, hi = B.hi, nx = B.nx, o = B.o, k = 3, rel = 0;
+      i32 rem = lim64 <= B.pos ? 0 : ((lim64 - B.pos) > 0x7fffff00ull ? 0x7fffff00 : (i32)(lim64 - B.pos));
+      const u32* wp = &B.buf[3][lane];
+      while (i < n && k + 1 <= K1_INBUF) {
+        const u32 x1 = wp[0];
+        const u32 pk = tbz_alignbit(hi, lo, o);
+        const u32 e = cl[pk & 127];
+        const u32 L = e & 7, sym = e >> 3;
+        const u32 xb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
+        const u32 x = tbz_bfe(pk, L, xb), nb = L + xb;
+        if (L == 0 || rem < (i32)nb) {
+          slow = true;
+          break;
+        }
+        if (sym < 16) {
+          lens[i++] = (u8)sym;
+          last = sym;
+        } else {
+          const u32 rep = (sym == 18 ? 11u : 3u) + x;
+          const u32 val = sym == 16 ? last : 0u;
+          if ((sym == 16 && last >= 16) || i + rep > n) {
+            slow = true;
+            break;
+          }
+          const u64 v8 = (u64)val * 0x0101010101010101ull;
+          for (u32 q = 0; q < rep; q += 8) k2_st64(lens + i + q, v8);  // spills <= 7 octets into entries not yet written
+          i += rep;
+          last = val;
+        }
+        rem -= (i32)nb;
+        rel += nb;
+        o += nb;
+        const bool adv = o >= 32;
+        o &= 31;
+        lo = adv ? hi : lo;
+        hi = adv ? nx : hi;
+        nx = adv ? x1 : nx;
+        k += adv ? 1u : 0u;
+        wp += adv ? 64 : 0;
+      }
+      B.pos += rel;
+      B.wi += k - 3;
+      B.lo = lo;
+      B.hi = hi;
+      B.nx = nx;
+      B.o = o;
+    }
+    if (slow) {
+      st.br = save;
+      i = 0;
+      last = 0xff;
+    }
+  }
   while (i < n) {
     br_ensure(st.br);
     const u64 ps = st.br.pos;
@@ -1310,14 +1385,21 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, u
       const u32 DX = ds < 4 ? 0u : de - 1;
       const u32 dbase = ds < 4 ? ds + 1 : 1 + ((2 + (ds & 1)) << ((de - 1) & 15));
       const u32 dist = dbase + tbz_bfe(pd, DL, DX);
-      const u32 nbits = isM ? n1 + DL + DX : L;
+      const u32 nb1 = isM ? n1 + DL + DX : L;
       const bool okm = (DL != 0) & (ds < 30), okl = e < 0x1000u;
-      const i32 rem2 = rem - (i32)nbits;
-      const bool good = (L != 0) & (isM ? okm : okl) & (rem2 >= 0);
+      const i32 rem1 = rem - (i32)nb1;
+      const bool good = (L != 0) & (isM ? okm : okl) & (rem1 >= 0);
       if (!good) {
         bad = true;
         break;
       }
+      // a second literal rides along when the code after a literal is a first-level literal too (it must
+      // start before the target and end inside the limit): literal-dense sub-ranges are the slow lanes
+      const u32 e2 = gt.lfast[(pk >> L) & ((1u << KG_TBL) - 1)];
+      const u32 L2 = e2 & 15;
+      const bool pair = !isM & (L2 != 0) & (e2 < 0x1000u) & (rel + L < tgt) & (rem1 >= (i32)L2);
+      const u32 nbits = nb1 + (pair ? L2 : 0u);
+      const i32 rem2 = rem - (i32)nbits;
       rem = rem2;
       rel += nbits;
       o += nbits;  // < 96: the window advances by up to two words
@@ -1332,14 +1414,15 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, u
       k += adv;
       wp += adv * 64;
       if (REC) {
-        // literal: 0x00bb (the high half is overwritten by the next token); match: head | payload << 16
+        // literal: 0x00bb (the high half is the second literal of a pair, or overwritten by the next token);
+        // match: head | payload << 16
 #if KG_EXP != 4
-        ((U32at2*)(stage + n))->v = isM ? (TOK_MATCH | lenx | ((dist - 1) << 16)) : lenx;
+        ((U32at2*)(stage + n))->v = isM ? (TOK_MATCH | lenx | ((dist - 1) << 16)) : (lenx | (((e2 >> 4) & 0xffu) << 16));
 #endif
         const i32 d = (i32)dist - (i32)out;
         mdef = isM & (d > mdef) ? d : mdef;
-        n += isM ? 2u : 1u;
-        out += isM ? lenx + 3 : 1u;
+        n += (isM | pair) ? 2u : 1u;
+        out += isM ? lenx + 3 : (pair ? 2u : 1u);
       }
       it++;
       go = (it < K1_PHASE) & (k + 2 <= K1_INBUF) & (rel < tgt);
@@ -1866,16 +1949,6 @@ constexpr u32 K2_TOKBUF = 2 * K2_TCH;  // LDS token ring: the chunk in use + the
 constexpr u32 K2_SLACK = 64;    // window octets past a group's output: alignment (16) + room for wide reads
 constexpr u32 K2_SMALL_MAX = 32768;  // groups producing at most this much (incl. K2_SLACK) take the linear path
 
-// LDS accepts any octet address for 2/4/8/16-octet accesses on gfx950
-struct __attribute__((packed, aligned(1))) K2U128 { u64 lo, hi; };
-struct __attribute__((packed, aligned(1))) K2U64 { u64 v; };
-struct __attribute__((packed, aligned(1))) K2U32 { u32 v; };
-struct __attribute__((packed, aligned(1))) K2U16 { u16 v; };
-TBZ_DEV u64 k2_ld64(const u8* p) { return ((const K2U64*)p)->v; }
-TBZ_DEV u32 k2_ld32(const u8* p) { return ((const K2U32*)p)->v; }
-TBZ_DEV void k2_st64(u8* p, u64 v) { ((K2U64*)p)->v = v; }
-TBZ_DEV void k2_st32(u8* p, u32 v) { ((K2U32*)p)->v = v; }
-TBZ_DEV void k2_st16(u8* p, u32 v) { ((K2U16*)p)->v = (u16)v; }
 
 struct K2Params {
   const u16* tok;

@@ -48,8 +48,8 @@ struct tbz_ctx {
   int k1_mode = 0;  // 0 auto, 1 lane-per-item, 4..64 gang of that many lanes (env TBZ_K1_MODE; tests force each)
   // device pools (grow-only)
   tbz::DevBuf d_str_off, d_str_len, d_tile_first, d_tile_counts, d_tile_offsets, d_markers, d_items, d_res,
-      d_tok, d_scratch, d_stage, d_segs, d_groups, d_order, d_k3_fi, d_k3_ni, d_k3_oo, d_k3_oc, d_k3_sums, d_k3_flags,
-      d_k3_gscan, d_k3_gne, d_k3_streams, d_k3_glob, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
+      d_tok, d_scratch, d_runs, d_segs, d_groups, d_order, d_k3_fi, d_k3_ni, d_k3_oo, d_k3_oc, d_k3_sums, d_k3_flags,
+      d_k3_gscan, d_k3_gne, d_k3_streams, d_k3_glob, d_redo_items, d_redo_res, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
       d_out_stage;
 };
 
@@ -308,6 +308,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   }
   // token pool: one u16 per input bit (K1 never writes more words than bits consumed)
   if ((r = ensure(ctx, ctx->d_tok, (size_t)in_extent * 16 + 64))) return r;
+  // run tables: one 8-byte slot per 2^RUN_SHIFT input bits, position-addressed like the token pool
+  if ((r = ensure(ctx, ctx->d_runs, (((size_t)in_extent * 8) >> RUN_SHIFT) * sizeof(RunRec) + 1024))) return r;
   if ((r = upload(ctx, ctx->d_items, items))) return r;
   if ((r = ensure(ctx, ctx->d_res, items.size() * sizeof(SegResult)))) return r;
   // K1 flavour.  One lane per item is bound by ONE item's serial chain (~1.1 us per token) and decodes
@@ -327,20 +329,43 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     while (ipw > 1 && n_it / ipw < 512) ipw >>= 1;
     return ipw;
   };
-  if ((r = ensure(ctx, ctx->d_scratch, items.size() * (size_t)K1_SCRATCH))) return r;
+  auto launch_lane = [&](const Item* d_items, SegResult* d_res, size_t n_it) -> int {
+    int rr = ensure(ctx, ctx->d_scratch, n_it * (size_t)K1_SCRATCH);
+    if (rr) return rr;
+    K1Params k1{(const u8*)d_in, (u16*)ctx->d_tok.p, d_items, d_res, (const u64*)ctx->d_markers.p,
+                (u8*)ctx->d_scratch.p, (RunRec*)ctx->d_runs.p, (u32)markers.size(), (u32)n_it, items_per_wg(n_it)};
+    TBZ_LAUNCH(tbz_k1_huff_decode, (n_it + k1.items_per_wg - 1) / k1.items_per_wg, ctx->stream, k1);
+    return 0;
+  };
+  // items the gang kernel declined (SEG_REDO: token stream as dense as the bitstream, run table full) are
+  // decoded again by the one-lane kernel, which writes one contiguous run
+  auto redo = [&](const std::vector<Item>& its, std::vector<SegResult>& rs) -> int {
+    std::vector<Item> sub;
+    std::vector<size_t> idx;
+    for (size_t i = 0; i < rs.size(); i++)
+      if (rs[i].status == SEG_REDO) {
+        sub.push_back(its[i]);
+        idx.push_back(i);
+      }
+    if (sub.empty()) return 0;
+    if (getenv("TBZ_DEBUG")) fprintf(stderr, "tbz: %zu item(s) redone by the one-lane kernel\n", sub.size());
+    int rr;
+    if ((rr = upload(ctx, ctx->d_redo_items, sub))) return rr;
+    if ((rr = ensure(ctx, ctx->d_redo_res, sub.size() * sizeof(SegResult)))) return rr;
+    if ((rr = launch_lane((const Item*)ctx->d_redo_items.p, (SegResult*)ctx->d_redo_res.p, sub.size()))) return rr;
+    std::vector<SegResult> tmp(sub.size());
+    TBZ_HIP(hipMemcpyAsync(tmp.data(), ctx->d_redo_res.p, tmp.size() * sizeof(SegResult), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    TBZ_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t k = 0; k < idx.size(); k++) rs[idx[k]] = tmp[k];
+    ctx->tim.huff_launches++;
+    return 0;
+  };
   auto launch_k1 = [&](const Item* d_items, SegResult* d_res, size_t n_it) -> int {
     int G = k1_gang(n_it);
-    if (G == 1) {
-      K1Params k1{(const u8*)d_in, (u16*)ctx->d_tok.p, d_items, d_res, (const u64*)ctx->d_markers.p,
-                  (u8*)ctx->d_scratch.p, (u32)markers.size(), (u32)n_it, items_per_wg(n_it)};
-      TBZ_LAUNCH(tbz_k1_huff_decode, (n_it + k1.items_per_wg - 1) / k1.items_per_wg, ctx->stream, k1);
-      return 0;
-    }
+    if (G == 1) return launch_lane(d_items, d_res, n_it);
     size_t per = 64 / G, nwg = (n_it + per - 1) / per;
-    // staging pool: addressed by bit position like the token pool
-    int rr = ensure(ctx, ctx->d_stage, (size_t)in_extent * 16 + (size_t)KG_STAGE_SLACK * 2);
-    if (rr) return rr;
-    K1gParams kg{(const u8*)d_in, (u16*)ctx->d_tok.p, (u16*)ctx->d_stage.p, d_items, d_res,
+    K1gParams kg{(const u8*)d_in, (u16*)ctx->d_tok.p, (RunRec*)ctx->d_runs.p, d_items, d_res,
                  (const u64*)ctx->d_markers.p, (u32)markers.size(), (u32)n_it};
     switch (G) {
       case 8: TBZ_LAUNCH(tbz_k1g8_huff_decode, nwg, ctx->stream, kg); break;
@@ -436,12 +461,12 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if (!size_only) {
       if (!d_out) return TBZ_E_ARG;
       const u32 n_it = (u32)items.size();
-      K2Params k2{(const u16*)ctx->d_tok.p, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, nullptr,
+      K2Params k2{(const u16*)ctx->d_tok.p, (const RunRec*)ctx->d_runs.p, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, nullptr,
                   (const u8*)d_in, (u8*)d_out, n_it, 0, 0};
       if (h_glob->n_big < n_it) {
         k2.win_bytes = (u32)((h_glob->max_small + K2_SLACK + 255) & ~255ull);
         k2.cls = h_glob->n_big ? 1 : 0;
-        TBZ_LAUNCH_DYN(tbz_k2_lz77_small, n_it, k2.win_bytes + 2 * K2_TOKBUF, ctx->stream, k2);
+        TBZ_LAUNCH_DYN(tbz_k2_lz77_small, n_it, k2.win_bytes + 2 * K2_TOKBUF + 512, ctx->stream, k2);
       }
       if (h_glob->n_big) {
         k2.win_bytes = 0;
@@ -475,6 +500,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
                          ctx->stream));
   TBZ_HIP(hipStreamSynchronize(ctx->stream));
   huff_ms = elapsed(ctx, 2, 3);
+  if ((r = redo(items, res))) return r;
 
   // ---------------------------------------------------------------- chain walk (+ fix-up rounds)
   std::vector<SegHost> segs;
@@ -485,6 +511,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     h.seg.tok_index = it.start_bit;
     h.seg.tok_words = q.tok_words;
     h.seg.out_bytes = q.out_bytes;
+    h.seg.n_runs = q.n_runs;
+    h.seg.pad = 0;
     h.stream = (uint32_t)s;
     h.deficit = q.max_deficit;
     h.continues = S.next_continues;
@@ -565,6 +593,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
                            ctx->stream));
     TBZ_HIP(hipStreamSynchronize(ctx->stream));
     huff_ms += elapsed(ctx, 2, 3);
+    if ((r = redo(fix, fr))) return r;
     for (size_t k = 0; k < fix.size(); k++) {
       size_t s = fix_stream[k];
       StreamPlan& S = sp[s];
@@ -646,12 +675,12 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     std::vector<uint32_t> order(order_small);
     order.insert(order.end(), order_big.begin(), order_big.end());
     if ((r = upload(ctx, ctx->d_order, order))) return r;
-    K2Params k2{(const u16*)ctx->d_tok.p, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p,
+    K2Params k2{(const u16*)ctx->d_tok.p, (const RunRec*)ctx->d_runs.p, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p,
                 (const u32*)ctx->d_order.p, (const u8*)d_in, (u8*)d_out, 0, 0, 0};
     if (!order_small.empty()) {
       k2.n_groups = (u32)order_small.size();
       k2.win_bytes = (u32)((max_small + K2_SLACK + 255) & ~255ull);
-      TBZ_LAUNCH_DYN(tbz_k2_lz77_small, order_small.size(), k2.win_bytes + 2 * K2_TOKBUF, ctx->stream, k2);
+      TBZ_LAUNCH_DYN(tbz_k2_lz77_small, order_small.size(), k2.win_bytes + 2 * K2_TOKBUF + 512, ctx->stream, k2);
     }
     if (!order_big.empty()) {
       k2.order = (const u32*)ctx->d_order.p + order_small.size();
@@ -802,11 +831,11 @@ void tbz_ctx_destroy(tbz_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   tbz::DevBuf* bufs[] = {&ctx->d_str_off, &ctx->d_str_len, &ctx->d_tile_first, &ctx->d_tile_counts,
-                         &ctx->d_tile_offsets, &ctx->d_markers, &ctx->d_items, &ctx->d_res, &ctx->d_tok, &ctx->d_scratch, &ctx->d_stage, &ctx->d_order,
+                         &ctx->d_tile_offsets, &ctx->d_markers, &ctx->d_items, &ctx->d_res, &ctx->d_tok, &ctx->d_scratch, &ctx->d_runs, &ctx->d_order,
                          &ctx->d_segs, &ctx->d_groups, &ctx->d_ck_chunks, &ctx->d_ck_parts, &ctx->d_ck_streams,
                          &ctx->d_ck_out, &ctx->d_crc_tab, &ctx->d_in_stage, &ctx->d_out_stage, &ctx->d_k3_fi, &ctx->d_k3_ni,
                          &ctx->d_k3_oo, &ctx->d_k3_oc, &ctx->d_k3_sums, &ctx->d_k3_flags, &ctx->d_k3_gscan, &ctx->d_k3_gne,
-                         &ctx->d_k3_streams, &ctx->d_k3_glob};
+                         &ctx->d_k3_streams, &ctx->d_k3_glob, &ctx->d_redo_items, &ctx->d_redo_res};
   for (auto* b : bufs)
     if (b->p) hipFree(b->p);
   if (ctx->h_pin) hipHostFree(ctx->h_pin);

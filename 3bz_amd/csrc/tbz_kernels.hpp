@@ -223,8 +223,10 @@ TBZ_CONSTANT u8 c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3
 //   0x8000 | (len-3)            match head, followed by  (dist-1)            (bit 15 clear)
 //   0xC000 | (n & 0x3fff)       stored-run head: n octets copied verbatim from the input, followed by
 //                               (n>>14) | (src&0x1fff)<<2 , (src>>13)&0x7fff , (src>>28)&0x7fff
-// payload words always have bit 15 clear, so a word with bit 15 set is always a head.
-constexpr u32 TOK_MATCH = 0x8000u, TOK_STORED = 0xC000u;
+//   0x4000                      no-op (pads a run to a multiple of 8 words)
+// payload words always have bit 15 clear, so a word with bit 15 set is always a head; bit 14 of a word
+// that is not a payload word marks the no-op.
+constexpr u32 TOK_MATCH = 0x8000u, TOK_STORED = 0xC000u, TOK_NOP = 0x4000u;
 
 constexpr u32 K1_SCRATCH = 512;   // octets of global scratch per item: lens[320] (code lengths while a header is parsed)
 constexpr u32 K1_SC_LENS = 0;
@@ -254,6 +256,7 @@ struct K1Params {
   SegResult* res;
   const u64* markers;
   u8* scratch;    // n_items * K1_SCRATCH octets
+  RunRec* runs;   // run tables (one run per item here: the lane writes its tokens contiguously)
   u32 n_markers;
   u32 n_items;
   u32 items_per_wg;  // 1..64: lanes >= items_per_wg idle (used to spread few large items over all CUs)
@@ -866,15 +869,29 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
   }
 
   SegResult r;
+  u64 TW;
   if (status == SEG_OVERSHOOT) {
     r.end_bit = blk_pos;
     r.out_bytes = blk_prod;
-    r.tok_words = blk_tok;
+    TW = blk_tok;
   } else {
     r.end_bit = (status == SEG_UNDERRUN) ? st.fail_pos : st.br.pos;
     r.out_bytes = st.produced;
-    r.tok_words = (u64)(st.tok - st.tok0);
+    TW = (u64)(st.tok - st.tok0);
   }
+  // one run: pad it to the 8-word granule (the padding stays inside the item's own token region: an
+  // item consumes at least 7 bits more than it has token words)
+  const u64 T8 = (TW + 7) >> 3;
+  for (u64 k = TW; k < T8 * 8; k++) st.tok0[k] = (u16)TOK_NOP;
+  if (T8) {
+    RunRec rr;
+    rr.off8 = 0;
+    rr.n8 = (u32)T8;
+    P.runs[it.start_bit >> RUN_SHIFT] = rr;
+  }
+  r.tok_words = T8 * 8;
+  r.n_runs = T8 ? 1u : 0u;
+  r.pad = 0;
   r.status = status;
   r.max_deficit = st.deficit;
   r.trailer0 = tr0;
@@ -923,7 +940,6 @@ constexpr u32 KG_SUB_MAX = 8192;
 #define KG_OVL_BITS 512
 #endif
 constexpr u32 KG_OVL = KG_OVL_BITS;             // run-up bits before a lane's sub-range
-constexpr u32 KG_STAGE_SLACK = 16384;   // words of slack at the end of the staging pool
 
 // lookup entries (u16).  bits 0-3: code length; 0 = not a symbol:
 //     whole entry 0          unassigned pattern, or a long code without a second-level table -> exact step
@@ -953,9 +969,10 @@ struct GangState {  // per gang, in LDS; owned by the leader
   u64 fail_pos;
   i32 status;
   u32 mode, bfinal, deficit, tables, land, tr0, tr1, tr_have;
+  u32 nruns, blk_runs;      // runs recorded so far / at the start of the current block
   u32 hlit, hdist, fixed;   // GM_BUILD: alphabet sizes; fixed: the lanes write the fixed code lengths first
   u32 rounds, valid_lanes;  // diagnostics: rounds run and lanes committed (efficiency = valid_lanes / (G*rounds))
-  u32 pad;
+  u32 pad[3];
 };
 template <int G>
 struct KgLds {
@@ -966,8 +983,8 @@ struct KgLds {
 
 struct K1gParams {
   const u8* in_base;
-  u16* tok;       // final token pool (as K1Params::tok)
-  u16* stage;     // staging pool, addressed by bit position like the token pool (+ KG_STAGE_SLACK words)
+  u16* tok;       // token pool (as K1Params::tok): lane g of a round writes its run at tok[s_g & ~7 ...]
+  RunRec* runs;   // run tables
   const Item* items;
   SegResult* res;
   const u64* markers;
@@ -1568,6 +1585,13 @@ TBZ_DEV void kg_lane_round(const GangTables& gt, BitReader& B, u64 start, u64 re
   ro.mdef = mdef;
 }
 
+// run-table slots an item may use once it has consumed the bitstream up to `upto`: the table is
+// position-addressed, so it must not grow into the slots of whatever starts after it
+TBZ_DEV u32 kg_run_slots(const Item& it, u64 upto) {
+  const u64 s = (upto - it.start_bit) >> RUN_SHIFT;
+  return s < 1 ? 1u : (s > 0x7fffffffull ? 0x7fffffffu : (u32)s);
+}
+
 // leader: what follows a block (deflate.lisp:719-722 + the container trailers + landing rules)
 TBZ_DEV void kg_block_end(GangState& gs, K1State& st, const Item& it, const K1gParams& P, u32 fmt, bool fixup) {
   if (gs.bfinal) {
@@ -1630,6 +1654,7 @@ TBZ_DEV void kg_leader_header(GangTables& gt, GangState& gs, K1State& st, const 
   gs.blk_pos = gs.P;
   gs.blk_prod = gs.produced;
   gs.blk_tok = gs.T;
+  gs.blk_runs = gs.nruns;
   u32 pk = br_peek(st.br);
   br_skip(st.br, 3);
   if (st.br.pos > st.end_bit) { gs.fail_pos = gs.blk_pos; gs.status = SEG_UNDERRUN; gs.mode = GM_DONE; return; }
@@ -1649,12 +1674,22 @@ TBZ_DEV void kg_leader_header(GangTables& gt, GangState& gs, K1State& st, const 
     u64 avail = it.end_byte - byte0;
     u32 ncopy = avail < LEN ? (u32)avail : LEN;
     if (ncopy) {
-      u16* t = tok0 + gs.T;
+      // a run of its own: one 8-word piece at the first granule at or after the block header (the block
+      // is at least 35 bits long, so the piece ends before anything that follows can start)
+      const u64 x = ((gs.blk_pos - it.start_bit) + 7) & ~7ull;
+      if (gs.nruns + 1 > kg_run_slots(it, byte0 * 8)) { gs.status = SEG_REDO; gs.mode = GM_DONE; return; }
+      u16* t = tok0 + x;
       t[0] = (u16)(TOK_STORED | (ncopy & 0x3fff));
       t[1] = (u16)((ncopy >> 14) | ((u32)(byte0 & 0x1fff) << 2));
       t[2] = (u16)((byte0 >> 13) & 0x7fff);
       t[3] = (u16)((byte0 >> 28) & 0x7fff);
-      gs.T += 4;
+      t[4] = t[5] = t[6] = t[7] = (u16)TOK_NOP;
+      RunRec rr;
+      rr.off8 = (u32)(x >> 3);
+      rr.n8 = 1;
+      (P.runs + (it.start_bit >> RUN_SHIFT))[gs.nruns] = rr;
+      gs.nruns += 1;
+      gs.T += 8;
       gs.produced += ncopy;
     }
     if (ncopy < LEN) { gs.fail_pos = (byte0 + ncopy) * 8; gs.status = SEG_UNDERRUN; gs.mode = GM_DONE; return; }
@@ -1731,6 +1766,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     gs.land = 0xFFFFFFFFu;
     gs.tr0 = gs.tr1 = gs.tr_have = 0;
     gs.hlit = gs.hdist = gs.fixed = 0;
+    gs.nruns = gs.blk_runs = 0;
     gs.rounds = gs.valid_lanes = 0;
     if (have && (it.flags & ITEM_HEAD)) {
       br_seek_fill(st.br, it.start_bit);
@@ -1790,7 +1826,8 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     ro.out = 0;
     ro.mdef = -(1 << 30);
     ro.flag = RF_JUNK;
-    u16* stage = P.stage;
+    u16* stage = P.tok;
+    u64 s_lo = 0;  // token-pool index of this lane's region
     if (inblk) {
       // sub-range per lane: what is left of the item split evenly (the next marker is where it should end)
       const u64 remb = lim64 > Pb ? lim64 - Pb : 0;
@@ -1800,8 +1837,9 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
       sub = sub < KG_SUB_MIN ? KG_SUB_MIN : sub;
       const u64 s_g = Pb + (u64)g * sub;
       const u64 start = g == 0 ? Pb : s_g - KG_OVL;
-      stage = P.stage + (s_g & ~7ull);  // private region [s_g, s_g + sub), 16-octet aligned for the commit copy
-      kg_lane_round(gt, st.br, start, s_g, s_g + sub, lim64, stage, sub - 8, ro);
+      s_lo = s_g & ~7ull;
+      stage = P.tok + s_lo;  // private region of the token pool: [s_g & ~7, (s_g + sub) & ~7), 16-octet aligned
+      kg_lane_round(gt, st.br, start, s_g, s_g + sub, lim64, stage, sub - 16, ro);
     }
     // ---- chain validation: lane g counts iff it began recording exactly where lane g-1 stopped
     const u32 pe_lo = tbz_wave_shr1((u32)ro.e), pe_hi = tbz_wave_shr1((u32)(ro.e >> 32));
@@ -1813,43 +1851,34 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     const u64 gm = (okm >> base) & GMASK;
     const u32 v = gm == GMASK ? (u32)G : (u32)__builtin_ctzll(~gm);  // valid lanes of my gang
     const bool valid = g < v;
-    const u32 nn = valid ? ro.n : 0, oo = valid ? ro.out : 0;
-    const u32 in_n = tbz_wave_incl_scan_u32(nn), in_o = tbz_wave_incl_scan_u32(oo);
-    const u32 bn = tbz_shfl(in_n, base ? (int)base - 1 : 0), bo = tbz_shfl(in_o, base ? (int)base - 1 : 0);
-    const u32 base_n = base ? bn : 0, base_o = base ? bo : 0;
-    const u32 D = in_n - nn - base_n, PO = in_o - oo - base_o;
+    // ---- commit: nothing is copied.  A valid lane's tokens stay where it staged them; it pads them to
+    // the 8-word granule and enters them in the item's run table, which is what K2 follows.
+    const u32 n8 = (ro.n + 7) >> 3;
+    const bool hasrun = valid && ro.n != 0;
+    const u32 nn = hasrun ? n8 * 8 : 0, oo = valid ? ro.out : 0, hr = hasrun ? 1u : 0u;
+    const u32 in_n = tbz_wave_incl_scan_u32(nn), in_o = tbz_wave_incl_scan_u32(oo), in_r = tbz_wave_incl_scan_u32(hr);
+    const int below = base ? (int)base - 1 : 0;
+    const u32 bn = tbz_shfl(in_n, below), bo = tbz_shfl(in_o, below), br_ = tbz_shfl(in_r, below);
+    const u32 base_n = base ? bn : 0, base_o = base ? bo : 0, base_r = base ? br_ : 0;
+    const u32 PO = in_o - oo - base_o, rank = in_r - hr - base_r;
     const u32 tot_n = tbz_shfl(in_n, (int)(base + G - 1)) - base_n;
     const u32 tot_o = tbz_shfl(in_o, (int)(base + G - 1)) - base_o;
-    // ---- commit: compact the valid runs into the item's contiguous token stream
-#if KG_EXP == 1
-    if (false) {
-#else
-    if (valid) {
-#endif
-      // 16-octet chunks, four loads in flight before their stores (an element-wise loop would be one
-      // memory round trip per token: the compiler must assume dst may alias stage)
-      u16* dst16 = tok0 + gs.T + D;
-      U16x8* dst = (U16x8*)dst16;
-      const uint4* src = (const uint4*)stage;
-      const u32 nfull = ro.n >> 3;
-      for (u32 c0 = 0; c0 < nfull; c0 += 4) {
-        uint4 v0 = src[c0], v1, v2, v3;
-        if (c0 + 1 < nfull) v1 = src[c0 + 1];
-        if (c0 + 2 < nfull) v2 = src[c0 + 2];
-        if (c0 + 3 < nfull) v3 = src[c0 + 3];
-        dst[c0].v = v0;
-        if (c0 + 1 < nfull) dst[c0 + 1].v = v1;
-        if (c0 + 2 < nfull) dst[c0 + 2].v = v2;
-        if (c0 + 3 < nfull) dst[c0 + 3].v = v3;
-      }
-      const u32 rest = ro.n & 7;  // never write past the run: the next word belongs to the next lane's run
-      if (rest) {
-        uint4 t = src[nfull];
-        u32 w[4] = {t.x, t.y, t.z, t.w};
+    const u32 tot_r = tbz_shfl(in_r, (int)(base + G - 1)) - base_r;
+    const u32 lv = base + (v ? v - 1 : 0);
+    const u64 e_last = tbz_shfl64(ro.e, (int)lv), aux_last = tbz_shfl64(ro.aux, (int)lv);
+    const u32 flag_last = tbz_shfl(ro.flag, (int)lv);
+    // the last run must end before the granule in which the next thing (a round, a stored run) may start,
+    // and the table must not outgrow the item's span; else the item is left to the one-lane kernel
+    const u64 end_lv = tbz_shfl64(s_lo + nn, (int)lv);
+    const bool fits = !inblk || (end_lv <= (e_last & ~7ull) && gs.nruns + tot_r <= kg_run_slots(it, e_last));
+    if (hasrun && fits) {
 #pragma unroll
-        for (u32 k = 0; k < 7; k++)
-          if (k < rest) dst16[nfull * 8 + k] = (u16)(w[k >> 1] >> ((k & 1) * 16));
-      }
+      for (u32 k = 0; k < 7; k++)
+        if (ro.n + k < n8 * 8) stage[ro.n + k] = (u16)TOK_NOP;
+      RunRec rr;
+      rr.off8 = (u32)((s_lo - it.start_bit) >> 3);
+      rr.n8 = n8;
+      (P.runs + (it.start_bit >> RUN_SHIFT))[gs.nruns + rank] = rr;
     }
     // history check material: largest (distance - octets produced before the match) over the round
     u64 hb = gs.produced + PO;
@@ -1860,14 +1889,15 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
       i32 t = (i32)tbz_shfl_xor((u32)cand, m);
       cand = t > cand ? t : cand;
     }
-    const u32 lv = base + (v ? v - 1 : 0);
-    const u64 e_last = tbz_shfl64(ro.e, (int)lv), aux_last = tbz_shfl64(ro.aux, (int)lv);
-    const u32 flag_last = tbz_shfl(ro.flag, (int)lv);
     tbz_sync();
-    if (leader && inblk) {
+    if (leader && inblk && !fits) {
+      gs.status = SEG_REDO;
+      gs.mode = GM_DONE;
+    } else if (leader && inblk) {
       gs.rounds += 1;
       gs.valid_lanes += v;
       gs.T += tot_n;
+      gs.nruns += tot_r;
       gs.produced += tot_o;
       if (cand > 0 && (u32)cand > gs.deficit) gs.deficit = (u32)cand;
       if (flag_last == RF_STOP) {
@@ -1901,11 +1931,14 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
       r.end_bit = gs.blk_pos;
       r.out_bytes = gs.blk_prod;
       r.tok_words = gs.blk_tok;
+      r.n_runs = gs.blk_runs;
     } else {
       r.end_bit = gs.status == SEG_UNDERRUN ? gs.fail_pos : gs.P;
       r.out_bytes = gs.produced;
       r.tok_words = gs.T;
+      r.n_runs = gs.nruns;
     }
+    r.pad = 0;
     r.status = gs.status;
     r.max_deficit = gs.deficit;
     r.trailer0 = gs.tr0;
@@ -1952,6 +1985,7 @@ constexpr u32 K2_SMALL_MAX = 32768;  // groups producing at most this much (incl
 
 struct K2Params {
   const u16* tok;
+  const RunRec* runs; // run tables (see RunRec)
   const Seg* segs;
   const Group* groups;
   const u32* order;   // group indices this launch handles
@@ -2084,7 +2118,7 @@ TBZ_DEV void k2_resolve(u8* win, u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist
 }
 
 template <bool LINEAR>
-TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks) {
+TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks, u32* rcache) {
   const u32 lane = tbz_lane();
   const u64 lane_bit = 1ull << lane;
   const Group g = P.groups[P.order ? P.order[tbz_block()] : tbz_block()];
@@ -2101,15 +2135,71 @@ TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks) {
   for (u32 s = 0; s < g.seg_count && pos < clip; s++) {
     const Seg sg = P.segs[g.seg_first + s];
     u64 p = 0;
-    // token ring: chunk c (words [c*K2_TCH, (c+1)*K2_TCH) of the segment) lives in ring half c & 1.  The
+    // The segment's token stream is the concatenation of its runs (8-word pieces).  Token ring: chunk c
+    // (logical words [c*K2_TCH, (c+1)*K2_TCH) = 64 pieces, one per lane) lives in ring half c & 1.  The
     // chunk after the one in use is already on its way in registers, so a batch never waits on memory
-    // except at the start of a segment.
-    const u16* tsrc = P.tok + sg.tok_index;
+    // except at the start of a segment.  A cache of 64 run records (inclusive piece counts rE, offsets rO,
+    // in LDS) maps logical pieces to addresses; it is re-based when a chunk reaches past it.
+    const u64 npieces = sg.tok_words >> 3;
+    const RunRec* rt = P.runs + (sg.tok_index >> RUN_SHIFT);
+    const u16* tbase = P.tok + sg.tok_index;
+    u32* rE = rcache;
+    u32* rO = rcache + 64;
+    u32 rbase = 0, ctot = 0;
+    u64 cbase = 0;
+    auto load_cache = [&]() {
+      RunRec rr;
+      rr.off8 = 0;
+      rr.n8 = 0;
+      if (rbase + lane < sg.n_runs) rr = rt[rbase + lane];
+      const u32 inc = tbz_wave_incl_scan_u32(rr.n8);
+      tbz_sync();
+      rE[lane] = inc;
+      rO[lane] = rr.off8;
+      tbz_sync();
+      ctot = tbz_shfl(inc, 63);
+    };
+    auto find_run = [&](u32 rel) -> u32 {  // first cached run whose inclusive end is beyond piece `rel`
+      u32 j = 0;
+#pragma unroll
+      for (u32 step = 32; step; step >>= 1) j += rE[j + step - 1] <= rel ? step : 0u;
+      return j;
+    };
+    auto cover = [&](u64 x0, u64 xl) {  // make the cache hold pieces x0..xl (a chunk: at most 64 pieces)
+      if (xl - cbase < ctot) return;
+      if (x0 - cbase < ctot) {
+        const u32 j0 = find_run((u32)(x0 - cbase));
+        cbase += j0 ? rE[j0 - 1] : 0u;
+        rbase += j0;
+      } else {
+        cbase += ctot;
+        rbase += 64;
+      }
+      load_cache();
+    };
+    auto fetch = [&](u32 c) -> uint4 {  // this lane's piece of chunk c
+      uint4 v{};
+      const u64 x0 = (u64)c * 64;
+      if (x0 >= npieces) return v;
+      const u64 xl = x0 + 63 < npieces ? x0 + 63 : npieces - 1;
+      cover(x0, xl);
+      const u64 x = x0 + lane;
+      if (x < npieces) {
+        const u32 rel = (u32)(x - cbase);
+        const u32 j = find_run(rel);
+        const u32 before = j ? rE[j - 1] : 0u;
+        v = *(const uint4*)(tbase + ((u64)rO[j] + (rel - before)) * 8);
+      }
+      return v;
+    };
     u32 cur = 0;
-    uint4 pre{};
-    tbz_sync();
-    if ((u64)lane * 8 < sg.tok_words) *(uint4*)(tks + lane * 8) = ((const U16x8*)(tsrc + lane * 8))->v;
-    if ((u64)K2_TCH + lane * 8 < sg.tok_words) pre = ((const U16x8*)(tsrc + K2_TCH + lane * 8))->v;
+    load_cache();
+    {
+      const uint4 v0 = fetch(0);
+      tbz_sync();
+      *(uint4*)(tks + lane * 8) = v0;
+    }
+    uint4 pre = fetch(1);
     tbz_sync();
     while (p < sg.tok_words && pos < clip) {
       const u64 left = sg.tok_words - p;
@@ -2118,8 +2208,7 @@ TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks) {
         cur += 1;
         tbz_sync();
         *(uint4*)(tks + (cur & 1) * K2_TCH + lane * 8) = pre;
-        const u64 nx0 = (u64)(cur + 1) * K2_TCH + lane * 8;
-        if (nx0 < sg.tok_words) pre = ((const U16x8*)(tsrc + nx0))->v;
+        pre = fetch(cur + 1);
         tbz_sync();
       }
       // ---- two words per lane: words 2*lane and 2*lane+1 of the batch
@@ -2133,7 +2222,7 @@ TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks) {
         const bool hav = ha && vb;                 // head with its distance word inside the batch
         const bool hbv = hb && 2 * lane + 2 < n2;
         const bool pa = tbz_wave_shr1(hb ? 1u : 0u) != 0;  // word a is the previous lane's distance word
-        const bool la = va && !ha && !pa, lb = vb && !hb && !ha;
+        const bool la = va && !ha && !pa && !(a & TOK_NOP), lb = vb && !hb && !ha && !(b & TOK_NOP);  // no-ops count for nothing
         const u32 len_a = hav ? (a & 0xff) + 3 : (la ? 1u : 0u);
         const u32 len_b = hbv ? (b & 0xff) + 3 : (lb ? 1u : 0u);
         const u32 sum = len_a + len_b;
@@ -2202,8 +2291,9 @@ TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks) {
         const u64 veff = n_eff == 64 ? ~0ull : ((1ull << n_eff) - 1);
         mb &= veff;
         u64 pm = (mb << 1);               // payload (distance) words
-        u64 lits = veff & ~mb & ~pm;
-        u64 cut_ok = (lits | pm) & veff;  // a batch may end after a literal or after a distance word
+        u64 nops = tbz_ballot((w & 0xC000u) == TOK_NOP) & veff & ~pm;
+        u64 lits = veff & ~mb & ~pm & ~nops;
+        u64 cut_ok = (lits | pm | nops) & veff;  // a batch may end after a literal, a no-op or a distance word
         bool head = (mb & lane_bit) != 0, islit = (lits & lane_bit) != 0;
         u32 len = head ? (w & 0xff) + 3 : (islit ? 1u : 0u);
         u32 incl = tbz_wave_incl_scan_u32(len);
@@ -2235,15 +2325,16 @@ TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks) {
 TBZ_KERNEL void tbz_k2_lz77(K2Params P) {
   TBZ_SHARED __attribute__((aligned(16))) u8 win[K2_WIN];
   TBZ_SHARED __attribute__((aligned(16))) u16 tks[K2_TOKBUF];
+  TBZ_SHARED u32 rcache[128];
   if (tbz_block() >= P.n_groups) return;
-  k2_body<false>(P, win, tks);
+  k2_body<false>(P, win, tks, rcache);
 }
 
 // groups whose output (plus 16 octets of alignment slack) fits P.win_bytes
 TBZ_KERNEL void tbz_k2_lz77_small(K2Params P) {
   TBZ_DYN_SHARED(u8, dyn);
   if (tbz_block() >= P.n_groups) return;
-  k2_body<true>(P, dyn, (u16*)(dyn + P.win_bytes));
+  k2_body<true>(P, dyn, (u16*)(dyn + P.win_bytes), (u32*)(dyn + P.win_bytes + 2 * K2_TOKBUF));
 }
 
 // ================================================================================================
@@ -2399,6 +2490,8 @@ TBZ_KERNEL void tbz_k3_emit(K3Params P) {
     sg.tok_index = im.start_bit;
     sg.tok_words = q.tok_words;
     sg.out_bytes = q.out_bytes;
+    sg.n_runs = q.n_runs;
+    sg.pad = 0;
     P.segs[i] = sg;
     Group g;
     g.out_abs = P.out_off[s] + rel;

@@ -11,6 +11,7 @@
 //   group    consecutive segments of one stream that must share one LZ77 window (the first needs no
 //            history; the rest reach back into their predecessors)
 //   token    u16 word: literal (0x00bb), or match head (0x8000 | len-3) followed by (dist-1)
+//   run      a contiguous piece of an item's token stream (one lane's share of a K1g round), 8-word granular
 #pragma once
 #include <cstdint>
 
@@ -28,7 +29,9 @@ enum : int32_t {
   SEG_LANDED = 1,     // ended a block exactly on a marker (index in land_marker)
   SEG_FINAL = 2,      // decoded the BFINAL block (trailer fields valid)
   SEG_OVERSHOOT = 3,  // crossed limit_bit mid-block: resume from end_bit (= start of that block)
-  SEG_UNDERRUN = 4    // input ended (deflate.lisp:114-120); out_bytes/tok_words cover complete tokens
+  SEG_UNDERRUN = 4,   // input ended (deflate.lisp:114-120); out_bytes/tok_words cover complete tokens
+  SEG_REDO = 5        // the gang kernel declined the item (token stream as dense as the bitstream, run table
+                      // full): decode it again with one lane
   // <0: TBZ_E_* error codes of include/tbz_amd.h
 };
 
@@ -44,20 +47,35 @@ struct SegResult {
   uint64_t end_bit;      // LANDED/FINAL: bit after the last block (FINAL: after the trailer);
                          // OVERSHOOT: start of the block that crossed; UNDERRUN: start of the token/field
   uint64_t out_bytes;    // octets the decoded tokens produce
-  uint64_t tok_words;    // u16 token words written at tok[start_bit ...]
+  uint64_t tok_words;    // logical length of the item's token stream in u16 words: the sum of its runs (each
+                         // padded to a multiple of 8 words with TOK_NOP)
   int32_t status;
   uint32_t max_deficit;  // max over matches of (distance - octets produced before it in THIS item), 0 if none
   uint32_t trailer0;     // zlib: adler32 (already byte-swapped to host order); gzip: crc32
   uint32_t trailer1;     // gzip: ISIZE
   uint32_t trailer_have; // 0 none, 1 first word only (gzip crc without isize), 2 complete
   uint32_t land_marker;  // LANDED: index of the marker landed on
-  uint64_t reserved;
+  uint32_t n_runs;       // entries of the item's run table that make up tok_words
+  uint32_t pad;
+  uint64_t reserved;     // K1g diagnostics: rounds << 32 | committed lanes
 };
 
+// One contiguous piece of an item's token stream: n8 * 8 words at tok[item.start_bit + off8 * 8 ...].
+// An item's table starts at runs[item.start_bit >> RUN_SHIFT] (position-addressed like the token pool:
+// a token-bearing item spans more than 2^RUN_SHIFT bits, and K1 declines items that would need more runs
+// than their span holds slots).
+struct RunRec {
+  uint32_t off8;
+  uint32_t n8;
+};
+constexpr uint32_t RUN_SHIFT = 5;
+
 struct Seg {
-  uint64_t tok_index;  // first token word (index into the u16 pool)
-  uint64_t tok_words;
+  uint64_t tok_index;  // the item's start_bit: base of its token region and (>> RUN_SHIFT) of its run table
+  uint64_t tok_words;  // logical token words (multiple of 8)
   uint64_t out_bytes;
+  uint32_t n_runs;
+  uint32_t pad;
 };
 
 struct Group {

@@ -350,6 +350,14 @@ def case_deep_codes(eng, n_tokens=12000):
             assert_same(eng, s, "deflate", len(p), end=cut, what="deep codes cut at %d ov=%d" % (cut, ov))
         z = zlib.compress(p[:50000], 6)  # same octets through zlib's own (shallow) codes, as a container stream
         assert_same(eng, z, "zlib", 50000, what="deep plain via zlib")
+    # tokens as dense as bits (1-bit literal codes): the gang kernel hands such an item to the one-lane kernel
+    s, p = K.dense_literal_stream()
+    assert zlib.decompressobj(-15).decompress(s) == p
+    assert_same(eng, s, "deflate", len(p), what="dense literals")
+    assert_same(eng, s, "deflate", len(p), end=len(s) // 2, what="dense literals, cut")
+    s, p = K.dense_literal_stream(n_lits=40 * 11, blocks=40)  # short dense blocks: runs that end ragged
+    assert zlib.decompressobj(-15).decompress(s) == p
+    assert_same(eng, s, "deflate", len(p), what="dense literals, short blocks")
 
 
 ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,

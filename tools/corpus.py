@@ -391,6 +391,25 @@ def deep_code_stream(n_tokens=40000, seed=7, dist_overflow=False, blocks=3):
     return w.getvalue(), bytes(out)
 
 
+def dense_literal_stream(n_lits=60000, blocks=2):
+    """Raw deflate stream whose tokens are as dense as its bits: a dynamic block with a two-symbol lit/len code
+    ('a' and end-of-block, one bit each) and a single one-bit distance code, filled with literals.  A decoder
+    that parks tokens by bit position has no slack here.  Returns (stream, plain)."""
+    lit_lens = [0] * 257
+    lit_lens[ord("a")] = 1
+    lit_lens[256] = 1
+    w = DynamicHuffmanWriter(lit_lens, [1])
+    out = bytearray()
+    for b in range(blocks):
+        w.begin_block(final=(b == blocks - 1))
+        for _ in range(n_lits // blocks):
+            w.literal(ord("a"))
+            out.append(ord("a"))
+        w.end_block()
+    w.align()
+    return w.getvalue(), bytes(out)
+
+
 def _lz_apply(out, length, dist):
     """reference LZ77 semantics for building the expected plaintext (pure Python, byte-exact)"""
     start = len(out) - dist

@@ -164,11 +164,16 @@ TBZ_KERNEL void tbz_k0_scan_count(K0Params P) {
 TBZ_KERNEL void tbz_k0_scan_offsets(K0Params P) {
   const u32 lane = tbz_lane();
   u32 carry = 0;
-  for (u32 i = 0; i < P.n_tiles; i += 64) {
-    u32 v = (i + lane) < P.n_tiles ? P.tile_counts[i + lane] : 0;
-    u32 inc = wave_incl_scan_u32(v);
-    if ((i + lane) < P.n_tiles) P.tile_offsets[i + lane] = carry + inc - v;
-    carry += tbz_shfl(inc, 63);
+  for (u32 i = 0; i < P.n_tiles; i += 256) {  // four rows per trip: their loads go out together
+    u32 v[4];
+#pragma unroll
+    for (u32 q = 0; q < 4; q++) v[q] = (i + q * 64 + lane) < P.n_tiles ? P.tile_counts[i + q * 64 + lane] : 0;
+#pragma unroll
+    for (u32 q = 0; q < 4; q++) {
+      const u32 inc = wave_incl_scan_u32(v[q]);
+      if ((i + q * 64 + lane) < P.n_tiles) P.tile_offsets[i + q * 64 + lane] = carry + inc - v[q];
+      carry += tbz_shfl(inc, 63);
+    }
   }
   if (lane == 0) P.tile_offsets[P.n_tiles] = carry;
 }
@@ -2121,7 +2126,9 @@ template <bool LINEAR>
 TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks, u32* rcache) {
   const u32 lane = tbz_lane();
   const u64 lane_bit = 1ull << lane;
-  const Group g = P.groups[P.order ? P.order[tbz_block()] : tbz_block()];
+  const u32 gi = P.order ? P.order[tbz_block()] : tbz_block();
+  const Seg sg_guess = P.segs[gi];  // device-built tables (K3) have segment i in group i: fetched along with the group
+  const Group g = P.groups[gi];
   if (!P.order && P.cls) {  // device-built tables (K3): one segment per group, sorted into launches by size here
     const bool small = P.segs[g.seg_first].out_bytes + K2_SLACK <= K2_SMALL_MAX;
     if ((P.cls == 1) != small) return;
@@ -2133,7 +2140,7 @@ TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks, u32* rcache) {
   u32 rpos = a0;  // window index of `pos`
 
   for (u32 s = 0; s < g.seg_count && pos < clip; s++) {
-    const Seg sg = P.segs[g.seg_first + s];
+    const Seg sg = g.seg_first + s == gi ? sg_guess : P.segs[g.seg_first + s];
     u64 p = 0;
     // The segment's token stream is the concatenation of its runs (8-word pieces).  Token ring: chunk c
     // (logical words [c*K2_TCH, (c+1)*K2_TCH) = 64 pieces, one per lane) lives in ring half c & 1.  The
@@ -2165,6 +2172,13 @@ TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks, u32* rcache) {
       for (u32 step = 32; step; step >>= 1) j += rE[j + step - 1] <= rel ? step : 0u;
       return j;
     };
+    // the same for the 64 pieces of one chunk, whose first piece lies in run j0: a chunk usually spans two or
+    // three runs, so four broadcast reads answer it; the binary search is the fallback
+    auto find_run_from = [&](u32 j0, u32 rel) -> u32 {
+      const u32 e0 = rE[j0], e1 = rE[j0 + 1 < 64 ? j0 + 1 : 63], e2 = rE[j0 + 2 < 64 ? j0 + 2 : 63], e3 = rE[j0 + 3 < 64 ? j0 + 3 : 63];
+      const u32 j = j0 + (rel >= e0 ? 1u : 0u) + (rel >= e1 ? 1u : 0u) + (rel >= e2 ? 1u : 0u);
+      return (rel < e3 && j0 + 3 < 64) ? j : find_run(rel);
+    };
     auto cover = [&](u64 x0, u64 xl) {  // make the cache hold pieces x0..xl (a chunk: at most 64 pieces)
       if (xl - cbase < ctot) return;
       if (x0 - cbase < ctot) {
@@ -2184,9 +2198,10 @@ TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks, u32* rcache) {
       const u64 xl = x0 + 63 < npieces ? x0 + 63 : npieces - 1;
       cover(x0, xl);
       const u64 x = x0 + lane;
+      const u32 j0 = find_run((u32)(x0 - cbase));  // uniform
       if (x < npieces) {
         const u32 rel = (u32)(x - cbase);
-        const u32 j = find_run(rel);
+        const u32 j = find_run_from(j0, rel);
         const u32 before = j ? rE[j - 1] : 0u;
         v = *(const uint4*)(tbase + ((u64)rO[j] + (rel - before)) * 8);
       }
@@ -2194,12 +2209,10 @@ TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks, u32* rcache) {
     };
     u32 cur = 0;
     load_cache();
-    {
-      const uint4 v0 = fetch(0);
-      tbz_sync();
-      *(uint4*)(tks + lane * 8) = v0;
-    }
+    const uint4 v0 = fetch(0);
     uint4 pre = fetch(1);
+    tbz_sync();
+    *(uint4*)(tks + lane * 8) = v0;
     tbz_sync();
     while (p < sg.tok_words && pos < clip) {
       const u64 left = sg.tok_words - p;
@@ -2588,17 +2601,25 @@ TBZ_KERNEL void tbz_k4_adler_combine(K4cParams P) {
   const u32 lane = tbz_lane();
   const CkStream cs = P.streams[tbz_block()];
   u64 s1 = cs.init0 & 0xffff, s2 = cs.init0 >> 16;  // running, < P
-  for (u32 c0 = 0; c0 < cs.count; c0 += 64) {
-    u32 c = c0 + lane;
-    bool v = c < cs.count;
-    u64 a = v ? P.parts[cs.first + c].a : 0, b = v ? P.parts[cs.first + c].b : 0;
-    u64 n = v ? P.chunks[cs.first + c].len : 0;
-    u64 inc = wave_incl_scan_u64(a);
-    u64 s1_before = (s1 + inc - a) % ADLER_P;
-    u64 term = v ? ((n % ADLER_P) * s1_before + b) % ADLER_P : 0;
-    u64 tsum = wave_sum_u64(term);
-    s2 = (s2 + tsum) % ADLER_P;
-    s1 = (s1 + tbz_shfl64(inc, 63)) % ADLER_P;
+  for (u32 c0 = 0; c0 < cs.count; c0 += 256) {  // four rows of 64 chunks per trip: their loads go out together
+    u64 a[4], b[4], n[4];
+#pragma unroll
+    for (u32 q = 0; q < 4; q++) {
+      const u32 c = c0 + q * 64 + lane;
+      const bool v = c < cs.count;
+      a[q] = v ? P.parts[cs.first + c].a : 0;
+      b[q] = v ? P.parts[cs.first + c].b : 0;
+      n[q] = v ? P.chunks[cs.first + c].len : 0;
+    }
+#pragma unroll
+    for (u32 q = 0; q < 4; q++) {
+      const u64 inc = wave_incl_scan_u64(a[q]);
+      const u64 s1_before = (s1 + inc - a[q]) % ADLER_P;
+      const u64 term = ((n[q] % ADLER_P) * s1_before + b[q]) % ADLER_P;  // absent chunks: n = b = 0
+      const u64 tsum = wave_sum_u64(term);
+      s2 = (s2 + tsum) % ADLER_P;
+      s1 = (s1 + tbz_shfl64(inc, 63)) % ADLER_P;
+    }
   }
   if (lane == 0) P.out[tbz_block()] = (u32)s1 | ((u32)s2 << 16);
 }

@@ -5,9 +5,10 @@ usage: pmc_traffic.py <fetch.db> <write.db> <raw_out.json> <traffic_out.json> <C
 
 Counters are in KB per dispatch, one row per counter instance: summed over the instances of a dispatch, then
 averaged over the dispatches of a kernel.  Corrections as MI355X_MICROARCH.md §HBM prescribes for gfx950:
-FETCH_SIZE under-reports wide coalesced streaming reads by 2x -> doubled for K2 (coalesced 16-byte token loads) and
-for the commit copy inside K1; K1's window loads are per-lane 16-byte reads of different lines and its raw value
-matches C, so it is taken as is (the K1 figure is therefore a lower bound).  WRITE_SIZE is used as reported."""
+FETCH_SIZE reports half of a wide coalesced streaming read (16 B per lane) -> doubled for K2 (its token loads are that
+pattern).  K1's loads (one 16-byte window read per lane, every lane in a different line) and K1's stores (4 bytes per
+lane per token, every lane in a different line) are patterns the guide calls uncalibrated: they are taken as reported,
+and say more as ratios between versions than as absolutes.  WRITE_SIZE is exact for K2's 16-byte streaming stores."""
 import json
 import sqlite3
 import sys

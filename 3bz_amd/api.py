@@ -194,6 +194,9 @@ class DeflateState:
         self.input_underrun = False
         self._calls = 0
         self.result = None
+        self._seen = bytearray()   # every input octet given to this state (resume replays it)
+        self._full = None          # scratch vector of the last replay
+        self._delivered = 0        # output octets handed out so far
 
 
 class ZlibState(DeflateState):
@@ -247,33 +250,77 @@ def replace_output_buffer(state, buffer):
 def decompress(context, state, engine=None):
     """api.lisp:3-10.  One call over everything the context holds, on the device.
 
-    Supported on the device path: a fresh state (first call).  All three outcomes are reported
-    exactly as the reference does — finished / input-underrun / output-overflow flags, octet count,
-    the correct prefix in the buffer.  RESUMING a state after underrun/overflow (the chunked
-    protocol of deflate.lisp:114-137) is the next row of SURVEY §8f and raises loudly rather than
-    falling back to any CPU path."""
-    if state._calls and not state.finished:
-        raise ThreeBzError(-104,
-                           "resuming a stream (chunked input/output) is not implemented on the device path")
+    All three outcomes are reported as the reference does — finished / input-underrun / output-overflow flags,
+    octet count, the correct prefix in the buffer.
+
+    RESUMING (the chunked protocol of deflate.lisp:114-137: more input after input-underrun, a new buffer after
+    output-overflow) is done by REPLAY on the device: the state keeps every input octet it has been given; a call
+    that brings new input decodes the whole prefix again (one engine call into a scratch vector) and hands out
+    the octets beyond those already delivered; a call that only brings a new output buffer hands out the next
+    slice of the scratch vector.  Same flags, counts and octets as the reference call by call on valid streams
+    (tests: case_chunked_resume); cost O(prefix) per call that brings input, so it suits a few large chunks —
+    a device-resident session that restarts at the last block boundary is SURVEY §8f-2, next.  Deviation: a
+    stream that turns out to be INVALID is reported when the replay first meets the error, which can be a call
+    earlier than the reference (which first hands out the output before the error, and a checksum
+    mismatch only after the last octet)."""
     eng = engine or default_engine()
+    first = state._calls == 0
     state._calls += 1
     state.input_underrun = False
     state.output_overflow = False
-    out = state.output_buffer
-    res = eng.inflate(context.octet_vector, state.format, out, start=context.offset, end=context.end)
-    state.result = res
-    if res.status < 0:
-        raise ThreeBzError(res.status, eng.strerror(res.status))
-    state.finished = res.status == _lib.FINISHED
-    state.input_underrun = res.status == _lib.INPUT_UNDERRUN
-    state.output_overflow = res.status == _lib.OUTPUT_OVERFLOW
-    state.output_offset = res.out_len
-    context.offset = context.end if not state.finished else context.offset + res.in_consumed
-    # the reference's early returns: zlib header underrun and every gzip header/trailer underrun
-    # `(return-from … 0)` (zlib.lisp:113-114, gzip.lisp:86,:99,:116…); otherwise output-offset
-    if state.input_underrun and state.format == FORMATS["gzip"] and (res.flags & 2):
-        return 0  # final block decoded but crc32 / ISIZE cut off: (return-from decompress-gzip 0)
-    return res.out_len
+    new = bytes(memoryview(context.octet_vector)[context.offset:context.end])
+    if first:
+        out = state.output_buffer
+        res = eng.inflate(new, state.format, out)
+        state.result = res
+        state._seen = bytearray(new)
+        state._full = None
+        if res.status < 0:
+            raise ThreeBzError(res.status, eng.strerror(res.status))
+        state.finished = res.status == _lib.FINISHED
+        state.input_underrun = res.status == _lib.INPUT_UNDERRUN
+        state.output_overflow = res.status == _lib.OUTPUT_OVERFLOW
+        state.output_offset = res.out_len
+        state._delivered = res.out_len
+        context.offset = context.end if not state.finished else context.offset + res.in_consumed
+        # the reference's early returns: zlib header underrun and every gzip header/trailer underrun
+        # `(return-from … 0)` (zlib.lisp:113-114, gzip.lisp:86,:99,:116…); otherwise output-offset
+        if state.input_underrun and state.format == FORMATS["gzip"] and (res.flags & 2):
+            return 0  # final block decoded but crc32 / ISIZE cut off: (return-from decompress-gzip 0)
+        return res.out_len
+    if state.finished:
+        return state.output_offset
+    # ---- resume by replay
+    if new or state._full is None:
+        state._seen += new
+        context.offset = context.end
+        size = eng.inflate_size(bytes(state._seen), state.format)
+        if size.status < 0:
+            raise ThreeBzError(size.status, eng.strerror(size.status))
+        full = bytearray(size.out_total)
+        res = eng.inflate(bytes(state._seen), state.format, full)
+        state.result = res
+        state._full = full
+        state._full_status = res.status
+        state._full_flags = res.flags
+    full, status = state._full, state._full_status
+    if status < 0:
+        raise ThreeBzError(status, eng.strerror(status))
+    avail = len(full)
+    off = state.output_offset
+    give = max(0, min(len(state.output_buffer) - off, avail - state._delivered))
+    state.output_buffer[off:off + give] = full[state._delivered:state._delivered + give]
+    state.output_offset = off + give
+    state._delivered += give
+    pending = avail - state._delivered
+    if pending > 0:
+        state.output_overflow = True
+        return state.output_offset
+    state.finished = status == _lib.FINISHED
+    state.input_underrun = status == _lib.INPUT_UNDERRUN
+    if state.input_underrun and state.format == FORMATS["gzip"] and (state._full_flags & 2):
+        return 0
+    return state.output_offset
 
 
 def decompress_vector(compressed, format="zlib", start=0, end=None, output=None, engine=None):

@@ -360,6 +360,73 @@ def case_deep_codes(eng, n_tokens=12000):
     assert_same(eng, s, "deflate", len(p), what="dense literals, short blocks")
 
 
+def _chunked_lockstep(eng, blob, fmt, in_steps, out_sizes, what):
+    """feed `blob` to the oracle and to the engine in the same input chunks / output buffers and compare every call"""
+    mk_e = {"deflate": A.make_deflate_state, "zlib": A.make_zlib_state, "gzip": A.make_gzip_state}[fmt]
+    so, se = O.State(FMT[fmt]), mk_e()
+    got_o, got_e = bytearray(), bytearray()
+    bo, be = bytearray(out_sizes[0]), bytearray(out_sizes[0])
+    O.replace_output_buffer(so, bo)
+    A.replace_output_buffer(se, be)
+    oi, pos, step_i, guard = 1, 0, 0, 0
+    while not O.finished(so):
+        guard += 1
+        assert guard < 2000, what
+        step = in_steps[step_i % len(in_steps)]
+        step_i += 1
+        end = min(len(blob), pos + step)
+        co = O.make_octet_vector_context(blob, start=pos, end=end)
+        ce = A.make_octet_vector_context(blob, start=pos, end=end)
+        while True:
+            ro = O.decompress(co, so)
+            re_ = A.decompress(ce, se, engine=eng)
+            flags_o = (O.finished(so), O.input_underrun(so), O.output_overflow(so))
+            flags_e = (A.finished(se), A.input_underrun(se), A.output_overflow(se))
+            assert flags_e == flags_o and re_ == ro, (what, guard, flags_e, flags_o, re_, ro)
+            assert bytes(be[:se.output_offset]) == bytes(bo[:so.output_offset]), (what, guard, "buffer differs")
+            if O.output_overflow(so):
+                got_o += bo[:ro]
+                got_e += be[:re_]
+                size = out_sizes[oi % len(out_sizes)]
+                oi += 1
+                bo, be = bytearray(size), bytearray(size)
+                O.replace_output_buffer(so, bo)
+                A.replace_output_buffer(se, be)
+                continue
+            break
+        pos = end
+        if pos >= len(blob) and not O.finished(so):
+            break  # truncated stream: both sit in input-underrun
+    got_o += bo[:so.output_offset]
+    got_e += be[:se.output_offset]
+    assert bytes(got_e) == bytes(got_o), what
+    return bytes(got_o)
+
+
+def case_chunked_resume(eng, n=90_000):
+    """the chunked protocol (deflate.lisp:114-137): more input after input-underrun, a new buffer after
+    output-overflow — every call compared with the oracle (flags, return value, buffer contents)"""
+    plain = _mixed_plain(n, 5)
+    rng = random.Random(2024)
+    fs, fp, _ = K.zlib_flush_stream(n, block=8192)
+    blobs = [("zlib", zlib.compress(plain, 6), plain), ("gzip", pygzip.compress(plain, 6, mtime=0), plain),
+             ("deflate", zlib.compress(plain, 1)[2:-4], plain), ("zlib", fs, fp)]
+    for fmt, blob, plain in blobs:
+        big = len(plain) + 10
+        # input chunks only
+        steps = [rng.randrange(2000, 9000) for _ in range(8)]
+        assert _chunked_lockstep(eng, blob, fmt, steps, [big], "%s input chunks" % fmt) == plain
+        # output buffers only
+        sizes = [rng.randrange(3000, 30000) for _ in range(8)]
+        assert _chunked_lockstep(eng, blob, fmt, [len(blob)], sizes, "%s output buffers" % fmt) == plain
+        # both, plus a first chunk that ends inside the container header
+        steps = [1] + [rng.randrange(3000, 12000) for _ in range(6)]
+        sizes = [rng.randrange(5000, 40000) for _ in range(6)]
+        assert _chunked_lockstep(eng, blob, fmt, steps, sizes, "%s both" % fmt) == plain
+    # truncated stream fed in chunks: ends in input-underrun on both sides
+    _chunked_lockstep(eng, blobs[0][1][: len(blobs[0][1]) // 2], "zlib", [5000], [n + 10], "truncated zlib in chunks")
+
+
 ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,
              case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_device_buffers,
-             case_checksum_kernels, case_deep_codes]
+             case_checksum_kernels, case_deep_codes, case_chunked_resume]

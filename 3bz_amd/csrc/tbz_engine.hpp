@@ -49,7 +49,7 @@ struct tbz_ctx {
   // device pools (grow-only)
   tbz::DevBuf d_str_off, d_str_len, d_tile_first, d_tile_counts, d_tile_offsets, d_markers, d_items, d_res,
       d_tok, d_scratch, d_runs, d_segs, d_groups, d_order, d_k3_fi, d_k3_ni, d_k3_oo, d_k3_oc, d_k3_sums, d_k3_flags,
-      d_k3_gscan, d_k3_gne, d_k3_streams, d_k3_glob, d_redo_items, d_redo_res, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
+      d_k3_gscan, d_k3_gne, d_k3_streams, d_k3_glob, d_redo_items, d_redo_res, d_k0_slots, d_k0_fm, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
       d_out_stage;
 };
 
@@ -84,6 +84,18 @@ static int upload(tbz_ctx* ctx, DevBuf& b, const std::vector<T>& v) {
   int r = ensure(ctx, b, std::max<size_t>(v.size() * sizeof(T), 16));
   if (r) return r;
   if (!v.empty()) TBZ_HIP(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  return 0;
+}
+
+// pinned host scratch for the small read-backs (grow-only)
+static int pinned(tbz_ctx* ctx, size_t bytes) {
+  bytes += 64;
+  if (bytes <= ctx->h_pin_cap) return 0;
+  if (ctx->h_pin) TBZ_HIP(hipHostFree(ctx->h_pin));
+  ctx->h_pin = nullptr;
+  ctx->h_pin_cap = 0;
+  TBZ_HIP(hipHostMalloc(&ctx->h_pin, bytes * 2));
+  ctx->h_pin_cap = bytes * 2;
   return 0;
 }
 
@@ -249,69 +261,100 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   if (in_extent && !d_in) return TBZ_E_ARG;
 
   if ((r = record(ctx, 0))) return r;
-  // ---------------------------------------------------------------- K0: markers
+  // ---------------------------------------------------------------- K0: markers + items, on the device
+  // One pass over the input finds the markers (kept per tile, then compacted in order) and a small kernel
+  // builds the K1 items; the host reads 8 bytes + one index per stream.  Host copies of the marker and item
+  // arrays are fetched only by the general (host) layout path.
   std::vector<uint64_t> markers;
+  std::vector<Item> items;
+  bool host_tables = false;
+  uint32_t n_mark = 0;
+  std::vector<uint32_t> first_marker(n + 1, 0);
   if (tiles) {
     if ((r = upload(ctx, ctx->d_str_off, h_off))) return r;
     if ((r = upload(ctx, ctx->d_str_len, h_len))) return r;
     if ((r = upload(ctx, ctx->d_tile_first, tile_first))) return r;
     if ((r = ensure(ctx, ctx->d_tile_counts, tiles * 4))) return r;
     if ((r = ensure(ctx, ctx->d_tile_offsets, (tiles + 1) * 4))) return r;
+    if ((r = ensure(ctx, ctx->d_k0_slots, tiles * (size_t)K0_SLOTS * 8))) return r;
+    if ((r = ensure(ctx, ctx->d_markers, tiles * (size_t)K0_SLOTS * 8 + 16))) return r;
+    if ((r = ensure(ctx, ctx->d_k0_fm, (n + 1) * 4 + 8))) return r;  // [0..1] head, [2..] first_marker
+    if ((r = ensure(ctx, ctx->d_items, (tiles * (size_t)K0_SLOTS + n) * sizeof(Item)))) return r;
+    if ((r = pinned(ctx, (n + 3) * 4 + sizeof(K3Global) + (n + 1) * sizeof(K3Stream)))) return r;
     K0Params k0{(const u8*)d_in, (const u64*)ctx->d_str_off.p, (const u64*)ctx->d_str_len.p,
                 (const u32*)ctx->d_tile_first.p, (u32)n, (u32)tiles, (u32*)ctx->d_tile_counts.p,
-                (u32*)ctx->d_tile_offsets.p, nullptr};
-    TBZ_LAUNCH(tbz_k0_scan_count, tiles, ctx->stream, k0);
+                (u32*)ctx->d_tile_offsets.p, (u64*)ctx->d_markers.p, (u64*)ctx->d_k0_slots.p,
+                (u32*)ctx->d_k0_fm.p + 2, (u32*)ctx->d_k0_fm.p, (Item*)ctx->d_items.p, (u32)format};
+    const size_t max_items = tiles * (size_t)K0_SLOTS + n;
+    TBZ_LAUNCH(tbz_k0_scan_tiles, tiles, ctx->stream, k0);
     TBZ_LAUNCH(tbz_k0_scan_offsets, 1, ctx->stream, k0);
-    uint32_t n_mark = 0;
-    TBZ_HIP(hipMemcpyAsync(&n_mark, (const uint32_t*)ctx->d_tile_offsets.p + tiles, 4, hipMemcpyDeviceToHost,
-                           ctx->stream));
+    TBZ_LAUNCH(tbz_k0_compact, tiles, ctx->stream, k0);
+    TBZ_LAUNCH(tbz_k0_items, (max_items + 63) / 64, ctx->stream, k0);
+    uint32_t* h_head = (uint32_t*)ctx->h_pin;
+    TBZ_HIP(hipMemcpyAsync(h_head, ctx->d_k0_fm.p, (n + 3) * 4, hipMemcpyDeviceToHost, ctx->stream));
     TBZ_HIP(hipStreamSynchronize(ctx->stream));
-    if ((r = ensure(ctx, ctx->d_markers, std::max<size_t>((size_t)n_mark * 8, 16)))) return r;
-    if (n_mark) {
+    n_mark = h_head[0];
+    for (size_t s = 0; s <= n; s++) first_marker[s] = h_head[2 + s];
+    if (h_head[1]) {  // a tile with more markers than slots: the second, emitting pass
+      if ((r = ensure(ctx, ctx->d_markers, (size_t)n_mark * 8 + 16))) return r;
+      if ((r = ensure(ctx, ctx->d_items, ((size_t)n_mark + n) * sizeof(Item)))) return r;
       k0.markers = (u64*)ctx->d_markers.p;
+      k0.items = (Item*)ctx->d_items.p;
       TBZ_LAUNCH(tbz_k0_scan_emit, tiles, ctx->stream, k0);
-      markers.resize(n_mark);
-      TBZ_HIP(hipMemcpyAsync(markers.data(), ctx->d_markers.p, (size_t)n_mark * 8, hipMemcpyDeviceToHost,
-                             ctx->stream));
-      TBZ_HIP(hipStreamSynchronize(ctx->stream));
+      TBZ_LAUNCH(tbz_k0_items, ((size_t)n_mark + n + 63) / 64, ctx->stream, k0);
     }
     TBZ_HIP(hipGetLastError());
+    for (size_t s = 0; s < n; s++) {
+      StreamPlan& S = sp[s];
+      S.first_marker = first_marker[s];
+      S.first_item = first_marker[s] + (uint32_t)s;
+      S.n_items = 1 + (first_marker[s + 1] - first_marker[s]);
+      S.cur_item = S.first_item;
+    }
   } else {
+    // nothing to scan (every stream empty): one head item per stream, built here
     if ((r = ensure(ctx, ctx->d_markers, 16))) return r;
+    if ((r = ensure(ctx, ctx->d_k0_fm, (n + 1) * 4 + 8))) return r;
+    std::vector<uint32_t> zero(n + 3, 0);
+    if ((r = upload(ctx, ctx->d_k0_fm, zero))) return r;
+    if ((r = pinned(ctx, (n + 3) * 4 + sizeof(K3Global) + (n + 1) * sizeof(K3Stream)))) return r;
+    for (size_t s = 0; s < n; s++) {
+      StreamPlan& S = sp[s];
+      Item it;
+      it.start_bit = S.in_off * 8;
+      it.limit_bit = ~0ull;
+      it.end_byte = S.in_off + S.in_len;
+      it.stream = (uint32_t)s;
+      it.flags = ((uint32_t)format << ITEM_FMT_SHIFT) | ITEM_HEAD;
+      items.push_back(it);
+      S.first_item = (uint32_t)s;
+      S.first_marker = 0;
+      S.n_items = 1;
+      S.cur_item = S.first_item;
+    }
+    if ((r = upload(ctx, ctx->d_items, items))) return r;
+    host_tables = true;
   }
+  const size_t n_items = (size_t)n_mark + n;
+  const u32* d_first_marker = (const u32*)ctx->d_k0_fm.p + 2;
+  auto fetch_host_tables = [&]() -> int {  // the general layout path walks items and markers on the host
+    if (host_tables) return 0;
+    markers.resize(n_mark);
+    items.resize(n_items);
+    if (n_mark)
+      TBZ_HIP(hipMemcpyAsync(markers.data(), ctx->d_markers.p, (size_t)n_mark * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TBZ_HIP(hipMemcpyAsync(items.data(), ctx->d_items.p, n_items * sizeof(Item), hipMemcpyDeviceToHost, ctx->stream));
+    TBZ_HIP(hipStreamSynchronize(ctx->stream));
+    host_tables = true;
+    return 0;
+  };
   if ((r = record(ctx, 1))) return r;
 
-  // ---------------------------------------------------------------- items
-  // markers are globally sorted; streams may be given in any order, so bucket by binary search
-  std::vector<Item> items;
-  items.reserve(n + markers.size());
-  std::vector<uint32_t> item_marker;  // for round-0 items: index of the marker that is its limit (or ~0)
-  for (size_t s = 0; s < n; s++) {
-    StreamPlan& S = sp[s];
-    uint64_t b = S.in_off, e = S.in_off + S.in_len;
-    size_t m0 = std::upper_bound(markers.begin(), markers.end(), b) - markers.begin();
-    size_t m1 = std::lower_bound(markers.begin(), markers.end(), e) - markers.begin();
-    if (m1 < m0) m1 = m0;
-    S.first_item = (uint32_t)items.size();
-    S.first_marker = (uint32_t)m0;
-    S.n_items = (uint32_t)(1 + (m1 - m0));
-    for (size_t k = 0; k <= m1 - m0; k++) {
-      Item it;
-      it.start_bit = (k == 0 ? b : markers[m0 + k - 1]) * 8;
-      it.limit_bit = (m0 + k < m1) ? markers[m0 + k] * 8 : ~0ull;
-      it.end_byte = e;
-      it.stream = (uint32_t)s;
-      it.flags = ((uint32_t)format << ITEM_FMT_SHIFT) | (k == 0 ? ITEM_HEAD : 0u);
-      items.push_back(it);
-    }
-    S.cur_item = S.first_item;
-  }
   // token pool: one u16 per input bit (K1 never writes more words than bits consumed)
   if ((r = ensure(ctx, ctx->d_tok, (size_t)in_extent * 16 + 64))) return r;
   // run tables: one 8-byte slot per 2^RUN_SHIFT input bits, position-addressed like the token pool
   if ((r = ensure(ctx, ctx->d_runs, (((size_t)in_extent * 8) >> RUN_SHIFT) * sizeof(RunRec) + 1024))) return r;
-  if ((r = upload(ctx, ctx->d_items, items))) return r;
-  if ((r = ensure(ctx, ctx->d_res, items.size() * sizeof(SegResult)))) return r;
+  if ((r = ensure(ctx, ctx->d_res, n_items * sizeof(SegResult)))) return r;
   // K1 flavour.  One lane per item is bound by ONE item's serial chain (~1.1 us per token) and decodes
   // without lookup tables; a gang of G lanes shares one item and one set of LDS tables.  G follows the
   // average item size (a lane should get at least ~2 Kibit of bitstream per round); only batches of
@@ -333,7 +376,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     int rr = ensure(ctx, ctx->d_scratch, n_it * (size_t)K1_SCRATCH);
     if (rr) return rr;
     K1Params k1{(const u8*)d_in, (u16*)ctx->d_tok.p, d_items, d_res, (const u64*)ctx->d_markers.p,
-                (u8*)ctx->d_scratch.p, (RunRec*)ctx->d_runs.p, (u32)markers.size(), (u32)n_it, items_per_wg(n_it)};
+                (u8*)ctx->d_scratch.p, (RunRec*)ctx->d_runs.p, d_first_marker, (u32)n_mark, (u32)n_it, items_per_wg(n_it)};
     TBZ_LAUNCH(tbz_k1_huff_decode, (n_it + k1.items_per_wg - 1) / k1.items_per_wg, ctx->stream, k1);
     return 0;
   };
@@ -366,7 +409,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if (G == 1) return launch_lane(d_items, d_res, n_it);
     size_t per = 64 / G, nwg = (n_it + per - 1) / per;
     K1gParams kg{(const u8*)d_in, (u16*)ctx->d_tok.p, (RunRec*)ctx->d_runs.p, d_items, d_res,
-                 (const u64*)ctx->d_markers.p, (u32)markers.size(), (u32)n_it};
+                 (const u64*)ctx->d_markers.p, d_first_marker, (u32)n_mark, (u32)n_it};
     switch (G) {
       case 8: TBZ_LAUNCH(tbz_k1g8_huff_decode, nwg, ctx->stream, kg); break;
       case 16: TBZ_LAUNCH(tbz_k1g16_huff_decode, nwg, ctx->stream, kg); break;
@@ -377,8 +420,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   };
   // K3 (layout on the device when every item simply lands on its successor): its stream tables go up before
   // K1 so that nothing but two tiny kernels and a 16-byte read-back stand between K1 and the decision
-  const bool try_simple = !ctx->host_layout && !items.empty();
-  const u32 k3_tiles = (u32)((items.size() + K3_TILE - 1) / K3_TILE);
+  const bool try_simple = !ctx->host_layout && n_items != 0;
+  const u32 k3_tiles = (u32)((n_items + K3_TILE - 1) / K3_TILE);
   K3Params k3{};
   if (try_simple) {
     std::vector<uint32_t> fi(n), ni(n);
@@ -395,34 +438,27 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if ((r = upload(ctx, ctx->d_k3_oc, oc))) return r;
     if ((r = ensure(ctx, ctx->d_k3_sums, 3 * (size_t)(k3_tiles + 1) * 8))) return r;
     if ((r = ensure(ctx, ctx->d_k3_flags, 3 * (size_t)k3_tiles * 8))) return r;
-    if ((r = ensure(ctx, ctx->d_k3_gscan, items.size() * 8))) return r;
-    if ((r = ensure(ctx, ctx->d_k3_gne, items.size() * 4))) return r;
-    if ((r = ensure(ctx, ctx->d_segs, items.size() * sizeof(Seg)))) return r;
-    if ((r = ensure(ctx, ctx->d_groups, items.size() * sizeof(Group)))) return r;
+    if ((r = ensure(ctx, ctx->d_k3_gscan, n_items * 8))) return r;
+    if ((r = ensure(ctx, ctx->d_k3_gne, n_items * 4))) return r;
+    if ((r = ensure(ctx, ctx->d_segs, n_items * sizeof(Seg)))) return r;
+    if ((r = ensure(ctx, ctx->d_groups, n_items * sizeof(Group)))) return r;
     if ((r = ensure(ctx, ctx->d_k3_streams, (n + 1) * sizeof(K3Stream)))) return r;
     if ((r = ensure(ctx, ctx->d_k3_glob, sizeof(K3Global)))) return r;
-    size_t pin = sizeof(K3Global) + (n + 1) * sizeof(K3Stream);
-    if (pin > ctx->h_pin_cap) {
-      if (ctx->h_pin) TBZ_HIP(hipHostFree(ctx->h_pin));
-      ctx->h_pin = nullptr;
-      ctx->h_pin_cap = 0;
-      TBZ_HIP(hipHostMalloc(&ctx->h_pin, pin * 2));
-      ctx->h_pin_cap = pin * 2;
-    }
     k3 = K3Params{(const Item*)ctx->d_items.p, (const SegResult*)ctx->d_res.p, (const u32*)ctx->d_k3_fi.p,
                   (const u32*)ctx->d_k3_ni.p, (const u64*)ctx->d_k3_oo.p, (const u64*)ctx->d_k3_oc.p,
                   (u64*)ctx->d_k3_sums.p, (u64*)ctx->d_k3_flags.p, (u64*)ctx->d_k3_gscan.p, (u32*)ctx->d_k3_gne.p,
                   (Seg*)ctx->d_segs.p, (Group*)ctx->d_groups.p, (K3Stream*)ctx->d_k3_streams.p,
-                  (K3Global*)ctx->d_k3_glob.p, (u32)items.size(), k3_tiles, (u32)n};
+                  (K3Global*)ctx->d_k3_glob.p, (u32)n_items, k3_tiles, (u32)n};
   }
   if ((r = record(ctx, 2))) return r;
-  if ((r = launch_k1((const Item*)ctx->d_items.p, (SegResult*)ctx->d_res.p, items.size()))) return r;
+  if ((r = launch_k1((const Item*)ctx->d_items.p, (SegResult*)ctx->d_res.p, n_items))) return r;
   TBZ_HIP(hipGetLastError());
   if ((r = record(ctx, 3))) return r;
   ctx->tim.huff_launches = 1;
   bool simple = false;
-  K3Global* h_glob = (K3Global*)ctx->h_pin;
-  K3Stream* h_k3s = (K3Stream*)((char*)ctx->h_pin + sizeof(K3Global));
+  char* pin_k3 = (char*)ctx->h_pin + (((n + 3) * 4 + 15) & ~(size_t)15);
+  K3Global* h_glob = (K3Global*)pin_k3;
+  K3Stream* h_k3s = (K3Stream*)(pin_k3 + sizeof(K3Global));
   if (try_simple) {
     TBZ_LAUNCH(tbz_k3_tile_sums, k3_tiles, ctx->stream, k3);
     TBZ_LAUNCH(tbz_k3_scan_tiles, 1, ctx->stream, k3);
@@ -460,7 +496,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if ((r = record(ctx, 4))) return r;
     if (!size_only) {
       if (!d_out) return TBZ_E_ARG;
-      const u32 n_it = (u32)items.size();
+      const u32 n_it = (u32)n_items;
       K2Params k2{(const u16*)ctx->d_tok.p, (const RunRec*)ctx->d_runs.p, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, nullptr,
                   (const u8*)d_in, (u8*)d_out, n_it, 0, 0};
       if (h_glob->n_big < n_it) {
@@ -495,7 +531,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       fill_result(s, TBZ_FINISHED, (uint32_t)k.nonempty);
     }
   } else {
-  std::vector<SegResult> res(items.size());
+  if ((r = fetch_host_tables())) return r;
+  std::vector<SegResult> res(n_items);
   TBZ_HIP(hipMemcpyAsync(res.data(), ctx->d_res.p, res.size() * sizeof(SegResult), hipMemcpyDeviceToHost,
                          ctx->stream));
   TBZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -504,7 +541,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
 
   // ---------------------------------------------------------------- chain walk (+ fix-up rounds)
   std::vector<SegHost> segs;
-  segs.reserve(items.size());
+  segs.reserve(n_items);
   std::vector<std::vector<SegHost>> per_stream(n);
   auto consume = [&](StreamPlan& S, size_t s, const Item& it, const SegResult& q, bool is_fixup) {
     SegHost h;
@@ -835,7 +872,7 @@ void tbz_ctx_destroy(tbz_ctx* ctx) {
                          &ctx->d_segs, &ctx->d_groups, &ctx->d_ck_chunks, &ctx->d_ck_parts, &ctx->d_ck_streams,
                          &ctx->d_ck_out, &ctx->d_crc_tab, &ctx->d_in_stage, &ctx->d_out_stage, &ctx->d_k3_fi, &ctx->d_k3_ni,
                          &ctx->d_k3_oo, &ctx->d_k3_oc, &ctx->d_k3_sums, &ctx->d_k3_flags, &ctx->d_k3_gscan, &ctx->d_k3_gne,
-                         &ctx->d_k3_streams, &ctx->d_k3_glob, &ctx->d_redo_items, &ctx->d_redo_res};
+                         &ctx->d_k3_streams, &ctx->d_k3_glob, &ctx->d_redo_items, &ctx->d_redo_res, &ctx->d_k0_slots, &ctx->d_k0_fm};
   for (auto* b : bufs)
     if (b->p) hipFree(b->p);
   if (ctx->h_pin) hipHostFree(ctx->h_pin);

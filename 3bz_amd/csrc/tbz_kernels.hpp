@@ -4,9 +4,9 @@
 // integer / byte work bounded by LDS latency (Huffman decode) or HBM bandwidth (scan, LZ77 flush,
 // checksums), so there is no MFMA here by design.
 //
-//   K0  tbz_k0_scan_count / tbz_k0_scan_offsets / tbz_k0_scan_emit
-//         find 00 00 FF FF flush markers (candidate independent-segment starts), coalesced reads,
-//         wave prefix-sums for an ordered compaction.
+//   K0  tbz_k0_scan_tiles / _offsets / _compact / _items  (+ tbz_k0_scan_emit, the second pass for crowded tiles)
+//         find 00 00 FF FF flush markers (candidate independent-segment starts) in one pass of aligned
+//         16-octet reads, compact them in order, build the K1 work items on the device.
 //   K1  tbz_k1_huff_decode
 //         one LANE per item (64 independent decoders per wave): bit reader + dynamic-header parse +
 //         lane-interleaved LDS lookup tables (replaces deflate.lisp:518-702 and
@@ -94,10 +94,16 @@ struct K0Params {
   const u32* tile_first;  // n_streams+1 prefix of tiles per stream
   u32 n_streams;
   u32 n_tiles;
-  u32* tile_counts;       // [n_tiles]   (count pass out)
+  u32* tile_counts;       // [n_tiles]   markers per tile
   u32* tile_offsets;      // [n_tiles+1] (scan out; [n_tiles] = total)
-  u64* markers;           // emit pass out, globally sorted
+  u64* markers;           // compact / emit out: in tile order, i.e. ascending within every stream
+  u64* tile_slots;        // [n_tiles][K0_SLOTS]: the first markers of each tile, written by the one-pass scan
+  u32* first_marker;      // [n_streams+1]: index of each stream's first marker (scan out)
+  u32* head;              // [2]: total markers, tiles whose markers did not fit their slots (scan out)
+  Item* items;            // item build out
+  u32 format;
 };
+constexpr u32 K0_SLOTS = 32;  // markers kept per 64 KiB tile by the one-pass scan (flush every 16 KiB of text: ~8)
 
 TBZ_DEV u32 k0_find_stream(const K0Params& P, u32 tile) {
   u32 lo = 0, hi = P.n_streams;  // tile_first[lo] <= tile < tile_first[hi]
@@ -151,13 +157,30 @@ TBZ_DEV u32 k0_row_mask(const K0Tile& T, uintptr_t c) {
   return m;
 }
 
-TBZ_KERNEL void tbz_k0_scan_count(K0Params P) {
+// ONE pass over the input: count the tile's markers and keep the first K0_SLOTS of them (in order) in the
+// tile's slots.  A tile with more markers than slots (stored data full of the pattern) makes the host fall
+// back to the second, emitting pass below.
+TBZ_KERNEL void tbz_k0_scan_tiles(K0Params P) {
   const K0Tile T = k0_tile(P);
   const u32 lane = tbz_lane();
-  u32 cnt = 0;
-  for (u32 r = 0; r < SCAN_TILE / 1024; r++) cnt += __builtin_popcount(k0_row_mask(T, T.t0 + r * 1024 + lane * 16));
-  u32 tot = (u32)wave_sum_u64(cnt);
-  if (lane == 0) P.tile_counts[tbz_block()] = tot;
+  u64* slots = P.tile_slots + (u64)tbz_block() * K0_SLOTS;
+  u32 base = 0;
+  for (u32 r = 0; r < SCAN_TILE / 1024; r++) {
+    const uintptr_t c = T.t0 + r * 1024 + lane * 16;
+    u32 m = k0_row_mask(T, c);
+    if (tbz_ballot(m != 0) == 0) continue;  // wave-uniform: nothing in this row
+    u32 n = __builtin_popcount(m);
+    u32 inc = wave_incl_scan_u32(n);
+    u32 o = base + inc - n;
+    while (m) {
+      u32 k = __builtin_ctz(m);
+      m &= m - 1;
+      if (o < K0_SLOTS) slots[o] = (u64)(c + k - T.base) + 4;
+      o++;
+    }
+    base += tbz_shfl(inc, 63);
+  }
+  if (lane == 0) P.tile_counts[tbz_block()] = base;
 }
 
 // single-wave exclusive scan over tile counts
@@ -175,7 +198,45 @@ TBZ_KERNEL void tbz_k0_scan_offsets(K0Params P) {
       carry += tbz_shfl(inc, 63);
     }
   }
-  if (lane == 0) P.tile_offsets[P.n_tiles] = carry;
+  u32 over = 0;
+  for (u32 i = lane; i < P.n_tiles; i += 64) over += P.tile_counts[i] > K0_SLOTS ? 1u : 0u;
+  over = (u32)wave_sum_u64(over);
+  if (lane == 0) {
+    P.tile_offsets[P.n_tiles] = carry;
+    P.head[0] = carry;
+    P.head[1] = over;
+  }
+}
+
+// slots -> the compact marker array; markers come out in tile order, so a stream's markers are the ones of
+// its tiles (workgroup 0 writes the per-stream index)
+TBZ_KERNEL void tbz_k0_compact(K0Params P) {
+  const u32 lane = tbz_lane(), t = tbz_block();
+  const u32 n = P.tile_counts[t], o = P.tile_offsets[t];
+  if (lane < n && lane < K0_SLOTS) P.markers[o + lane] = P.tile_slots[(u64)t * K0_SLOTS + lane];
+  if (t == 0)
+    for (u32 s = lane; s <= P.n_streams; s += 64) P.first_marker[s] = P.tile_offsets[s < P.n_streams ? P.tile_first[s] : P.n_tiles];
+}
+
+// items: per stream one head item (the stream's first octet) and one per marker
+TBZ_KERNEL void tbz_k0_items(K0Params P) {
+  const u32 i = tbz_block() * 64 + tbz_lane();
+  const u32 n_items = P.head[0] + P.n_streams;
+  if (i >= n_items) return;
+  u32 lo = 0, hi = P.n_streams;  // first_item[s] = first_marker[s] + s; find s with first_item[s] <= i < first_item[s+1]
+  while (hi - lo > 1) {
+    const u32 mid = (lo + hi) >> 1;
+    if (P.first_marker[mid] + mid <= i) lo = mid; else hi = mid;
+  }
+  const u32 s = lo, fm = P.first_marker[s], nm = P.first_marker[s + 1] - fm;
+  const u32 k = i - (fm + s);
+  Item it;
+  it.start_bit = (k == 0 ? P.str_off[s] : P.markers[fm + k - 1]) * 8;
+  it.limit_bit = k < nm ? P.markers[fm + k] * 8 : ~0ull;
+  it.end_byte = P.str_off[s] + P.str_len[s];
+  it.stream = s;
+  it.flags = (P.format << ITEM_FMT_SHIFT) | (k == 0 ? ITEM_HEAD : 0u);
+  P.items[i] = it;
 }
 
 TBZ_KERNEL void tbz_k0_scan_emit(K0Params P) {
@@ -262,6 +323,7 @@ struct K1Params {
   const u64* markers;
   u8* scratch;    // n_items * K1_SCRATCH octets
   RunRec* runs;   // run tables (one run per item here: the lane writes its tokens contiguously)
+  const u32* first_marker;  // [n_streams+1]: a stream's markers are markers[first_marker[s] .. first_marker[s+1])
   u32 n_markers;
   u32 n_items;
   u32 items_per_wg;  // 1..64: lanes >= items_per_wg idle (used to spread few large items over all CUs)
@@ -864,12 +926,14 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
       if (st.br.pos == st.limit_bit) { status = SEG_LANDED; break; }
     } else if ((st.br.pos & 7) == 0) {
       u64 b = st.br.pos >> 3;
-      u32 lo = 0, hi = P.n_markers;
+      u32 lo = P.first_marker[it.stream];
+      const u32 hi0 = P.first_marker[it.stream + 1];
+      u32 hi = hi0;
       while (lo < hi) {
         u32 mid = (lo + hi) >> 1;
         if (P.markers[mid] < b) lo = mid + 1; else hi = mid;
       }
-      if (lo < P.n_markers && P.markers[lo] == b) { land = lo; status = SEG_LANDED; break; }
+      if (lo < hi0 && P.markers[lo] == b) { land = lo; status = SEG_LANDED; break; }
     }
   }
 
@@ -993,6 +1057,7 @@ struct K1gParams {
   const Item* items;
   SegResult* res;
   const u64* markers;
+  const u32* first_marker;  // [n_streams+1]
   u32 n_markers;
   u32 n_items;
 };
@@ -1636,12 +1701,14 @@ TBZ_DEV void kg_block_end(GangState& gs, K1State& st, const Item& it, const K1gP
     }
   } else if ((gs.P & 7) == 0) {
     u64 b = gs.P >> 3;
-    u32 lo = 0, hi = P.n_markers;
+    u32 lo = P.first_marker[it.stream];
+    const u32 hi0 = P.first_marker[it.stream + 1];
+    u32 hi = hi0;
     while (lo < hi) {
       u32 mid = (lo + hi) >> 1;
       if (P.markers[mid] < b) lo = mid + 1; else hi = mid;
     }
-    if (lo < P.n_markers && P.markers[lo] == b) {
+    if (lo < hi0 && P.markers[lo] == b) {
       gs.land = lo;
       gs.status = SEG_LANDED;
       gs.mode = GM_DONE;

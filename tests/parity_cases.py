@@ -430,3 +430,7 @@ def case_chunked_resume(eng, n=90_000):
 ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,
              case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_device_buffers,
              case_checksum_kernels, case_deep_codes, case_chunked_resume]
+# the cases whose behaviour depends on the K1 flavour (forced-flavour runs skip the rest: checksums, device
+# buffers and the replay protocol go through the same engine calls whatever decodes the Huffman codes)
+K1_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,
+            case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_deep_codes]

@@ -32,5 +32,8 @@ def eng(request):
 
 
 @pytest.mark.parametrize("case", P.ALL_CASES, ids=lambda c: c.__name__)
-def test_emu_case(eng, case):
+def test_emu_case(eng, case, request):
+    forced = request.node.callspec.params["eng"] not in ("auto", "hostlayout")
+    if forced and case not in P.K1_CASES:
+        pytest.skip("does not depend on the K1 flavour")
     case(eng)

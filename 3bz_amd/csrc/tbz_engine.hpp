@@ -2,13 +2,15 @@
 //
 // One call = one pipeline over a batch of streams, all device-resident:
 //
-//   K0 scan markers ──> host: items ──> K1 huff_decode (one wave per item)
-//        ──> host: follow the landing chain, repair overshoots (K1 fix-up rounds), prefix-sum the
-//            segment sizes, form LZ77 groups, decide per-stream status
-//        ──> K2 lz77 (one wave per group) ──> K4/K5 checksum partials + combine ──> results
+//   K0 scan markers + build items (device) ──> K1 huffman decode (a gang of lanes per item; tokens + run tables)
+//        ──> K3: prove that every item landed on its successor, scan the sizes, write K2's tables (device)
+//            [else, on the host: follow the landing chain, repair overshoots (K1 fix-up rounds), redo
+//             declined items, prefix-sum the segment sizes, form LZ77 groups]
+//        ──> K2 lz77 (one wave per group) ──> K4/K5 checksum partials + combine ──> per-stream status, results
 //
-// The host part between K1 and K2 is control flow over a few records per segment (it reads no
-// stream octets and decodes nothing).  Correctness argument for the speculative markers: item 0 of
+// The host reads 8 bytes + one index per stream after K0, a 16-byte verdict after K1 and one record per
+// stream while K2 runs; its general path is control flow over one record per segment.  It never reads
+// stream octets and decodes nothing.  Correctness argument for the speculative markers: item 0 of
 // a stream starts at a true block boundary; an item is on the chain iff its predecessor on the
 // chain ENDED A BLOCK exactly at its start, so by induction every chained item starts at a true
 // block boundary and the concatenation of their tokens is exactly what a sequential decoder
@@ -284,7 +286,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     K0Params k0{(const u8*)d_in, (const u64*)ctx->d_str_off.p, (const u64*)ctx->d_str_len.p,
                 (const u32*)ctx->d_tile_first.p, (u32)n, (u32)tiles, (u32*)ctx->d_tile_counts.p,
                 (u32*)ctx->d_tile_offsets.p, (u64*)ctx->d_markers.p, (u64*)ctx->d_k0_slots.p,
-                (u32*)ctx->d_k0_fm.p + 2, (u32*)ctx->d_k0_fm.p, (Item*)ctx->d_items.p, (u32)format};
+                (u32*)ctx->d_k0_fm.p + 2, (u32*)ctx->d_k0_fm.p, (Item*)ctx->d_items.p, (u32)format, 0};
     const size_t max_items = tiles * (size_t)K0_SLOTS + n;
     TBZ_LAUNCH(tbz_k0_scan_tiles, tiles, ctx->stream, k0);
     TBZ_LAUNCH(tbz_k0_scan_offsets, 1, ctx->stream, k0);
@@ -300,6 +302,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       if ((r = ensure(ctx, ctx->d_items, ((size_t)n_mark + n) * sizeof(Item)))) return r;
       k0.markers = (u64*)ctx->d_markers.p;
       k0.items = (Item*)ctx->d_items.p;
+      k0.second_pass = 1;
       TBZ_LAUNCH(tbz_k0_scan_emit, tiles, ctx->stream, k0);
       TBZ_LAUNCH(tbz_k0_items, ((size_t)n_mark + n + 63) / 64, ctx->stream, k0);
     }

@@ -102,6 +102,7 @@ struct K0Params {
   u32* head;              // [2]: total markers, tiles whose markers did not fit their slots (scan out)
   Item* items;            // item build out
   u32 format;
+  u32 second_pass;        // items: the marker array was written by the emitting pass
 };
 constexpr u32 K0_SLOTS = 32;  // markers kept per 64 KiB tile by the one-pass scan (flush every 16 KiB of text: ~8)
 
@@ -213,7 +214,8 @@ TBZ_KERNEL void tbz_k0_scan_offsets(K0Params P) {
 TBZ_KERNEL void tbz_k0_compact(K0Params P) {
   const u32 lane = tbz_lane(), t = tbz_block();
   const u32 n = P.tile_counts[t], o = P.tile_offsets[t];
-  if (lane < n && lane < K0_SLOTS) P.markers[o + lane] = P.tile_slots[(u64)t * K0_SLOTS + lane];
+  // crowded tiles (head[1]): the marker array is sized for the slots only; the host runs the emitting pass
+  if (P.head[1] == 0 && lane < n) P.markers[o + lane] = P.tile_slots[(u64)t * K0_SLOTS + lane];
   if (t == 0)
     for (u32 s = lane; s <= P.n_streams; s += 64) P.first_marker[s] = P.tile_offsets[s < P.n_streams ? P.tile_first[s] : P.n_tiles];
 }
@@ -222,7 +224,7 @@ TBZ_KERNEL void tbz_k0_compact(K0Params P) {
 TBZ_KERNEL void tbz_k0_items(K0Params P) {
   const u32 i = tbz_block() * 64 + tbz_lane();
   const u32 n_items = P.head[0] + P.n_streams;
-  if (i >= n_items) return;
+  if (i >= n_items || (P.head[1] != 0 && !P.second_pass)) return;  // crowded tiles: wait for the emitting pass
   u32 lo = 0, hi = P.n_streams;  // first_item[s] = first_marker[s] + s; find s with first_item[s] <= i < first_item[s+1]
   while (hi - lo > 1) {
     const u32 mid = (lo + hi) >> 1;
@@ -2667,25 +2669,27 @@ TBZ_KERNEL void tbz_k4_adler_combine(K4cParams P) {
   if (tbz_block() >= P.n_streams) return;
   const u32 lane = tbz_lane();
   const CkStream cs = P.streams[tbz_block()];
-  u64 s1 = cs.init0 & 0xffff, s2 = cs.init0 >> 16;  // running, < P
+  // everything fits 32 bits: partials and n mod P are < 65521, a row's prefix sum < 64 * 65521, and
+  // (P-1)^2 + (P-1) < 2^32
+  u32 s1 = cs.init0 & 0xffff, s2 = cs.init0 >> 16;  // running, < P
   for (u32 c0 = 0; c0 < cs.count; c0 += 256) {  // four rows of 64 chunks per trip: their loads go out together
-    u64 a[4], b[4], n[4];
+    u32 a[4], b[4], n[4];
 #pragma unroll
     for (u32 q = 0; q < 4; q++) {
       const u32 c = c0 + q * 64 + lane;
       const bool v = c < cs.count;
       a[q] = v ? P.parts[cs.first + c].a : 0;
       b[q] = v ? P.parts[cs.first + c].b : 0;
-      n[q] = v ? P.chunks[cs.first + c].len : 0;
+      n[q] = v ? P.chunks[cs.first + c].len % ADLER_P : 0;
     }
 #pragma unroll
     for (u32 q = 0; q < 4; q++) {
-      const u64 inc = wave_incl_scan_u64(a[q]);
-      const u64 s1_before = (s1 + inc - a[q]) % ADLER_P;
-      const u64 term = ((n[q] % ADLER_P) * s1_before + b[q]) % ADLER_P;  // absent chunks: n = b = 0
-      const u64 tsum = wave_sum_u64(term);
+      const u32 inc = tbz_wave_incl_scan_u32(a[q]);
+      const u32 s1_before = (s1 + inc - a[q]) % ADLER_P;
+      const u32 term = (n[q] * s1_before + b[q]) % ADLER_P;  // absent chunks: n = b = 0
+      const u32 tsum = tbz_shfl(tbz_wave_incl_scan_u32(term), 63);
       s2 = (s2 + tsum) % ADLER_P;
-      s1 = (s1 + tbz_shfl64(inc, 63)) % ADLER_P;
+      s1 = (s1 + tbz_shfl(inc, 63)) % ADLER_P;
     }
   }
   if (lane == 0) P.out[tbz_block()] = (u32)s1 | ((u32)s2 << 16);

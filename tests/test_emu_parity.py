@@ -37,3 +37,28 @@ def test_emu_case(eng, case, request):
     if forced and case not in P.K1_CASES:
         pytest.skip("does not depend on the K1 flavour")
     case(eng)
+
+
+def test_emu_sanitized():
+    """ASan/UBSan are CPU-only on this pool: the kernel + engine sources, compiled with both, run the cases
+    that stress addressing (known-answer vectors; false markers incl. crowded tiles and fix-up rounds).  The
+    whole case list was run this way once per K1 flavour when the kernels last changed."""
+    import sys
+
+    r = subprocess.run(["make", "-C", EMU_DIR, "libtbz_emu_asan.so"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    code = (
+        "import importlib, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from tests import parity_cases as P\n"
+        "T = importlib.import_module('3bz_amd')\n"
+        "eng = T.Engine(0, lib_path=%r)\n"
+        "for c in (P.case_known_answer_vectors, P.case_false_markers):\n"
+        "    c(eng)\n"
+        "eng.close()\n"
+        "print('sanitized ok')\n" % (ROOT, os.path.join(EMU_DIR, "libtbz_emu_asan.so")))
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0")
+    env.pop("TBZ_K1_MODE", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "sanitized ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])

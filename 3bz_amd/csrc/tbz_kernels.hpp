@@ -2248,16 +2248,17 @@ TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks, u32* rcache) {
       const u32 j = j0 + (rel >= e0 ? 1u : 0u) + (rel >= e1 ? 1u : 0u) + (rel >= e2 ? 1u : 0u);
       return (rel < e3 && j0 + 3 < 64) ? j : find_run(rel);
     };
+    u32 jn = 0;  // cached run that holds the first piece of the next chunk (chunks are fetched in order)
     auto cover = [&](u64 x0, u64 xl) {  // make the cache hold pieces x0..xl (a chunk: at most 64 pieces)
       if (xl - cbase < ctot) return;
       if (x0 - cbase < ctot) {
-        const u32 j0 = find_run((u32)(x0 - cbase));
-        cbase += j0 ? rE[j0 - 1] : 0u;
-        rbase += j0;
+        cbase += jn ? rE[jn - 1] : 0u;
+        rbase += jn;
       } else {
         cbase += ctot;
         rbase += 64;
       }
+      jn = 0;
       load_cache();
     };
     auto fetch = [&](u32 c) -> uint4 {  // this lane's piece of chunk c
@@ -2267,13 +2268,15 @@ TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks, u32* rcache) {
       const u64 xl = x0 + 63 < npieces ? x0 + 63 : npieces - 1;
       cover(x0, xl);
       const u64 x = x0 + lane;
-      const u32 j0 = find_run((u32)(x0 - cbase));  // uniform
+      u32 j = jn;
       if (x < npieces) {
         const u32 rel = (u32)(x - cbase);
-        const u32 j = find_run_from(j0, rel);
+        j = find_run_from(jn, rel);
         const u32 before = j ? rE[j - 1] : 0u;
         v = *(const uint4*)(tbase + ((u64)rO[j] + (rel - before)) * 8);
       }
+      const u32 jl = tbz_readlane(j, (u32)(xl - x0));  // the run of the chunk's last piece
+      jn = jl + ((u32)(xl - cbase) + 1 >= rE[jl] ? 1u : 0u);
       return v;
     };
     u32 cur = 0;

@@ -44,6 +44,7 @@ struct tbz_ctx {
   std::string err;
   tbz_timings tim{};
   uint64_t gang_rounds = 0, gang_valid = 0;  // diagnostics of the last call (K1g)
+  bool k2_single = false;    // env TBZ_K2_MODE=single: one wave per group for the linear-window groups too (default: two)
   bool host_layout = false;  // env TBZ_HOST_LAYOUT=1: always chain / lay out on the host (tests force both paths)
   void* h_pin = nullptr;     // pinned host scratch for small read-backs
   size_t h_pin_cap = 0;
@@ -503,9 +504,13 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       K2Params k2{(const u16*)ctx->d_tok.p, (const RunRec*)ctx->d_runs.p, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, nullptr,
                   (const u8*)d_in, (u8*)d_out, n_it, 0, 0};
       if (h_glob->n_big < n_it) {
-        k2.win_bytes = (u32)((h_glob->max_small + K2_SLACK + 255) & ~255ull);
+        k2.win_bytes = (u32)((h_glob->max_small + K2_SLACK + 63) & ~63ull);
         k2.cls = h_glob->n_big ? 1 : 0;
-        TBZ_LAUNCH_DYN(tbz_k2_lz77_small, n_it, k2.win_bytes + 2 * K2_TOKBUF + 512, ctx->stream, k2);
+        if (ctx->k2_single)
+          TBZ_LAUNCH_DYN(tbz_k2_lz77_small, n_it, k2.win_bytes + 2 * K2_TOKBUF + 512, ctx->stream, k2);
+        else
+          TBZ_LAUNCH_DYN_WG(tbz_k2_lz77_dual, n_it, 128, k2.win_bytes + 2 * K2_TOKBUF + 512 + 2 * sizeof(K2Hand),
+                            ctx->stream, k2);
       }
       if (h_glob->n_big) {
         k2.win_bytes = 0;
@@ -719,8 +724,12 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
                 (const u32*)ctx->d_order.p, (const u8*)d_in, (u8*)d_out, 0, 0, 0};
     if (!order_small.empty()) {
       k2.n_groups = (u32)order_small.size();
-      k2.win_bytes = (u32)((max_small + K2_SLACK + 255) & ~255ull);
-      TBZ_LAUNCH_DYN(tbz_k2_lz77_small, order_small.size(), k2.win_bytes + 2 * K2_TOKBUF + 512, ctx->stream, k2);
+      k2.win_bytes = (u32)((max_small + K2_SLACK + 63) & ~63ull);
+      if (ctx->k2_single)
+        TBZ_LAUNCH_DYN(tbz_k2_lz77_small, order_small.size(), k2.win_bytes + 2 * K2_TOKBUF + 512, ctx->stream, k2);
+      else
+        TBZ_LAUNCH_DYN_WG(tbz_k2_lz77_dual, order_small.size(), 128,
+                          k2.win_bytes + 2 * K2_TOKBUF + 512 + 2 * sizeof(K2Hand), ctx->stream, k2);
     }
     if (!order_big.empty()) {
       k2.order = (const u32*)ctx->d_order.p + order_small.size();
@@ -855,6 +864,7 @@ int tbz_ctx_create(int device_id, tbz_ctx** out_ctx) {
   if ((e = hipMemcpy(ctx->d_crc_tab.p, t.data(), t.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
     return fail(e, "hipMemcpy");
   if (const char* m = getenv("TBZ_HOST_LAYOUT")) ctx->host_layout = m[0] == '1';
+  if (const char* m = getenv("TBZ_K2_MODE")) ctx->k2_single = !strcmp(m, "single");
   if (const char* m = getenv("TBZ_K1_MODE")) {
     if (!strcmp(m, "lane")) ctx->k1_mode = 1;
     else if (!strncmp(m, "gang", 4)) {

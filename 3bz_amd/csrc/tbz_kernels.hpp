@@ -998,6 +998,9 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
 // SUB adapts to what is left of the item (the next marker is where the segment is expected to end),
 // so a 16 KiB-segment item is one round.
 // ================================================================================================
+#ifndef K2_EXP
+#define K2_EXP 0
+#endif
 #ifndef KG_EXP
 #define KG_EXP 0
 #endif
@@ -2149,7 +2152,13 @@ TBZ_DEV void k2_resolve(u8* win, u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist
   // writes that cover exactly [rd, rd + len)
   const bool fastable = len <= K2_SHORT && dist >= len && (LINEAR || (rs + 32 <= K2_WIN && rd + 32 <= K2_WIN));
   tbz_sync();
+#if K2_EXP == 1
+  if (pend) {
+#elif K2_EXP == 2
+  if (false) {
+#else
   while (pend) {
+#endif
     const u32 first = (u32)tbz_ffs64(pend) - 1;
     const i32 hwm = (i32)tbz_readlane(dofs, first);
     const bool ready = (pend & lane_bit) && need <= hwm;
@@ -2191,17 +2200,27 @@ TBZ_DEV void k2_resolve(u8* win, u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist
   }
 }
 
-template <bool LINEAR>
-TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks, u32* rcache) {
+// which group this workgroup handles; false: none (beyond the list, or filtered out by size class)
+TBZ_DEV bool k2_pick_group(const K2Params& P, u32& gi, Group& g, Seg& sg_guess) {
+  if (tbz_block() >= P.n_groups) return false;
+  gi = P.order ? P.order[tbz_block()] : tbz_block();
+  sg_guess = P.segs[gi];  // device-built tables (K3) have segment i in group i: fetched along with the group
+  g = P.groups[gi];
+  if (!P.order && P.cls) {  // device-built tables (K3): one segment per group, sorted into launches by size here
+    const bool small = (g.seg_first == gi ? sg_guess : P.segs[g.seg_first]).out_bytes + K2_SLACK <= K2_SMALL_MAX;
+    if ((P.cls == 1) != small) return false;
+  }
+  return true;
+}
+
+// The front end of a group: token fetch, classification, offsets, literals; every batch's matches go to
+// `emit(pend, rpos, dofs, len, dist)` — the resolve step itself in the one-wave kernels, the hand-off to the
+// resolving wave in the two-wave kernel — and `finish()` runs before the final flush.
+template <bool LINEAR, class Emit, class Finish>
+TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_guess, u8* win, u16* tks, u32* rcache,
+                     Emit&& emit, Finish&& finish) {
   const u32 lane = tbz_lane();
   const u64 lane_bit = 1ull << lane;
-  const u32 gi = P.order ? P.order[tbz_block()] : tbz_block();
-  const Seg sg_guess = P.segs[gi];  // device-built tables (K3) have segment i in group i: fetched along with the group
-  const Group g = P.groups[gi];
-  if (!P.order && P.cls) {  // device-built tables (K3): one segment per group, sorted into launches by size here
-    const bool small = P.segs[g.seg_first].out_bytes + K2_SLACK <= K2_SMALL_MAX;
-    if ((P.cls == 1) != small) return;
-  }
   u8* outp = P.out_base + g.out_abs;
   const u32 a0 = (u32)((uintptr_t)outp & 15);
   const u64 clip = g.out_end > g.out_abs ? g.out_end - g.out_abs : 0;
@@ -2332,7 +2351,7 @@ TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks, u32* rcache) {
         const bool hasm = (hav || hbv) && act;
         const u32 len = hav ? len_a : len_b;
         const u32 dist = ((hav ? b : na) & 0x7fffu) + 1;
-        k2_resolve<LINEAR>(win, tbz_ballot(hasm), rpos, hav ? oa : ob, hasm ? len : 0u, dist);
+        emit(tbz_ballot(hasm), rpos, hav ? oa : ob, hasm ? len : 0u, dist);
         pos += total;
         rpos = ring<LINEAR>(rpos + total);
         p += m;
@@ -2390,7 +2409,7 @@ TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks, u32* rcache) {
         u32 dofs = incl - len;  // octet offset of this token inside the batch
         u32 dist = (tbz_wave_shl1(w) & 0x7fffu) + 1;
         if (islit && (act & lane_bit)) win[ring<LINEAR>(rpos + dofs)] = (u8)w;
-        k2_resolve<LINEAR>(win, mb & act, rpos, dofs, len, dist);
+        emit(mb & act, rpos, dofs, len, dist);
         pos += total;
         rpos = ring<LINEAR>(rpos + total);
         p += m;
@@ -2404,6 +2423,7 @@ TBZ_DEV void k2_body(const K2Params& P, u8* win, u16* tks, u32* rcache) {
       }
     }
   }
+  finish();
   k2_flush<LINEAR>(win, outp, flushed, pos, clip, a0);
 }
 
@@ -2411,15 +2431,79 @@ TBZ_KERNEL void tbz_k2_lz77(K2Params P) {
   TBZ_SHARED __attribute__((aligned(16))) u8 win[K2_WIN];
   TBZ_SHARED __attribute__((aligned(16))) u16 tks[K2_TOKBUF];
   TBZ_SHARED u32 rcache[128];
-  if (tbz_block() >= P.n_groups) return;
-  k2_body<false>(P, win, tks, rcache);
+  u32 gi;
+  Group g;
+  Seg sg;
+  if (!k2_pick_group(P, gi, g, sg)) return;
+  k2_body<false>(
+      P, gi, g, sg, win, tks, rcache,
+      [&](u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) { k2_resolve<false>(win, pend, rpos, dofs, len, dist); }, [] {});
 }
 
-// groups whose output (plus 16 octets of alignment slack) fits P.win_bytes
+// groups whose output (plus K2_SLACK octets) fits P.win_bytes, one wave doing everything
 TBZ_KERNEL void tbz_k2_lz77_small(K2Params P) {
   TBZ_DYN_SHARED(u8, dyn);
-  if (tbz_block() >= P.n_groups) return;
-  k2_body<true>(P, dyn, (u16*)(dyn + P.win_bytes), (u32*)(dyn + P.win_bytes + 2 * K2_TOKBUF));
+  u32 gi;
+  Group g;
+  Seg sg;
+  if (!k2_pick_group(P, gi, g, sg)) return;
+  u8* win = dyn;
+  k2_body<true>(
+      P, gi, g, sg, win, (u16*)(dyn + P.win_bytes), (u32*)(dyn + P.win_bytes + 2 * K2_TOKBUF),
+      [&](u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) { k2_resolve<true>(win, pend, rpos, dofs, len, dist); }, [] {});
+}
+
+// The same groups with TWO wavefronts per workgroup over one window: wave 0 runs the front end of batch k
+// (token fetch, classification, prefix sum, literals) while wave 1 resolves the matches of batch k-1; they
+// meet at a workgroup barrier once per batch and hand the match descriptors over through LDS.  Both halves
+// are latency-bound chains, so overlapping them (and doubling the waves per CU at the same LDS) is what pays.
+// Safe because a batch's front end only writes octets at or beyond its own start (literals, stored runs),
+// which the resolve of the previous batch neither reads as a source nor writes.
+struct K2Hand {
+  u64 desc[64];  // per lane: dofs | len << 16 | dist << 32
+  u64 pend;      // lanes holding a match
+  u32 rpos;      // window index of the batch's first octet
+  u32 end;       // 1: no batch — the group is done
+};
+TBZ_KERNEL_WG(128, 2) void tbz_k2_lz77_dual(K2Params P) {
+  TBZ_DYN_SHARED(u8, dyn);
+  u32 gi;
+  Group g;
+  Seg sg;
+  if (!k2_pick_group(P, gi, g, sg)) return;  // both waves take the same decision
+  const u32 lane = tbz_lane();
+  u8* win = dyn;
+  K2Hand* H = (K2Hand*)(dyn + P.win_bytes + 2 * K2_TOKBUF + 512);
+  if (tbz_wave() == 0) {
+    u32 k = 0;
+    k2_body<true>(
+        P, gi, g, sg, win, (u16*)(dyn + P.win_bytes), (u32*)(dyn + P.win_bytes + 2 * K2_TOKBUF),
+        [&](u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) {
+          K2Hand& h = H[k & 1];
+          h.desc[lane] = (u64)dofs | ((u64)len << 16) | ((u64)dist << 32);
+          if (lane == 0) {
+            h.pend = pend;
+            h.rpos = rpos;
+            h.end = 0;
+          }
+          tbz_wg_barrier();
+          k += 1;
+        },
+        [&] {
+          if (lane == 0) H[k & 1].end = 1;
+          tbz_wg_barrier();
+        });
+  } else {
+    for (u32 k = 0;; k++) {
+      if (k > 0) {
+        const K2Hand& h = H[(k - 1) & 1];
+        const u64 d = h.desc[lane];
+        k2_resolve<true>(win, h.pend, h.rpos, (u32)(d & 0xffffu), (u32)((d >> 16) & 0xffffu), (u32)(d >> 32));
+      }
+      tbz_wg_barrier();
+      if (H[k & 1].end) break;
+    }
+  }
 }
 
 // ================================================================================================

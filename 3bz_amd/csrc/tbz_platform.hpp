@@ -29,7 +29,10 @@ using u64 = uint64_t;
 using i32 = int32_t;
 using i64 = int64_t;
 
-TBZ_DEV u32 tbz_lane() { return threadIdx.x; }
+TBZ_DEV u32 tbz_lane() { return threadIdx.x & 63; }   // lane within the wavefront
+TBZ_DEV u32 tbz_wave() { return threadIdx.x >> 6; }   // wavefront within the workgroup (two-wave kernels)
+// the real thing, for the kernels whose workgroup is two wavefronts: LDS drain + s_barrier
+TBZ_DEV void tbz_wg_barrier() { __syncthreads(); }
 TBZ_DEV u32 tbz_block() { return blockIdx.x; }
 TBZ_DEV u32 tbz_nblocks() { return gridDim.x; }
 // Workgroup == one wavefront, and a wave's LDS (and vector-memory) instructions execute in issue order, so
@@ -106,4 +109,7 @@ TBZ_DEV u32 tbz_wave_incl_scan_u32(u32 x) {
   hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3(64), (lds_bytes), (stream), __VA_ARGS__)
 #define TBZ_LAUNCH(kernel, grid, stream, ...) \
   hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3(64), 0, (stream), __VA_ARGS__)
+#define TBZ_LAUNCH_DYN_WG(kernel, grid, threads, lds_bytes, stream, ...) \
+  hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3(threads), (lds_bytes), (stream), __VA_ARGS__)
+#define TBZ_KERNEL_WG(threads, w) extern "C" __global__ __launch_bounds__(threads, w)
 #endif  // TBZ_PLATFORM_HPP_INCLUDED

@@ -44,28 +44,36 @@ struct uint4 {
 };
 
 namespace tbz_emu {
-// 64 lanes = 64 cooperative fibers on ONE OS thread.  Every collective (barrier / ballot / shuffle)
-// is "yield to the next lane"; because convergent code makes every lane execute the same sequence
-// of collectives, one trip round the ring is exactly one barrier.  Deterministic, and ~100x faster
-// than 64 OS threads on a std::barrier.
+// A workgroup = W wavefronts (W = 1 or 2) of 64 lanes = 64*W cooperative fibers on ONE OS thread.  Every
+// wave-level collective (fence / ballot / shuffle) is "yield to the next lane of my wave"; because convergent
+// code makes every lane of a wave execute the same sequence of collectives, one trip round the wave's ring is
+// exactly one barrier.  A WORKGROUP barrier is a trip round the own wave followed by a switch to the other
+// wave until it has reached the same barrier.  Deterministic, and ~100x faster than OS threads on a
+// std::barrier.
 constexpr size_t kStack = 512 << 10;
+constexpr int kMaxLanes = 128;
 struct State {
   ucontext_t main_ctx;
-  ucontext_t fib[64];
-  char* stacks[64] = {};
-  bool done[64];
-  u64 nbar[64];
-  int cur = 0;
-  int ndone = 0;
+  ucontext_t fib[kMaxLanes];
+  char* stacks[kMaxLanes] = {};
+  bool done[kMaxLanes];
+  u64 nbar[kMaxLanes];
+  u64 nwg[kMaxLanes];  // workgroup barriers passed, per lane
+  int cur = 0;         // running fiber: wave = cur >> 6, lane = cur & 63
+  int wcur[2] = {0, 64};  // fiber to resume when a wave is switched back in
+  u64 wgcount[2] = {0, 0};  // workgroup barriers the wave has arrived at
+  int wdone[2] = {0, 0};
+  int nwaves = 1;
   u32 block = 0, nblocks = 0;
   const std::function<void()>* fn = nullptr;
-  volatile u64 slot[64];
+  volatile u64 slot[kMaxLanes];
 #if defined(__SANITIZE_ADDRESS__)
-  void* fake[65] = {};  // [64] = main
+  void* fake[kMaxLanes + 1] = {};  // [kMaxLanes] = main
   const void* main_bottom = nullptr;
   size_t main_size = 0;
 #endif
 };
+constexpr int kMain = kMaxLanes;
 inline State& st() {
   static State s;
   return s;
@@ -78,8 +86,8 @@ inline bool strict() {
 #if defined(__SANITIZE_ADDRESS__)
 inline void san_start(int from, int to) {
   State& s = st();
-  const void* bottom = to == 64 ? s.main_bottom : (const void*)s.stacks[to];
-  size_t size = to == 64 ? s.main_size : kStack;
+  const void* bottom = to == kMain ? s.main_bottom : (const void*)s.stacks[to];
+  size_t size = to == kMain ? s.main_size : kStack;
   __sanitizer_start_switch_fiber(&s.fake[from], bottom, size);
 }
 inline void san_finish(int me) {
@@ -87,28 +95,32 @@ inline void san_finish(int me) {
   const void* ob;
   size_t os;
   __sanitizer_finish_switch_fiber(s.fake[me], &ob, &os);
-  if (me != 64 && !s.main_bottom) { /* learned lazily below */ }
 }
 #else
 inline void san_start(int, int) {}
 inline void san_finish(int) {}
 #endif
-inline void switch_to(int me, int nx) {  // me/nx in 0..63, or 64 for the launcher
+inline void switch_to(int me, int nx) {  // me/nx: fiber index, or kMain for the launcher
   State& s = st();
-  if (nx != 64) s.cur = nx;
+  if (me != kMain) s.wcur[me >> 6] = me;
+  if (nx != kMain) {
+    s.cur = nx;
+    s.wcur[nx >> 6] = nx;
+  }
   san_start(me, nx);
-  swapcontext(me == 64 ? &s.main_ctx : &s.fib[me], nx == 64 ? &s.main_ctx : &s.fib[nx]);
+  swapcontext(me == kMain ? &s.main_ctx : &s.fib[me], nx == kMain ? &s.main_ctx : &s.fib[nx]);
   san_finish(me);
 }
-inline int next_alive(int me) {
+inline int next_alive(int me) {  // next unfinished lane of MY wave
   State& s = st();
+  const int base = me & ~63;
   for (int k = 1; k <= 64; k++) {
-    int c = (me + k) & 63;
+    int c = base | ((me + k) & 63);
     if (!s.done[c]) return c;
   }
   return -1;
 }
-inline void barrier() {
+inline void barrier() {  // wave-level
   State& s = st();
   int me = s.cur;
   s.nbar[me]++;
@@ -116,14 +128,24 @@ inline void barrier() {
   if (nx < 0 || nx == me) return;
   switch_to(me, nx);
 }
+inline void wg_barrier() {
+  State& s = st();
+  barrier();  // every lane of my wave has arrived
+  const int me = s.cur, w = me >> 6, o = w ^ 1;
+  s.nwg[me]++;
+  if (s.wgcount[w] < s.nwg[me]) s.wgcount[w] = s.nwg[me];
+  if (s.nwaves < 2) return;
+  while (s.wgcount[o] < s.nwg[me] && s.wdone[o] < 64) switch_to(me, s.wcur[o]);  // let the other wave catch up
+}
 inline void trampoline() {
   State& s = st();
   san_finish(s.cur);
   int me = s.cur;
   (*s.fn)();
   s.done[me] = true;
-  s.ndone++;
-  for (int i = 0; i < 64; i++)
+  s.wdone[me >> 6]++;
+  const int base = me & ~63;
+  for (int i = base; i < base + 64; i++)
     if (s.done[i] && s.nbar[i] != s.nbar[me]) {
       fprintf(stderr, "tbz_emu: lanes %d and %d executed a different number of collectives (%llu vs %llu): "
               "divergent barrier / ballot / shuffle\n", i, me, (unsigned long long)s.nbar[i],
@@ -131,22 +153,28 @@ inline void trampoline() {
       abort();
     }
   int nx = next_alive(me);
-  if (nx < 0) nx = 64;
-  else s.cur = nx;
+  if (nx < 0) {  // my wave is finished: the other wave, if it still runs, else back to the launcher
+    const int o = (me >> 6) ^ 1;
+    nx = (s.nwaves == 2 && s.wdone[o] < 64) ? s.wcur[o] : kMain;
+  }
+  if (nx != kMain) {
+    s.cur = nx;
+    s.wcur[nx >> 6] = nx;
+  }
 #if defined(__SANITIZE_ADDRESS__)
   {
-    const void* bottom = nx == 64 ? s.main_bottom : (const void*)s.stacks[nx];
-    size_t size = nx == 64 ? s.main_size : kStack;
+    const void* bottom = nx == kMain ? s.main_bottom : (const void*)s.stacks[nx];
+    size_t size = nx == kMain ? s.main_size : kStack;
     __sanitizer_start_switch_fiber(nullptr, bottom, size);  // this fiber is finished
   }
 #endif
-  setcontext(nx == 64 ? &s.main_ctx : &s.fib[nx]);
+  setcontext(nx == kMain ? &s.main_ctx : &s.fib[nx]);
 }
-// run kernel body `fn` for `grid` workgroups of 64 lanes, one workgroup after another
-inline void launch(u32 grid, const std::function<void()>& fn) {
+// run kernel body `fn` for `grid` workgroups of `threads` (64 or 128) lanes, one workgroup after another
+inline void launch(u32 grid, const std::function<void()>& fn, int threads = 64) {
   if (grid == 0) return;
   State& s = st();
-  for (int l = 0; l < 64; l++)
+  for (int l = 0; l < threads; l++)
     if (!s.stacks[l]) s.stacks[l] = (char*)malloc(kStack);
 #if defined(__SANITIZE_ADDRESS__)
   if (!s.main_bottom) {
@@ -162,33 +190,42 @@ inline void launch(u32 grid, const std::function<void()>& fn) {
 #endif
   s.fn = &fn;
   s.nblocks = grid;
+  s.nwaves = threads / 64;
   for (u32 b = 0; b < grid; b++) {
     s.block = b;
-    s.ndone = 0;
-    for (int l = 0; l < 64; l++) {
+    for (int w = 0; w < 2; w++) {
+      s.wcur[w] = w * 64;
+      s.wgcount[w] = 0;
+      s.wdone[w] = w < s.nwaves ? 0 : 64;
+    }
+    for (int l = 0; l < threads; l++) {
       s.done[l] = false;
       s.nbar[l] = 0;
+      s.nwg[l] = 0;
       getcontext(&s.fib[l]);
       s.fib[l].uc_stack.ss_sp = s.stacks[l];
       s.fib[l].uc_stack.ss_size = kStack;
       s.fib[l].uc_link = nullptr;
       makecontext(&s.fib[l], (void (*)())trampoline, 0);
     }
-    switch_to(64, 0);
+    switch_to(kMain, 0);
   }
   s.fn = nullptr;
+  s.nwaves = 1;
 }
-inline u64 xchg(u64 v, u32 src) {
+inline u64 xchg(u64 v, u32 src) {  // value of lane `src` of MY wave
   State& s = st();
   s.slot[s.cur] = v;
   barrier();
-  u64 r = s.slot[src & 63];
+  u64 r = s.slot[(s.cur & ~63) | (int)(src & 63)];
   barrier();
   return r;
 }
 }  // namespace tbz_emu
 
-TBZ_DEV u32 tbz_lane() { return (u32)tbz_emu::st().cur; }
+TBZ_DEV u32 tbz_lane() { return (u32)tbz_emu::st().cur & 63; }
+TBZ_DEV u32 tbz_wave() { return (u32)tbz_emu::st().cur >> 6; }
+TBZ_DEV void tbz_wg_barrier() { tbz_emu::wg_barrier(); }
 TBZ_DEV u32 tbz_block() { return tbz_emu::st().block; }
 TBZ_DEV u32 tbz_nblocks() { return tbz_emu::st().nblocks; }
 TBZ_DEV void tbz_sync() { tbz_emu::barrier(); }
@@ -197,20 +234,21 @@ TBZ_DEV u64 tbz_ballot(bool p) {
   s.slot[s.cur] = p ? 1 : 0;
   tbz_emu::barrier();
   u64 m = 0;
-  for (int i = 0; i < 64; i++) m |= (u64)(s.slot[i] & 1) << i;
+  const int wb = s.cur & ~63;
+  for (int i = 0; i < 64; i++) m |= (u64)(s.slot[wb + i] & 1) << i;
   tbz_emu::barrier();
   return m;
 }
 TBZ_DEV u64 tbz_shfl64(u64 v, int src) { return tbz_emu::xchg(v, (u32)src); }
 TBZ_DEV u64 tbz_shfl_up64(u64 v, unsigned d) {
-  u32 l = (u32)tbz_emu::st().cur;
+  u32 l = (u32)tbz_emu::st().cur & 63;
   return tbz_emu::xchg(v, l >= d ? l - d : l);
 }
-TBZ_DEV u64 tbz_shfl_xor64(u64 v, int m) { return tbz_emu::xchg(v, (u32)tbz_emu::st().cur ^ (u32)m); }
+TBZ_DEV u64 tbz_shfl_xor64(u64 v, int m) { return tbz_emu::xchg(v, ((u32)tbz_emu::st().cur & 63) ^ (u32)m); }
 TBZ_DEV u32 tbz_shfl(u32 v, int src) { return (u32)tbz_emu::xchg(v, (u32)src); }
 TBZ_DEV u32 tbz_shfl_up(u32 v, unsigned d) { return (u32)tbz_shfl_up64(v, d); }
 TBZ_DEV u32 tbz_shfl_down(u32 v, unsigned d) {
-  u32 l = (u32)tbz_emu::st().cur;
+  u32 l = (u32)tbz_emu::st().cur & 63;
   return (u32)tbz_emu::xchg(v, l + d < 64 ? l + d : l);
 }
 TBZ_DEV u32 tbz_shfl_xor(u32 v, int m) { return (u32)tbz_shfl_xor64(v, m); }
@@ -261,17 +299,17 @@ TBZ_DEV u32 tbz_alignbit(u32 hi, u32 lo, u32 o) { return (u32)(((((u64)hi) << 32
 TBZ_DEV u32 tbz_bfe(u32 v, u32 off, u32 n) { return n ? ((v >> (off & 31)) & (n >= 32 ? ~0u : ((1u << n) - 1))) : 0; }
 TBZ_DEV u32 tbz_readlane(u32 v, u32 i) { return (u32)tbz_emu::xchg(v, i); }
 TBZ_DEV u32 tbz_wave_shr1(u32 v) {
-  u32 l = (u32)tbz_emu::st().cur;
+  u32 l = (u32)tbz_emu::st().cur & 63;
   u32 r = (u32)tbz_emu::xchg(v, l ? l - 1 : 0);
   return l ? r : 0;
 }
 TBZ_DEV u32 tbz_wave_shl1(u32 v) {
-  u32 l = (u32)tbz_emu::st().cur;
+  u32 l = (u32)tbz_emu::st().cur & 63;
   u32 r = (u32)tbz_emu::xchg(v, l < 63 ? l + 1 : 63);
   return l < 63 ? r : 0;
 }
 TBZ_DEV u32 tbz_wave_incl_scan_u32(u32 v) {
-  u32 l = (u32)tbz_emu::st().cur;
+  u32 l = (u32)tbz_emu::st().cur & 63;
   for (u32 d = 1; d < 64; d <<= 1) {
     u32 t = (u32)tbz_emu::xchg(v, l >= d ? l - d : l);
     if (l >= d) v += t;
@@ -284,6 +322,9 @@ TBZ_DEV u32 tbz_wave_incl_scan_u32(u32 v) {
   tbz_emu::launch((u32)(grid), [&] { kernel(__VA_ARGS__); })
 #define TBZ_LAUNCH(kernel, grid, stream, ...) \
   tbz_emu::launch((u32)(grid), [&] { kernel(__VA_ARGS__); })
+#define TBZ_LAUNCH_DYN_WG(kernel, grid, threads, lds_bytes, stream, ...) \
+  tbz_emu::launch((u32)(grid), [&] { kernel(__VA_ARGS__); }, (int)(threads))
+#define TBZ_KERNEL_WG(threads, w) static
 
 // ---- the sliver of the HIP runtime the engine uses ----------------------------------------------
 typedef int hipError_t;

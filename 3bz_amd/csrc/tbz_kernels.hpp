@@ -1127,7 +1127,7 @@ TBZ_DEV i32 kg_build(const u8* lens, u32 n, SymT* sorted, u32* lim, u16* dlt, u1
   // 3. canonical parameters (every lane computes them; the leader publishes what the decoders read)
   u32 used = 0, code = 0, off = 0, prev = 0, min_len = 0;
   i32 left = 1, err = 0;
-  u32 offp[8], limr[15];
+  u32 offp[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) offp[k] = 0;
 #pragma unroll
@@ -1141,10 +1141,10 @@ TBZ_DEV i32 kg_build(const u8* lens, u32 n, SymT* sorted, u32* lim, u16* dlt, u1
     code = (code + prev) << 1;
     prev = c;
     offp[L >> 1] |= off << ((L & 1) * 16);
-    limr[L - 1] = (code + c) << (16 - L);
+    const u32 limL = (code + c) << (16 - L);
     if (leader && n) {
       dlt[L] = (u16)(off - code);
-      lim[L - 1] = limr[L - 1];
+      lim[L - 1] = limL;
     }
     off += c;
   }
@@ -1168,6 +1168,7 @@ TBZ_DEV i32 kg_build(const u8* lens, u32 n, SymT* sorted, u32* lim, u16* dlt, u1
       sorted[(v >> sh) & 0xffffu] = (SymT)i;
     }
   }
+  tbz_sync();  // the limits are read back from LDS below (keeps fifteen registers free for the rest of the kernel)
   // 5. second-level sizes: a prefix whose codes are longer than TB bits gets 2^(longest - TB) pool entries.
   //    Lane g owns the left-aligned (MSB-first) prefixes [g*R, (g+1)*R); long prefixes are the ones at or
   //    above the first value no code of <= TB bits reaches.
@@ -1181,11 +1182,11 @@ TBZ_DEV i32 kg_build(const u8* lens, u32 n, SymT* sorted, u32* lim, u16* dlt, u1
 #pragma nounroll
     for (u32 t = 0; t < R; t++) {
       const u32 r16 = (r0 + t) << SH;
-      if (r16 < limr[TB - 1]) continue;
+      if (r16 < lim[TB - 1]) continue;
       const u32 last = r16 | ((1u << SH) - 1);
       u32 Lm = TB + 1;
 #pragma unroll
-      for (u32 q = TB; q < 15; q++) Lm += last >= limr[q] ? 1u : 0u;
+      for (u32 q = TB; q < 15; q++) Lm += last >= lim[q] ? 1u : 0u;
       if (Lm <= 15) need += 1u << (Lm - TB);
     }
   }
@@ -1207,7 +1208,7 @@ TBZ_DEV i32 kg_build(const u8* lens, u32 n, SymT* sorted, u32* lim, u16* dlt, u1
         const u32 r16 = r << SH;
         u32 L = 1;
 #pragma unroll
-        for (int k = 0; k < 15; k++) L += r16 >= limr[k] ? 1u : 0u;
+        for (int k = 0; k < 15; k++) L += r16 >= lim[k] ? 1u : 0u;
         if (L <= TB) {
           const u32 slot = ((r16 >> (16 - L)) + dlt[L]) & 0xffffu;
           const u32 sym = sorted[slot < n ? slot : 0];
@@ -1217,7 +1218,7 @@ TBZ_DEV i32 kg_build(const u8* lens, u32 n, SymT* sorted, u32* lim, u16* dlt, u1
           const u32 last = r16 | ((1u << SH) - 1);
           u32 Lm = TB + 1;
 #pragma unroll
-          for (u32 q = TB; q < 15; q++) Lm += last >= limr[q] ? 1u : 0u;
+          for (u32 q = TB; q < 15; q++) Lm += last >= lim[q] ? 1u : 0u;
           entry = 0;
           if (L <= 15 && Lm <= 15) {
             if (two) entry = ((Lm - TB) << 4) | (poff << 7);

@@ -40,6 +40,33 @@ TBZ_DEV void tbz_wg_barrier() {
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+TBZ_DEV u32 tbz_block() { return blockIdx.x; }
+TBZ_DEV u32 tbz_nblocks() { return gridDim.x; }
+// Workgroup == one wavefront, and a wave's LDS (and vector-memory) instructions execute in issue order, so
+// "all lanes' earlier accesses are visible to all lanes' later ones" needs no s_barrier and no s_waitcnt:
+// a wavefront-scope fence (compiler ordering only) is the whole synchronisation.  In particular it does
+// not drain vmcnt, so prefetches and stores stay in flight across it.
+TBZ_DEV void tbz_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+TBZ_DEV u64 tbz_ballot(bool p) { return __ballot(p); }
+TBZ_DEV u32 tbz_shfl(u32 v, int src) { return (u32)__shfl((int)v, src, 64); }
+TBZ_DEV u32 tbz_shfl_up(u32 v, unsigned d) { return (u32)__shfl_up((int)v, d, 64); }
+TBZ_DEV u32 tbz_shfl_down(u32 v, unsigned d) { return (u32)__shfl_down((int)v, d, 64); }
+TBZ_DEV u32 tbz_shfl_xor(u32 v, int m) { return (u32)__shfl_xor((int)v, m, 64); }
+TBZ_DEV u64 tbz_shfl64(u64 v, int src) {
+  u32 lo = tbz_shfl((u32)v, src), hi = tbz_shfl((u32)(v >> 32), src);
+  return ((u64)hi << 32) | lo;
+}
+TBZ_DEV u64 tbz_shfl_up64(u64 v, unsigned d) {
+  u32 lo = tbz_shfl_up((u32)v, d), hi = tbz_shfl_up((u32)(v >> 32), d);
+  return ((u64)hi << 32) | lo;
+}
+TBZ_DEV u64 tbz_shfl_xor64(u64 v, int m) {
+  u32 lo = tbz_shfl_xor((u32)v, m), hi = tbz_shfl_xor((u32)(v >> 32), m);
+  return ((u64)hi << 32) | lo;
+}
 // value of the first active lane, as a wave-uniform (SGPR) value: lets the compiler keep the
 // sequential part of the decoders on the scalar unit
 TBZ_DEV u32 tbz_uniform(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }

@@ -44,6 +44,7 @@ struct tbz_ctx {
   std::string err;
   tbz_timings tim{};
   uint64_t gang_rounds = 0, gang_valid = 0;  // diagnostics of the last call (K1g)
+  bool k1h = true;           // env TBZ_K1H=0: no header pre-pass (the gang leaders parse every header)
   bool k2_single = false;    // env TBZ_K2_MODE=single: one wave per group for the linear-window groups too (default: two)
   bool host_layout = false;  // env TBZ_HOST_LAYOUT=1: always chain / lay out on the host (tests force both paths)
   void* h_pin = nullptr;     // pinned host scratch for small read-backs
@@ -52,7 +53,7 @@ struct tbz_ctx {
   // device pools (grow-only)
   tbz::DevBuf d_str_off, d_str_len, d_tile_first, d_tile_counts, d_tile_offsets, d_markers, d_items, d_res,
       d_tok, d_scratch, d_runs, d_segs, d_groups, d_order, d_k3_fi, d_k3_ni, d_k3_oo, d_k3_oc, d_k3_sums, d_k3_flags,
-      d_k3_gscan, d_k3_gne, d_k3_streams, d_k3_glob, d_redo_items, d_redo_res, d_k0_slots, d_k0_fm, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
+      d_k3_gscan, d_k3_gne, d_k3_streams, d_k3_glob, d_redo_items, d_redo_res, d_k0_slots, d_k0_fm, d_hdr, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
       d_out_stage;
 };
 
@@ -412,8 +413,16 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     int G = k1_gang(n_it);
     if (G == 1) return launch_lane(d_items, d_res, n_it);
     size_t per = 64 / G, nwg = (n_it + per - 1) / per;
+    // K1h: every lane parses the first block header of its own item, so that the gangs need not (their leaders
+    // would do it with 2 of 64 lanes busy)
+    int rr;
+    if ((rr = ensure(ctx, ctx->d_scratch, n_it * (size_t)K1_SCRATCH))) return rr;
+    if ((rr = ensure(ctx, ctx->d_hdr, n_it * sizeof(HdrRec)))) return rr;
+    K1hParams kh{(const u8*)d_in, d_items, (u8*)ctx->d_scratch.p, (HdrRec*)ctx->d_hdr.p, (u32)n_it};
+    if (ctx->k1h) TBZ_LAUNCH(tbz_k1h_headers, (n_it + 63) / 64, ctx->stream, kh);
     K1gParams kg{(const u8*)d_in, (u16*)ctx->d_tok.p, (RunRec*)ctx->d_runs.p, d_items, d_res,
-                 (const u64*)ctx->d_markers.p, d_first_marker, (u32)n_mark, (u32)n_it};
+                 (const u64*)ctx->d_markers.p, d_first_marker, ctx->k1h ? (const HdrRec*)ctx->d_hdr.p : nullptr,
+                 (const u8*)ctx->d_scratch.p, (u32)n_mark, (u32)n_it};
     switch (G) {
       case 8: TBZ_LAUNCH(tbz_k1g8_huff_decode, nwg, ctx->stream, kg); break;
       case 16: TBZ_LAUNCH(tbz_k1g16_huff_decode, nwg, ctx->stream, kg); break;
@@ -865,6 +874,7 @@ int tbz_ctx_create(int device_id, tbz_ctx** out_ctx) {
     return fail(e, "hipMemcpy");
   if (const char* m = getenv("TBZ_HOST_LAYOUT")) ctx->host_layout = m[0] == '1';
   if (const char* m = getenv("TBZ_K2_MODE")) ctx->k2_single = !strcmp(m, "single");
+  if (const char* m = getenv("TBZ_K1H")) ctx->k1h = m[0] != '0';
   if (const char* m = getenv("TBZ_K1_MODE")) {
     if (!strcmp(m, "lane")) ctx->k1_mode = 1;
     else if (!strncmp(m, "gang", 4)) {
@@ -885,7 +895,7 @@ void tbz_ctx_destroy(tbz_ctx* ctx) {
                          &ctx->d_segs, &ctx->d_groups, &ctx->d_ck_chunks, &ctx->d_ck_parts, &ctx->d_ck_streams,
                          &ctx->d_ck_out, &ctx->d_crc_tab, &ctx->d_in_stage, &ctx->d_out_stage, &ctx->d_k3_fi, &ctx->d_k3_ni,
                          &ctx->d_k3_oo, &ctx->d_k3_oc, &ctx->d_k3_sums, &ctx->d_k3_flags, &ctx->d_k3_gscan, &ctx->d_k3_gne,
-                         &ctx->d_k3_streams, &ctx->d_k3_glob, &ctx->d_redo_items, &ctx->d_redo_res, &ctx->d_k0_slots, &ctx->d_k0_fm};
+                         &ctx->d_k3_streams, &ctx->d_k3_glob, &ctx->d_redo_items, &ctx->d_redo_res, &ctx->d_k0_slots, &ctx->d_k0_fm, &ctx->d_hdr};
   for (auto* b : bufs)
     if (b->p) hipFree(b->p);
   if (ctx->h_pin) hipHostFree(ctx->h_pin);

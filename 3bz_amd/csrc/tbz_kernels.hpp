@@ -554,7 +554,8 @@ TBZ_DEV i32 k1_build_fixed(K1Lds& S, K1State& st, K1Tables& T, u8* sc) {
 }
 
 // :dynamic-huffman-block … :dht-len-table-data (deflate.lisp:577-669)
-TBZ_DEV i32 k1_dynamic_header(K1Lds& S, K1State& st, K1Tables& T, u8* sc) {
+// `sizes` != nullptr: stop once the code lengths are in `sc` and report hlit | hdist << 16 there (K1h)
+TBZ_DEV i32 k1_dynamic_header(K1Lds& S, K1State& st, K1Tables& T, u8* sc, u32* sizes = nullptr) {
   const u64 p0 = st.br.pos;
   u32 pk = br_peek(st.br);
   u32 hlit = (pk & 31) + 257, hdist = ((pk >> 5) & 31) + 1, hclen = ((pk >> 10) & 15) + 4;
@@ -612,6 +613,10 @@ TBZ_DEV i32 k1_dynamic_header(K1Lds& S, K1State& st, K1Tables& T, u8* sc) {
       for (u32 k = 0; k < rep; k++) lens[i + k] = (u8)val;
       i += rep;
     }
+  }
+  if (sizes) {
+    *sizes = hlit | (hdist << 16);
+    return 0;
   }
   e = build_canon(lens, hlit, k1_tmp(S), k1_cs_lit(S, sc), T.ll);
   if (e) return e;
@@ -972,6 +977,63 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
   r.reserved = 0;
   P.res[idx] = r;
 }
+// K1h — header pre-pass for the gang kernel.  Parsing a dynamic block's code lengths is a serial job for ONE
+// lane; inside the gang kernel that is the gang leader alone, i.e. 2 of a wave's 64 lanes busy for ~17 % of
+// the kernel's instructions.  Here every lane parses the FIRST block header of its own item (64 per wave),
+// leaves the code lengths in the item's scratch and the sizes / positions in a HdrRec; the gang kernel picks
+// them up and goes straight to the (gang-parallel) build.  Anything unusual (not a dynamic block, error,
+// underrun, limit) is simply not recorded: the gang kernel then parses that header itself, with the exact
+// failure rules.
+struct HdrRec {
+  u64 hdr_bit;   // position of the block's 3 header bits
+  u64 end_bit;   // position after the code lengths
+  u32 sizes;     // hlit | hdist << 16; 0 = nothing recorded
+  u32 pad;
+};
+struct K1hParams {
+  const u8* in_base;
+  const Item* items;
+  u8* scratch;   // n_items * K1_SCRATCH: the code lengths
+  HdrRec* hdr;
+  u32 n_items;
+};
+TBZ_KERNEL void tbz_k1h_headers(K1hParams P) {
+  TBZ_SHARED K1Lds S;
+  const u32 lane = tbz_lane();
+  const u32 idx = tbz_block() * 64 + lane;
+  if (idx >= P.n_items) return;  // no collectives below: lanes are independent
+  const Item it = P.items[idx];
+  const u32 fmt = (it.flags >> ITEM_FMT_SHIFT) & 3;
+  K1State st;
+  K1Tables T;
+  br_init(st.br, P.in_base, it.end_byte, S.inbuf);
+  br_seek(st.br, it.start_bit);
+  st.end_bit = it.end_byte * 8;
+  st.limit_bit = (it.flags & ITEM_FIXUP) ? ~0ull : it.limit_bit;
+  st.produced = 0;
+  st.deficit = 0;
+  st.tok0 = st.tok = nullptr;
+  st.fail_pos = it.start_bit;
+  HdrRec h;
+  h.hdr_bit = h.end_bit = 0;
+  h.sizes = 0;
+  h.pad = 0;
+  i32 status = 0;
+  if (it.flags & ITEM_HEAD) status = k1_container_header(st, fmt);
+  if (status == 0) {
+    h.hdr_bit = st.br.pos;
+    const u32 pk = br_peek(st.br);
+    br_skip(st.br, 3);
+    if (st.br.pos <= st.end_bit && st.br.pos <= st.limit_bit && ((pk >> 1) & 3) == 2) {
+      u32 sizes = 0;
+      if (k1_dynamic_header(S, st, T, P.scratch + (u64)idx * K1_SCRATCH, &sizes) == 0) {
+        h.end_bit = st.br.pos;
+        h.sizes = sizes;
+      }
+    }
+  }
+  P.hdr[idx] = h;
+}
 #undef K1_CHECK
 
 // ================================================================================================
@@ -1008,6 +1070,7 @@ constexpr u32 KG_TBL = 9;               // index bits of the literal/length look
 constexpr u32 KG_TBD = 8;               // index bits of the distance lookup table (first level)
 constexpr u32 KG_LPOOL = 352;           // second-level entries (codes longer than the index); zlib's ENOUGH bound is 340
 constexpr u32 KG_DPOOL = 128;           //   … if a code needs more, its long codes take the exact (slow) step instead
+constexpr u32 KG_RING_STRIDE = 36;     // LDS octets per lane of the token output ring (16 words + one dword of skew)
 constexpr u32 KG_SUB_MIN = 1024;        // bits of bitstream per lane per round
 constexpr u32 KG_SUB_MAX = 8192;
 #ifndef KG_OVL_BITS
@@ -1044,7 +1107,8 @@ struct GangState {  // per gang, in LDS; owned by the leader
   i32 status;
   u32 mode, bfinal, deficit, tables, land, tr0, tr1, tr_have;
   u32 nruns, blk_runs;      // runs recorded so far / at the start of the current block
-  u32 hlit, hdist, fixed;   // GM_BUILD: alphabet sizes; fixed: the lanes write the fixed code lengths first
+  u32 hlit, hdist, fixed;   // GM_BUILD: alphabet sizes; fixed: 1 the lanes write the fixed code lengths first,
+                            //   2 they copy the lengths K1h left in the item's scratch
   u32 rounds, valid_lanes;  // diagnostics: rounds run and lanes committed (efficiency = valid_lanes / (G*rounds))
   u32 pad[3];
 };
@@ -1053,6 +1117,7 @@ struct KgLds {
   GangTables gt[64 / G];
   GangState gs[64 / G];
   u32 inbuf[K1_INBUF][64];
+  u8 tokring[64 * KG_RING_STRIDE];  // per lane: 16 token words on their way to memory (see TokOut)
 };
 
 struct K1gParams {
@@ -1063,6 +1128,8 @@ struct K1gParams {
   SegResult* res;
   const u64* markers;
   const u32* first_marker;  // [n_streams+1]
+  const HdrRec* hdr;        // K1h's records (nullptr: none), and the code lengths they refer to
+  const u8* hdr_lens;       //   … at hdr_lens[item * K1_SCRATCH ...]
   u32 n_markers;
   u32 n_items;
 };
@@ -1429,6 +1496,25 @@ struct RoundOut {
   i32 mdef;  // max over recorded matches of (distance - octets this lane produced before the match)
   u32 flag;
 };
+// A lane's token output.  Storing every token straight to memory is a 2- or 4-octet store per lane into 64
+// different cache lines per instruction, and the lines leave L2 partly written (measured: 4.7 GB of write
+// traffic for 1.3 GB of tokens, 0.75 ms of the kernel).  Instead the words go through a 16-word ring in LDS
+// (stride of 9 dwords per lane: conflict-free) and leave as whole 16-octet pieces.
+struct TokOut {
+  u8* ring;    // this lane's 32 octets of LDS
+  u16* stage;  // where the run goes in the token pool (16-octet aligned)
+  u32 n;       // words produced
+  u32 nf;      // words already stored (multiple of 8)
+};
+TBZ_DEV void tok_put(TokOut& t, u32 w) { *(u16*)(t.ring + ((t.n & 15) << 1)) = (u16)w; }
+TBZ_DEV void tok_put2(TokOut& t, u32 w) {  // words n and n+1 from the halves of w
+  *(u16*)(t.ring + ((t.n & 15) << 1)) = (u16)w;
+  *(u16*)(t.ring + (((t.n + 1) & 15) << 1)) = (u16)(w >> 16);
+}
+TBZ_DEV void tok_flush_piece(TokOut& t) {  // the oldest 8 words
+  *(uint4*)(t.stage + t.nf) = *(const uint4*)(t.ring + ((t.nf & 15) << 1));
+  t.nf += 8;
+}
 struct __attribute__((packed, aligned(2))) U32at2 {  // two token words stored at once
   u32 v;
 };
@@ -1440,10 +1526,11 @@ struct __attribute__((packed, aligned(2))) U32at2 {  // two token words stored a
 // iteration is straight-line code: both table lookups, the window advance and one 32-bit token store
 // are unconditional, only second-level lookups (long codes) branch.
 template <bool REC>
-TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, u16* stage, u32 cap, u32& n_, u32& out_,
+TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, TokOut& to, u32 cap, u32& out_,
                     i32& mdef_) {
   const u32 lane = tbz_lane();
-  u32 n = n_, out = out_;
+  u32 out = out_;
+  u32& n = to.n;
   i32 mdef = mdef_;
   u32 ret;
   for (;;) {
@@ -1510,12 +1597,15 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, u
         // literal: 0x00bb (the high half is the second literal of a pair, or overwritten by the next token);
         // match: head | payload << 16
 #if KG_EXP != 4
-        ((U32at2*)(stage + n))->v = isM ? (TOK_MATCH | lenx | ((dist - 1) << 16)) : (lenx | (((e2 >> 4) & 0xffu) << 16));
+        tok_put2(to, isM ? (TOK_MATCH | lenx | ((dist - 1) << 16)) : (lenx | (((e2 >> 4) & 0xffu) << 16)));
 #endif
         const i32 d = (i32)dist - (i32)out;
         mdef = isM & (d > mdef) ? d : mdef;
         n += (isM | pair) ? 2u : 1u;
         out += isM ? lenx + 3 : (pair ? 2u : 1u);
+      }
+      if (REC && (it & 1)) {  // every other token: a whole 16-octet piece leaves the ring (at most 4 words came in)
+        if (to.n - to.nf >= 8) tok_flush_piece(to);
       }
       it++;
       go = (it < K1_PHASE) & (k + 2 <= K1_INBUF) & (rel < tgt);
@@ -1529,7 +1619,6 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, u
     if (bad) { ret = 1; break; }
     if (rel >= tgt) { ret = 0; break; }
   }
-  n_ = n;
   out_ = out;
   mdef_ = mdef;
   return ret;
@@ -1548,7 +1637,7 @@ TBZ_DEV u32 kg_canon_lds(u32 pk, const u32* lim, const u16* dlt, u32 cap, u32& s
 // The exact step: decode ONE token at the reader's position the long way (no lookup tables), with the
 // reference's failure rules.  Returns 0 if it was a literal or match inside the limit (consumed, and
 // recorded when `rec`); otherwise fills ro.flag / ro.e / ro.aux and returns 1.
-TBZ_DEV u32 kg_exact_step(const GangTables& gt, BitReader& B, u64 lim64, bool rec, u16* stage, u32& n, u32& out, i32& mdef,
+TBZ_DEV u32 kg_exact_step(const GangTables& gt, BitReader& B, u64 lim64, bool rec, TokOut& to, u32& out, i32& mdef,
                           RoundOut& ro) {
   const u64 p0 = B.pos;
   br_seek_fill(B, p0);
@@ -1579,9 +1668,10 @@ TBZ_DEV u32 kg_exact_step(const GangTables& gt, BitReader& B, u64 lim64, bool re
       return 1;
     }
     if (rec) {
-      stage[n] = (u16)sym;
-      n += 1;
+      tok_put(to, sym);
+      to.n += 1;
       out += 1;
+      if (to.n - to.nf >= 8) tok_flush_piece(to);
     }
     return 0;
   }
@@ -1615,10 +1705,10 @@ TBZ_DEV u32 kg_exact_step(const GangTables& gt, BitReader& B, u64 lim64, bool re
   if (rec) {
     const i32 d = (i32)dist - (i32)out;
     mdef = d > mdef ? d : mdef;
-    stage[n] = (u16)(TOK_MATCH | (len - 3));
-    stage[n + 1] = (u16)(dist - 1);
-    n += 2;
+    tok_put2(to, (TOK_MATCH | (len - 3)) | ((dist - 1) << 16));
+    to.n += 2;
     out += len;
+    if (to.n - to.nf >= 8) tok_flush_piece(to);
   }
   return 0;
 }
@@ -1626,14 +1716,18 @@ TBZ_DEV u32 kg_exact_step(const GangTables& gt, BitReader& B, u64 lim64, bool re
 // One lane's share of a round: decode from `start`; tokens that start before rec_from are the run-up
 // (not recorded), the ones from there to the first token start >= stop are staged.
 TBZ_DEV void kg_lane_round(const GangTables& gt, BitReader& B, u64 start, u64 rec_from, u64 stop, u64 lim64,
-                           u16* stage, u32 cap, RoundOut& ro) {
-  u32 n = 0, out = 0;
+                           u16* stage, u8* ring, u32 cap, RoundOut& ro) {
+  TokOut to;
+  to.ring = ring;
+  to.stage = stage;
+  to.n = to.nf = 0;
+  u32 out = 0;
   i32 mdef = -(1 << 30);
   br_seek_fill(B, start);
   bool junk = false;
   while (B.pos < rec_from) {  // run-up
-    if (kg_span<false>(gt, B, rec_from, lim64, stage, cap, n, out, mdef) == 0) break;
-    if (kg_exact_step(gt, B, lim64, false, stage, n, out, mdef, ro)) {
+    if (kg_span<false>(gt, B, rec_from, lim64, to, cap, out, mdef) == 0) break;
+    if (kg_exact_step(gt, B, lim64, false, to, out, mdef, ro)) {
       junk = true;  // ended (end-of-block / failure) during the run-up: nothing of this lane can be valid
       break;
     }
@@ -1648,15 +1742,19 @@ TBZ_DEV void kg_lane_round(const GangTables& gt, BitReader& B, u64 start, u64 re
   }
   ro.c = B.pos;
   for (;;) {
-    if (kg_span<true>(gt, B, stop, lim64, stage, cap, n, out, mdef) == 0) {
+    if (kg_span<true>(gt, B, stop, lim64, to, cap, out, mdef) == 0) {
       ro.flag = RF_STOP;
       ro.e = B.pos;
       ro.aux = B.pos;
       break;
     }
-    if (kg_exact_step(gt, B, lim64, true, stage, n, out, mdef, ro)) break;
+    if (kg_exact_step(gt, B, lim64, true, to, out, mdef, ro)) break;
   }
-  ro.n = n;
+  // the run is stored in whole 8-word granules: pad with no-ops and let the last pieces out
+  ro.n = to.n;
+  const u32 n8 = (to.n + 7) >> 3;
+  for (u32 k = to.n; k < n8 * 8; k++) *(u16*)(to.ring + ((k & 15) << 1)) = (u16)TOK_NOP;
+  while (to.nf < n8 * 8) tok_flush_piece(to);
   ro.out = out;
   ro.mdef = mdef;
 }
@@ -1727,7 +1825,7 @@ TBZ_DEV void kg_block_end(GangState& gs, K1State& st, const Item& it, const K1gP
 // leader: block header at gs.P (deflate.lisp:518-573); stored blocks are handled completely here,
 // Huffman blocks leave the gang in GM_BUILD (or GM_BLOCK when the fixed code is already loaded)
 TBZ_DEV void kg_leader_header(GangTables& gt, GangState& gs, K1State& st, const Item& it, const K1gParams& P,
-                              u16* tok0, u32 fmt, bool fixup) {
+                              u16* tok0, u32 fmt, bool fixup, u32 idx) {
   br_seek_fill(st.br, gs.P);
   gs.blk_pos = gs.P;
   gs.blk_prod = gs.produced;
@@ -1788,6 +1886,18 @@ TBZ_DEV void kg_leader_header(GangTables& gt, GangState& gs, K1State& st, const 
       gs.mode = GM_BUILD;
     }
     return;
+  }
+  if (P.hdr) {  // K1h parsed this header already
+    const HdrRec h = P.hdr[idx];
+    if (h.sizes && h.hdr_bit == gs.blk_pos) {
+      gs.tables = 2;
+      gs.hlit = h.sizes & 0xffffu;
+      gs.hdist = h.sizes >> 16;
+      gs.fixed = 2;
+      gs.P = h.end_bit;
+      gs.mode = GM_BUILD;
+      return;
+    }
   }
   const i32 e = kg_dynamic_header(gt, gs, st);
   gs.tables = 2;
@@ -1862,7 +1972,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     tbz_sync();
     if (tbz_ballot(gs.mode != GM_DONE) == 0) break;
     // ---- H: leaders whose gang is between blocks parse the next header
-    if (leader && gs.mode == GM_HEADER) kg_leader_header(gt, gs, st, it, P, tok0, fmt, fixup);
+    if (leader && gs.mode == GM_HEADER) kg_leader_header(gt, gs, st, it, P, tok0, fmt, fixup, idx);
 #if KG_EXP == 3
     if (leader) { gs.mode = GM_DONE; if (gs.status == 0) gs.status = E_BTYPE; }
 #endif
@@ -1871,7 +1981,11 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     const bool building = gs.mode == GM_BUILD;
     if (tbz_ballot(building) != 0) {
       const u32 nl = building ? gs.hlit : 0, nd = building ? gs.hdist : 0;
-      if (building && gs.fixed)  // fixed code lengths: huffman-tree.lisp:89-97
+      if (building && gs.fixed == 2) {  // the code lengths K1h decoded
+        const u8* src = P.hdr_lens + (u64)idx * K1_SCRATCH;
+#pragma nounroll
+        for (u32 i = g * 4; i < 320; i += G * 4) *(u32*)(kg_lens(gt) + i) = *(const u32*)(src + i);
+      } else if (building && gs.fixed)  // fixed code lengths: huffman-tree.lisp:89-97
 #pragma nounroll
         for (u32 i = g; i < 320; i += G) kg_lens(gt)[i] = (u8)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5);
       tbz_sync();
@@ -1917,7 +2031,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
       const u64 start = g == 0 ? Pb : s_g - KG_OVL;
       s_lo = s_g & ~7ull;
       stage = P.tok + s_lo;  // private region of the token pool: [s_g & ~7, (s_g + sub) & ~7), 16-octet aligned
-      kg_lane_round(gt, st.br, start, s_g, s_g + sub, lim64, stage, sub - 16, ro);
+      kg_lane_round(gt, st.br, start, s_g, s_g + sub, lim64, stage, S.tokring + lane * KG_RING_STRIDE, sub - 16, ro);
     }
     // ---- chain validation: lane g counts iff it began recording exactly where lane g-1 stopped
     const u32 pe_lo = tbz_wave_shr1((u32)ro.e), pe_hi = tbz_wave_shr1((u32)(ro.e >> 32));
@@ -1949,10 +2063,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     // and the table must not outgrow the item's span; else the item is left to the one-lane kernel
     const u64 end_lv = tbz_shfl64(s_lo + nn, (int)lv);
     const bool fits = !inblk || (end_lv <= (e_last & ~7ull) && gs.nruns + tot_r <= kg_run_slots(it, e_last));
-    if (hasrun && fits) {
-#pragma unroll
-      for (u32 k = 0; k < 7; k++)
-        if (ro.n + k < n8 * 8) stage[ro.n + k] = (u16)TOK_NOP;
+    if (hasrun && fits) {  // (the lane has padded its run to the granule already)
       RunRec rr;
       rr.off8 = (u32)((s_lo - it.start_bit) >> 3);
       rr.n8 = n8;

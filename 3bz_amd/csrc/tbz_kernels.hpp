@@ -298,8 +298,8 @@ constexpr u32 TOK_MATCH = 0x8000u, TOK_STORED = 0xC000u, TOK_NOP = 0x4000u;
 
 constexpr u32 K1_SCRATCH = 512;   // octets of global scratch per item: lens[320] (code lengths while a header is parsed)
 constexpr u32 K1_SC_LENS = 0;
-constexpr u32 K1_INBUF = 20;      // 32-bit words of compressed input windowed per lane (80 octets); multiple of 4
-constexpr u32 K1_PHASE = 48;      // tokens decoded per phase between window reloads
+constexpr u32 K1_INBUF = 16;      // 32-bit words of compressed input windowed per lane (64 octets); multiple of 4
+constexpr u32 K1_PHASE = 32;      // tokens decoded per phase between window reloads
 constexpr u32 K1_LCAP = 288;      // every lit/len symbol (canonical order) is held in LDS per lane
 
 // Per-workgroup LDS, every array LANE-INTERLEAVED ([index][lane]): the bank depends on the lane only, so

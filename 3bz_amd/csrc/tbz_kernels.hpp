@@ -134,13 +134,18 @@ TBZ_DEV K0Tile k0_tile(const K0Params& P) {
 
 // 16-bit mask of marker-pattern starts among the 16 octets at address c owned by this lane:
 // octet address q is a hit iff q..q+3 = 00 00 FF FF, q >= s_lo and q + 4 < s_hi
-TBZ_DEV u32 k0_row_mask(const K0Tile& T, uintptr_t c) {
-  const u32 lane = tbz_lane();
+// this lane's aligned 16-octet chunk at address c (zeros outside the stream): an aligned chunk that holds at
+// least one octet of the stream lies inside a mapped page
+TBZ_DEV uint4 k0_load(const K0Tile& T, uintptr_t c) {
   uint4 v{};
-  // an aligned 16-octet chunk that holds at least one octet of the stream lies inside a mapped page
   if (c < T.s_hi && c + 16 > T.s_lo) v = *(const uint4*)c;
+  return v;
+}
+// `v` = k0_load(T, c) of every lane, `after` = the dword that follows lane 63's chunk
+TBZ_DEV u32 k0_row_mask(const K0Tile& T, uintptr_t c, uint4 v, u32 after) {
+  const u32 lane = tbz_lane();
   u32 nx = tbz_wave_shl1(v.x);
-  if (lane == 63 && c + 16 < T.s_hi) nx = *(const u32*)(c + 16);
+  if (lane == 63) nx = after;
   const u32 ref = 0xFFFF0000u;
   const u64 q0 = tbz_qsad4(((u64)v.y << 32) | v.x, ref), q1 = tbz_qsad4(((u64)v.z << 32) | v.y, ref);
   const u64 q2 = tbz_qsad4(((u64)v.w << 32) | v.z, ref), q3 = tbz_qsad4(((u64)nx << 32) | v.w, ref);
@@ -166,20 +171,35 @@ TBZ_KERNEL void tbz_k0_scan_tiles(K0Params P) {
   const u32 lane = tbz_lane();
   u64* slots = P.tile_slots + (u64)tbz_block() * K0_SLOTS;
   u32 base = 0;
-  for (u32 r = 0; r < SCAN_TILE / 1024; r++) {
-    const uintptr_t c = T.t0 + r * 1024 + lane * 16;
-    u32 m = k0_row_mask(T, c);
-    if (tbz_ballot(m != 0) == 0) continue;  // wave-uniform: nothing in this row
-    u32 n = __builtin_popcount(m);
-    u32 inc = wave_incl_scan_u32(n);
-    u32 o = base + inc - n;
-    while (m) {
-      u32 k = __builtin_ctz(m);
-      m &= m - 1;
-      if (o < K0_SLOTS) slots[o] = (u64)(c + k - T.base) + 4;
-      o++;
+  constexpr u32 ROWS = SCAN_TILE / 1024, AHEAD = 4;  // rows in flight: the loop is a chain of dependent waits otherwise
+  uint4 v[AHEAD + 1];
+#pragma unroll
+  for (u32 q = 0; q < AHEAD; q++) v[q] = k0_load(T, T.t0 + q * 1024 + lane * 16);
+  for (u32 r0 = 0; r0 < ROWS; r0 += AHEAD) {
+    uint4 nv[AHEAD];
+#pragma unroll
+    for (u32 q = 0; q < AHEAD; q++)  // (past the tile only the row whose first dword follows the tile's last chunk)
+      nv[q] = (r0 + AHEAD + q < ROWS || q == 0) ? k0_load(T, T.t0 + (r0 + AHEAD + q) * 1024 + lane * 16) : uint4{};
+    v[AHEAD] = nv[0];
+#pragma unroll
+    for (u32 q = 0; q < AHEAD; q++) {
+      const uintptr_t c = T.t0 + (r0 + q) * 1024 + lane * 16;
+      u32 m = k0_row_mask(T, c, v[q], tbz_readlane(v[q + 1].x, 0));  // the next row's first dword follows lane 63
+      if (tbz_ballot(m != 0) != 0) {                                 // wave-uniform: something in this row
+        u32 n = __builtin_popcount(m);
+        u32 inc = wave_incl_scan_u32(n);
+        u32 o = base + inc - n;
+        while (m) {
+          u32 k = __builtin_ctz(m);
+          m &= m - 1;
+          if (o < K0_SLOTS) slots[o] = (u64)(c + k - T.base) + 4;
+          o++;
+        }
+        base += tbz_shfl(inc, 63);
+      }
     }
-    base += tbz_shfl(inc, 63);
+#pragma unroll
+    for (u32 q = 0; q < AHEAD; q++) v[q] = nv[q];
   }
   if (lane == 0) P.tile_counts[tbz_block()] = base;
 }
@@ -247,7 +267,8 @@ TBZ_KERNEL void tbz_k0_scan_emit(K0Params P) {
   u32 base = P.tile_offsets[tbz_block()];
   for (u32 r = 0; r < SCAN_TILE / 1024; r++) {
     const uintptr_t c = T.t0 + r * 1024 + lane * 16;
-    u32 m = k0_row_mask(T, c);
+    const uintptr_t ca = T.t0 + r * 1024 + 1024;  // the dword after lane 63's chunk
+    u32 m = k0_row_mask(T, c, k0_load(T, c), (ca < T.s_hi && ca + 16 > T.s_lo) ? *(const u32*)ca : 0u);
     if (tbz_ballot(m != 0) == 0) continue;  // wave-uniform: nothing in this row
     u32 n = __builtin_popcount(m);
     u32 inc = wave_incl_scan_u32(n);

@@ -1579,6 +1579,8 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, T
       const u32 n1 = L + X, o2 = o + n1;
       const u32 pa = tbz_alignbit(hi, lo, o2 & 31), pb = tbz_alignbit(nx, hi, o2 & 31);
       const u32 pd = o2 < 32 ? pa : pb;
+      // both speculative lookups go out together: the distance code of a match, and the code after a literal
+      const u32 e2 = gt.lfast[(pk >> L) & ((1u << KG_TBL) - 1)];
       u32 ed = gt.dfast[pd & ((1u << KG_TBD) - 1)];
       if (isM & ((ed & 15) == 0) & (ed != 0)) ed = gt.dfast[(1u << KG_TBD) + (ed >> 7) + tbz_bfe(pd, KG_TBD, (ed >> 4) & 7)];
       const u32 DL = ed & 15, ds = (ed >> 4) & 31;
@@ -1596,7 +1598,6 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, T
       }
       // a second literal rides along when the code after a literal is a first-level literal too (it must
       // start before the target and end inside the limit): literal-dense sub-ranges are the slow lanes
-      const u32 e2 = gt.lfast[(pk >> L) & ((1u << KG_TBL) - 1)];
       const u32 L2 = e2 & 15;
       const bool pair = !isM & (L2 != 0) & (e2 < 0x1000u) & (rel + L < tgt) & (rem1 >= (i32)L2);
       const u32 nbits = nb1 + (pair ? L2 : 0u);

@@ -1,21 +1,28 @@
 // tbz_kernels.hpp — the device side of the inflate engine (hand-written for gfx950 / CDNA4).
 //
-// All kernels run 64-thread workgroups (one wavefront each).  None of this is GEMM-shaped: it is
-// integer / byte work bounded by LDS latency (Huffman decode) or HBM bandwidth (scan, LZ77 flush,
-// checksums), so there is no MFMA here by design.
+// Every kernel runs 64-thread workgroups (one wavefront each) except the two-wave LZ77 kernel.  None of this
+// is GEMM-shaped: it is integer / byte work bounded by LDS latency and instruction issue (Huffman decode,
+// LZ77) or HBM bandwidth (scan, checksums), so there is no MFMA here by design.
 //
 //   K0  tbz_k0_scan_tiles / _offsets / _compact / _items  (+ tbz_k0_scan_emit, the second pass for crowded tiles)
 //         find 00 00 FF FF flush markers (candidate independent-segment starts) in one pass of aligned
 //         16-octet reads, compact them in order, build the K1 work items on the device.
+//   K1h tbz_k1h_headers
+//         one lane per item parses the item's first dynamic block header (code lengths) ahead of K1g.
+//   K1g tbz_k1g{8,16,32,64}_huff_decode
+//         a GANG of G lanes per item: gang-parallel canonical build, two-level lookup tables in the gang's
+//         LDS, speculative sub-range decode with exact chain validation; tokens written once, in place,
+//         as runs listed in the item's run table (replaces deflate.lisp:518-702, huffman-tree.lisp:99-218).
 //   K1  tbz_k1_huff_decode
-//         one LANE per item (64 independent decoders per wave): bit reader + dynamic-header parse +
-//         lane-interleaved LDS lookup tables (replaces deflate.lisp:518-702 and
-//         huffman-tree.lisp:99-218).  Emits u16 tokens, counts output octets, reports where it
-//         landed.  Needs no history, so every item is independent.
-//   K2  tbz_k2_lz77
-//         one wave per group: token stream -> 36 KiB LDS ring (32 KiB history + one batch span),
-//         matches resolved lane-parallel in rounds -> 16-byte coalesced HBM stores (replaces
-//         copy-history / out-byte / :copy-block, deflate.lisp:233-359,:538-573).
+//         one LANE per item (table-free canonical decode): batches of many tiny items, and the redo of items
+//         K1g declines.  Same results record, one run.
+//   K2  tbz_k2_lz77_dual / tbz_k2_lz77_small / tbz_k2_lz77
+//         one workgroup per group: tokens (followed through the run tables) -> LDS window -> 16-byte
+//         coalesced HBM stores; matches resolved lane-parallel in rounds.  Linear window for groups that
+//         fit (two waves: front end || resolve), 36 KiB ring otherwise (replaces copy-history / out-byte /
+//         :copy-block, deflate.lisp:233-359,:538-573).
+//   K3  tbz_k3_*
+//         proof that every item landed on its successor + segment-size scan + K2's tables, on the device.
 //   K4  tbz_k4_adler_partial / tbz_k4_adler_combine   (checksums.lisp:18-62)
 //   K5  tbz_k5_crc_partial / tbz_k5_crc_combine       (checksums.lisp:177-210)
 #pragma once
@@ -296,10 +303,10 @@ TBZ_KERNEL void tbz_k0_scan_emit(K0Params P) {
 //   - NO lookup tables: a fast table only pays if all 64 lanes hit it, which never happens (some lane
 //     always has a long code, so the wave always runs both paths), and it costs the LDS that limits
 //     occupancy.  Instead: canonical decode — the code length is 1 + #{L : r16 >= limit[L]} (fifteen
-//     register compares), the symbol comes from a compact per-lane list in LDS.  25.5 KiB per
-//     workgroup -> 6 workgroups = 384 decoders per CU
-//   - compressed input: a 24-word LDS window per lane, reloaded by all lanes together once per
-//     phase of 40 tokens (nested loops make the wave reconverge at the reload)
+//     register compares), the symbol comes from a compact per-lane list in LDS.  31 KiB per
+//     workgroup -> 5 workgroups = 320 decoders per CU
+//   - compressed input: a K1_INBUF-word LDS window per lane, reloaded by all lanes together once per
+//     phase of K1_PHASE tokens (nested loops make the wave reconverge at the reload)
 //   - tokens are stored straight to the item's token region (consecutive u16 per lane, merged in L2);
 //     stores need no wait
 // Replaces deflate.lisp:518-702 + huffman-tree.lisp:99-218 (same acceptance rules and errors).
@@ -2175,12 +2182,12 @@ TBZ_K1G_KERNEL(64)
 // ================================================================================================
 // K2 — LZ77 resolve: tokens -> LDS ring window -> coalesced 16-byte stores.  One wave per group.
 //
-// A batch is up to 64 token words.  Lanes classify their word (literal / match head / payload) with
+// A batch is up to 128 token words, two per lane.  Lanes classify their words (literal / match head / payload) with
 // ballots, a DPP prefix sum gives every token its output offset, literals are stored at once, and
 // matches are resolved LANE-PARALLEL in rounds: a match is ready when the part of its source that
 // it does not produce itself lies below the high-water mark (the offset of the first unresolved
 // match; everything below is final).  The first unresolved match is always ready, so every round
-// makes progress; typical text needs 2-4 rounds per batch.  Long matches (> 16 octets) and stored
+// makes progress; typical text needs 2-4 rounds per batch.  Long matches (> 32 octets) and stored
 // runs are copied cooperatively by all 64 lanes.  Replaces copy-history / out-byte / :copy-block
 // (deflate.lisp:233-359, :538-573).
 // ================================================================================================

@@ -53,7 +53,7 @@ struct tbz_ctx {
   // device pools (grow-only)
   tbz::DevBuf d_str_off, d_str_len, d_tile_first, d_tile_counts, d_tile_offsets, d_markers, d_items, d_res,
       d_tok, d_scratch, d_runs, d_segs, d_groups, d_order, d_k3_fi, d_k3_ni, d_k3_oo, d_k3_oc, d_k3_sums, d_k3_flags,
-      d_k3_gscan, d_k3_gne, d_k3_streams, d_k3_glob, d_redo_items, d_redo_res, d_k0_slots, d_k0_fm, d_hdr, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
+      d_k3_gscan, d_k3_gne, d_k3_streams, d_k3_glob, d_redo_items, d_redo_res, d_k0_slots, d_k0_fm, d_hdr, d_gck, d_gchunks, d_ck_l1, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
       d_out_stage;
 };
 
@@ -220,6 +220,47 @@ static int run_checksums(tbz_ctx* ctx, int kind, const void* d_out, const std::v
                 (u32)n};
     TBZ_LAUNCH(tbz_k5_crc_combine, n, ctx->stream, c);
   }
+  TBZ_HIP(hipGetLastError());
+  out.resize(n);
+  TBZ_HIP(hipMemcpyAsync(out.data(), ctx->d_ck_out.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  TBZ_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// adler32 from the per-group partials the two-wave K2 leaves behind (it takes them from its LDS window while the
+// window is flushed): level 1 folds ranges of 256 groups, level 2 is the ordinary ordered combine per stream
+static int run_adler_groups(tbz_ctx* ctx, const std::vector<uint32_t>& first_group, const std::vector<uint32_t>& n_groups,
+                            const std::vector<uint32_t>& init, std::vector<uint32_t>& out) {
+  size_t n = first_group.size();
+  std::vector<CkStream> l1, l2(n);
+  for (size_t s = 0; s < n; s++) {
+    l2[s].first = (uint32_t)l1.size();
+    for (uint32_t j = 0; j < n_groups[s]; j += 256) {
+      CkStream r;
+      r.first = first_group[s] + j;
+      r.count = std::min<uint32_t>(256, n_groups[s] - j);
+      r.init0 = 0;
+      r.pad = 0;
+      l1.push_back(r);
+    }
+    l2[s].count = (uint32_t)l1.size() - l2[s].first;
+    l2[s].init0 = init[s];
+    l2[s].pad = 0;
+  }
+  int r;
+  if ((r = upload(ctx, ctx->d_ck_l1, l1))) return r;
+  if ((r = upload(ctx, ctx->d_ck_streams, l2))) return r;
+  if ((r = ensure(ctx, ctx->d_ck_chunks, std::max<size_t>(l1.size(), 1) * sizeof(CkChunk)))) return r;
+  if ((r = ensure(ctx, ctx->d_ck_parts, std::max<size_t>(l1.size(), 1) * sizeof(CkPartial)))) return r;
+  if ((r = ensure(ctx, ctx->d_ck_out, std::max<size_t>(n, 1) * sizeof(uint32_t)))) return r;
+  if (!l1.empty()) {
+    K4lParams p{(const CkChunk*)ctx->d_gchunks.p, (const CkPartial*)ctx->d_gck.p, (const CkStream*)ctx->d_ck_l1.p,
+                (CkChunk*)ctx->d_ck_chunks.p, (CkPartial*)ctx->d_ck_parts.p, (u32)l1.size()};
+    TBZ_LAUNCH(tbz_k4_adler_combine_l1, l1.size(), ctx->stream, p);
+  }
+  K4cParams c{(const CkChunk*)ctx->d_ck_chunks.p, (const CkPartial*)ctx->d_ck_parts.p,
+              (const CkStream*)ctx->d_ck_streams.p, (u32*)ctx->d_ck_out.p, (u32)n};
+  TBZ_LAUNCH(tbz_k4_adler_combine, n, ctx->stream, c);
   TBZ_HIP(hipGetLastError());
   out.resize(n);
   TBZ_HIP(hipMemcpyAsync(out.data(), ctx->d_ck_out.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -469,6 +510,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   if ((r = record(ctx, 3))) return r;
   ctx->tim.huff_launches = 1;
   bool simple = false;
+  bool fused_adler = false;  // adler32 partials come from K2 (simple path, zlib, all groups in the two-wave kernel)
   char* pin_k3 = (char*)ctx->h_pin + (((n + 3) * 4 + 15) & ~(size_t)15);
   K3Global* h_glob = (K3Global*)pin_k3;
   K3Stream* h_k3s = (K3Stream*)(pin_k3 + sizeof(K3Global));
@@ -510,11 +552,18 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if (!size_only) {
       if (!d_out) return TBZ_E_ARG;
       const u32 n_it = (u32)n_items;
+      fused_adler = format == TBZ_FORMAT_ZLIB && !ctx->k2_single && h_glob->n_big == 0 && !getenv("TBZ_NO_FUSED_ADLER");
       K2Params k2{(const u16*)ctx->d_tok.p, (const RunRec*)ctx->d_runs.p, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, nullptr,
-                  (const u8*)d_in, (u8*)d_out, n_it, 0, 0};
+                  (const u8*)d_in, (u8*)d_out, n_it, 0, 0, nullptr, nullptr};
       if (h_glob->n_big < n_it) {
         k2.win_bytes = (u32)((h_glob->max_small + K2_SLACK + 63) & ~63ull);
         k2.cls = h_glob->n_big ? 1 : 0;
+        if (fused_adler) {  // every group goes through the two-wave kernel: it leaves the adler32 partials behind
+          if ((r = ensure(ctx, ctx->d_gck, (size_t)n_it * sizeof(CkPartial)))) return r;
+          if ((r = ensure(ctx, ctx->d_gchunks, (size_t)n_it * sizeof(CkChunk)))) return r;
+          k2.gck = (CkPartial*)ctx->d_gck.p;
+          k2.gchunks = (CkChunk*)ctx->d_gchunks.p;
+        }
         if (ctx->k2_single)
           TBZ_LAUNCH_DYN(tbz_k2_lz77_small, n_it, k2.win_bytes + 2 * K2_TOKBUF + 512, ctx->stream, k2);
         else
@@ -730,7 +779,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     order.insert(order.end(), order_big.begin(), order_big.end());
     if ((r = upload(ctx, ctx->d_order, order))) return r;
     K2Params k2{(const u16*)ctx->d_tok.p, (const RunRec*)ctx->d_runs.p, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p,
-                (const u32*)ctx->d_order.p, (const u8*)d_in, (u8*)d_out, 0, 0, 0};
+                (const u32*)ctx->d_order.p, (const u8*)d_in, (u8*)d_out, 0, 0, 0, nullptr, nullptr};
     if (!order_small.empty()) {
       k2.n_groups = (u32)order_small.size();
       k2.win_bytes = (u32)((max_small + K2_SLACK + 63) & ~63ull);
@@ -762,7 +811,16 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       cl[s] = want ? results[s].out_len : 0;
       init[s] = format == TBZ_FORMAT_ZLIB ? 1u : 0u;  // s1=1,s2=0 (zlib.lisp:11-12) / crc 0 (gzip.lisp:28)
     }
-    if ((r = run_checksums(ctx, format == TBZ_FORMAT_ZLIB ? 1 : 2, d_out, co, cl, init, sums))) return r;
+    if (fused_adler) {
+      std::vector<uint32_t> fg(n), ng(n);
+      for (size_t s = 0; s < n; s++) {
+        fg[s] = sp[s].first_item;
+        ng[s] = sp[s].n_items;
+      }
+      if ((r = run_adler_groups(ctx, fg, ng, init, sums))) return r;
+    } else if ((r = run_checksums(ctx, format == TBZ_FORMAT_ZLIB ? 1 : 2, d_out, co, cl, init, sums))) {
+      return r;
+    }
     for (size_t s = 0; s < n; s++) {
       tbz_result& R = results[s];
       if (format == TBZ_FORMAT_ZLIB) R.adler32 = sums[s];
@@ -895,7 +953,7 @@ void tbz_ctx_destroy(tbz_ctx* ctx) {
                          &ctx->d_segs, &ctx->d_groups, &ctx->d_ck_chunks, &ctx->d_ck_parts, &ctx->d_ck_streams,
                          &ctx->d_ck_out, &ctx->d_crc_tab, &ctx->d_in_stage, &ctx->d_out_stage, &ctx->d_k3_fi, &ctx->d_k3_ni,
                          &ctx->d_k3_oo, &ctx->d_k3_oc, &ctx->d_k3_sums, &ctx->d_k3_flags, &ctx->d_k3_gscan, &ctx->d_k3_gne,
-                         &ctx->d_k3_streams, &ctx->d_k3_glob, &ctx->d_redo_items, &ctx->d_redo_res, &ctx->d_k0_slots, &ctx->d_k0_fm, &ctx->d_hdr};
+                         &ctx->d_k3_streams, &ctx->d_k3_glob, &ctx->d_redo_items, &ctx->d_redo_res, &ctx->d_k0_slots, &ctx->d_k0_fm, &ctx->d_hdr, &ctx->d_gck, &ctx->d_gchunks, &ctx->d_ck_l1};
   for (auto* b : bufs)
     if (b->p) hipFree(b->p);
   if (ctx->h_pin) hipHostFree(ctx->h_pin);

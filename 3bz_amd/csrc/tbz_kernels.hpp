@@ -2191,6 +2191,7 @@ TBZ_K1G_KERNEL(64)
 // runs are copied cooperatively by all 64 lanes.  Replaces copy-history / out-byte / :copy-block
 // (deflate.lisp:233-359, :538-573).
 // ================================================================================================
+constexpr u32 ADLER_P = 65521;
 constexpr u32 K2_WIN = 36864;   // 32 KiB history + one batch span + slack; multiple of 16
 constexpr u32 K2_SPAN = 3072;   // max octets one batch may produce (cut otherwise)
 constexpr u32 K2_FLUSH = 8192;  // flush the ring to HBM every this many octets
@@ -2212,6 +2213,8 @@ struct K2Params {
   u32 n_groups;       // entries in `order` (order == nullptr: groups 0..n_groups-1, filtered by `cls`)
   u32 win_bytes;      // LINEAR launches: octets of the window (dynamic LDS = win_bytes + 2*K2_TOKBUF)
   u32 cls;            // with order == nullptr: 1 = only groups that fit the linear window, 2 = only the others
+  CkPartial* gck;     // two-wave kernel: adler32 partial of every group's output, computed from the window while it
+  CkChunk* gchunks;   //   is flushed (nullptr: not wanted); gchunks[g].len = octets the group stored
 };
 
 // A group whose whole output fits the LDS window needs no ring: LINEAR = true keeps every octet of
@@ -2564,7 +2567,7 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
       }
     }
   }
-  finish();
+  finish(pos < clip ? pos : clip, a0);
   k2_flush<LINEAR>(win, outp, flushed, pos, clip, a0);
 }
 
@@ -2578,7 +2581,8 @@ TBZ_KERNEL void tbz_k2_lz77(K2Params P) {
   if (!k2_pick_group(P, gi, g, sg)) return;
   k2_body<false>(
       P, gi, g, sg, win, tks, rcache,
-      [&](u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) { k2_resolve<false>(win, pend, rpos, dofs, len, dist); }, [] {});
+      [&](u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) { k2_resolve<false>(win, pend, rpos, dofs, len, dist); },
+      [](u64, u32) {});
 }
 
 // groups whose output (plus K2_SLACK octets) fits P.win_bytes, one wave doing everything
@@ -2591,7 +2595,8 @@ TBZ_KERNEL void tbz_k2_lz77_small(K2Params P) {
   u8* win = dyn;
   k2_body<true>(
       P, gi, g, sg, win, (u16*)(dyn + P.win_bytes), (u32*)(dyn + P.win_bytes + 2 * K2_TOKBUF),
-      [&](u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) { k2_resolve<true>(win, pend, rpos, dofs, len, dist); }, [] {});
+      [&](u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) { k2_resolve<true>(win, pend, rpos, dofs, len, dist); },
+      [](u64, u32) {});
 }
 
 // The same groups with TWO wavefronts per workgroup over one window: wave 0 runs the front end of batch k
@@ -2630,8 +2635,13 @@ TBZ_KERNEL_WG(128, 2) void tbz_k2_lz77_dual(K2Params P) {
           tbz_wg_barrier();
           k += 1;
         },
-        [&] {
-          if (lane == 0) H[k & 1].end = 1;
+        [&](u64 n_out, u32 a0) {
+          if (lane == 0) {
+            K2Hand& h = H[k & 1];
+            h.end = 1;
+            h.pend = n_out;  // what wave 1 needs for the checksum: octets of the group, window index of the first
+            h.rpos = a0;
+          }
           tbz_wg_barrier();
         });
   } else {
@@ -2642,7 +2652,51 @@ TBZ_KERNEL_WG(128, 2) void tbz_k2_lz77_dual(K2Params P) {
         k2_resolve<true>(win, h.pend, h.rpos, (u32)(d & 0xffffu), (u32)((d >> 16) & 0xffffu), (u32)(d >> 32));
       }
       tbz_wg_barrier();
-      if (H[k & 1].end) break;
+      if (H[k & 1].end) {
+        // every match is resolved: while wave 0 flushes the window, this wave takes the group's adler32
+        // partial from it (A = sum b_i, B = sum (n - i) b_i; checksums.lisp:18-62 split for the combine)
+        if (P.gck) {
+          const u32 n = (u32)H[k & 1].pend;
+          const u8* w = win + H[k & 1].rpos;
+          u64 A = 0, B = 0;
+          for (u32 c = lane * 16; c < n; c += 64 * 16) {
+            const K2U128 v = *(const K2U128*)(w + c);  // the window is K2_SLACK longer than the output: reads stay inside
+            u32 d[4] = {(u32)v.lo, (u32)(v.lo >> 32), (u32)v.hi, (u32)(v.hi >> 32)};
+            if (n - c < 16) {  // the group's last, partial piece: octets past the end count for nothing
+              const u32 lim = n - c;
+#pragma unroll
+              for (u32 q = 0; q < 4; q++) {
+                const u32 valid = lim > 4 * q ? (lim - 4 * q < 4 ? lim - 4 * q : 4u) : 0u;
+                d[q] &= valid == 4 ? ~0u : ((1u << (8 * valid)) - 1);
+              }
+            }
+            u32 a16 = tbz_sum4_u8(d[0], 0);
+            a16 = tbz_sum4_u8(d[1], a16);
+            a16 = tbz_sum4_u8(d[2], a16);
+            a16 = tbz_sum4_u8(d[3], a16);
+            u32 w16 = tbz_dot4_u8(d[0], 0x03020100u, 0);
+            w16 = tbz_dot4_u8(d[1], 0x07060504u, w16);
+            w16 = tbz_dot4_u8(d[2], 0x0b0a0908u, w16);
+            w16 = tbz_dot4_u8(d[3], 0x0f0e0d0cu, w16);
+            A += a16;
+            B += (u64)(n - c) * a16 - w16;
+          }
+          A = wave_sum_u64(A);
+          B = wave_sum_u64(B % ADLER_P);
+          if (lane == 0) {
+            CkPartial r;
+            r.a = (u32)(A % ADLER_P);
+            r.b = (u32)(B % ADLER_P);
+            P.gck[gi] = r;
+            CkChunk ch;
+            ch.out_abs = g.out_abs;
+            ch.len = n;
+            ch.stream = 0;
+            P.gchunks[gi] = ch;
+          }
+        }
+        break;
+      }
     }
   }
 }
@@ -2838,7 +2892,6 @@ struct K4Params {
   CkPartial* parts;
   u32 n_chunks;
 };
-constexpr u32 ADLER_P = 65521;
 
 TBZ_KERNEL void tbz_k4_adler_partial(K4Params P) {
   if (tbz_block() >= P.n_chunks) return;
@@ -2921,6 +2974,56 @@ TBZ_KERNEL void tbz_k4_adler_combine(K4cParams P) {
     }
   }
   if (lane == 0) P.out[tbz_block()] = (u32)s1 | ((u32)s2 << 16);
+}
+
+// the same combine over a RANGE of chunks, leaving a partial again ({A, B} and the range's length): level 1 of the
+// two-level combine used when K2 hands over one partial per group (65 536 of them for 1 GiB)
+struct K4lParams {
+  const CkChunk* chunks;
+  const CkPartial* parts;
+  const CkStream* ranges;  // first / count; init0 unused
+  CkChunk* out_chunks;
+  CkPartial* out_parts;
+  u32 n_ranges;
+};
+TBZ_KERNEL void tbz_k4_adler_combine_l1(K4lParams P) {
+  if (tbz_block() >= P.n_ranges) return;
+  const u32 lane = tbz_lane();
+  const CkStream cs = P.ranges[tbz_block()];
+  u32 s1 = 0, s2 = 0;
+  u64 total = 0;
+  for (u32 c0 = 0; c0 < cs.count; c0 += 256) {
+    u32 a[4], b[4], n[4];
+#pragma unroll
+    for (u32 q = 0; q < 4; q++) {
+      const u32 c = c0 + q * 64 + lane;
+      const bool v = c < cs.count;
+      a[q] = v ? P.parts[cs.first + c].a : 0;
+      b[q] = v ? P.parts[cs.first + c].b : 0;
+      n[q] = v ? P.chunks[cs.first + c].len : 0;
+    }
+#pragma unroll
+    for (u32 q = 0; q < 4; q++) {
+      total += wave_sum_u64(n[q]);
+      const u32 inc = tbz_wave_incl_scan_u32(a[q]);
+      const u32 s1_before = (s1 + inc - a[q]) % ADLER_P;
+      const u32 term = ((n[q] % ADLER_P) * s1_before + b[q]) % ADLER_P;
+      const u32 tsum = tbz_shfl(tbz_wave_incl_scan_u32(term), 63);
+      s2 = (s2 + tsum) % ADLER_P;
+      s1 = (s1 + tbz_shfl(inc, 63)) % ADLER_P;
+    }
+  }
+  if (lane == 0) {
+    CkPartial r;
+    r.a = s1;
+    r.b = s2;
+    P.out_parts[tbz_block()] = r;
+    CkChunk ch;
+    ch.out_abs = 0;
+    ch.len = (u32)total;
+    ch.stream = 0;
+    P.out_chunks[tbz_block()] = ch;
+  }
 }
 
 // ================================================================================================

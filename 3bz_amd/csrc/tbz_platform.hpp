@@ -88,6 +88,9 @@ TBZ_DEV u32 tbz_pk_min_u16(u32 a, u32 b) {
   tbz_us2 r = __builtin_elementwise_min(__builtin_bit_cast(tbz_us2, a), __builtin_bit_cast(tbz_us2, b));
   return __builtin_bit_cast(u32, r);
 }
+// acc + sum of the four octets of x (v_sad_u8 against zero); acc + sum of x's octets times w's octets (v_dot4_u32_u8)
+TBZ_DEV u32 tbz_sum4_u8(u32 x, u32 acc) { return __builtin_amdgcn_sad_u8(x, 0u, acc); }
+TBZ_DEV u32 tbz_dot4_u8(u32 x, u32 w, u32 acc) { return __builtin_amdgcn_udot4(x, w, acc, false); }
 // 32 bits of the 64-bit value hi:lo starting at bit o (o < 32): one v_alignbit_b32
 TBZ_DEV u32 tbz_alignbit(u32 hi, u32 lo, u32 o) { return __builtin_amdgcn_alignbit(hi, lo, o); }
 // n bits of v starting at bit off (n = 0 gives 0): one v_bfe_u32

@@ -53,7 +53,7 @@ struct tbz_ctx {
   // device pools (grow-only)
   tbz::DevBuf d_str_off, d_str_len, d_tile_first, d_tile_counts, d_tile_offsets, d_markers, d_items, d_res,
       d_tok, d_scratch, d_runs, d_segs, d_groups, d_order, d_k3_fi, d_k3_ni, d_k3_oo, d_k3_oc, d_k3_sums, d_k3_flags,
-      d_k3_gscan, d_k3_gne, d_k3_streams, d_k3_glob, d_redo_items, d_redo_res, d_k0_slots, d_k0_fm, d_hdr, d_gck, d_gchunks, d_ck_l1, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
+      d_k3_gscan, d_k3_gne, d_k3_streams, d_k3_glob, d_redo_items, d_redo_res, d_k0_slots, d_k0_fm, d_hdr, d_gck, d_gchunks, d_ck_l1, d_tok2, d_runs2, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
       d_out_stage;
 };
 
@@ -418,17 +418,21 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     while (ipw > 1 && n_it / ipw < 512) ipw >>= 1;
     return ipw;
   };
-  auto launch_lane = [&](const Item* d_items, SegResult* d_res, size_t n_it) -> int {
+  // Repair (fix-up) launches decode into pools of their own: a gang that repairs an item runs past the marker
+  // it will land on, into the bit range of items whose tokens (position-addressed!) are already in place.
+  auto pool_tok = [&](bool fix) { return (u16*)(fix ? ctx->d_tok2.p : ctx->d_tok.p); };
+  auto pool_runs = [&](bool fix) { return (RunRec*)(fix ? ctx->d_runs2.p : ctx->d_runs.p); };
+  auto launch_lane = [&](const Item* d_items, SegResult* d_res, size_t n_it, bool fix) -> int {
     int rr = ensure(ctx, ctx->d_scratch, n_it * (size_t)K1_SCRATCH);
     if (rr) return rr;
-    K1Params k1{(const u8*)d_in, (u16*)ctx->d_tok.p, d_items, d_res, (const u64*)ctx->d_markers.p,
-                (u8*)ctx->d_scratch.p, (RunRec*)ctx->d_runs.p, d_first_marker, (u32)n_mark, (u32)n_it, items_per_wg(n_it)};
+    K1Params k1{(const u8*)d_in, pool_tok(fix), d_items, d_res, (const u64*)ctx->d_markers.p,
+                (u8*)ctx->d_scratch.p, pool_runs(fix), d_first_marker, (u32)n_mark, (u32)n_it, items_per_wg(n_it)};
     TBZ_LAUNCH(tbz_k1_huff_decode, (n_it + k1.items_per_wg - 1) / k1.items_per_wg, ctx->stream, k1);
     return 0;
   };
   // items the gang kernel declined (SEG_REDO: token stream as dense as the bitstream, run table full) are
   // decoded again by the one-lane kernel, which writes one contiguous run
-  auto redo = [&](const std::vector<Item>& its, std::vector<SegResult>& rs) -> int {
+  auto redo = [&](const std::vector<Item>& its, std::vector<SegResult>& rs, bool fix) -> int {
     std::vector<Item> sub;
     std::vector<size_t> idx;
     for (size_t i = 0; i < rs.size(); i++)
@@ -441,7 +445,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     int rr;
     if ((rr = upload(ctx, ctx->d_redo_items, sub))) return rr;
     if ((rr = ensure(ctx, ctx->d_redo_res, sub.size() * sizeof(SegResult)))) return rr;
-    if ((rr = launch_lane((const Item*)ctx->d_redo_items.p, (SegResult*)ctx->d_redo_res.p, sub.size()))) return rr;
+    if ((rr = launch_lane((const Item*)ctx->d_redo_items.p, (SegResult*)ctx->d_redo_res.p, sub.size(), fix))) return rr;
     std::vector<SegResult> tmp(sub.size());
     TBZ_HIP(hipMemcpyAsync(tmp.data(), ctx->d_redo_res.p, tmp.size() * sizeof(SegResult), hipMemcpyDeviceToHost,
                            ctx->stream));
@@ -450,9 +454,9 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     ctx->tim.huff_launches++;
     return 0;
   };
-  auto launch_k1 = [&](const Item* d_items, SegResult* d_res, size_t n_it) -> int {
+  auto launch_k1 = [&](const Item* d_items, SegResult* d_res, size_t n_it, bool fix) -> int {
     int G = k1_gang(n_it);
-    if (G == 1) return launch_lane(d_items, d_res, n_it);
+    if (G == 1) return launch_lane(d_items, d_res, n_it, fix);
     size_t per = 64 / G, nwg = (n_it + per - 1) / per;
     // K1h: every lane parses the first block header of its own item, so that the gangs need not (their leaders
     // would do it with 2 of 64 lanes busy)
@@ -461,7 +465,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if ((rr = ensure(ctx, ctx->d_hdr, n_it * sizeof(HdrRec)))) return rr;
     K1hParams kh{(const u8*)d_in, d_items, (u8*)ctx->d_scratch.p, (HdrRec*)ctx->d_hdr.p, (u32)n_it};
     if (ctx->k1h) TBZ_LAUNCH(tbz_k1h_headers, (n_it + 63) / 64, ctx->stream, kh);
-    K1gParams kg{(const u8*)d_in, (u16*)ctx->d_tok.p, (RunRec*)ctx->d_runs.p, d_items, d_res,
+    K1gParams kg{(const u8*)d_in, pool_tok(fix), pool_runs(fix), d_items, d_res,
                  (const u64*)ctx->d_markers.p, d_first_marker, ctx->k1h ? (const HdrRec*)ctx->d_hdr.p : nullptr,
                  (const u8*)ctx->d_scratch.p, (u32)n_mark, (u32)n_it};
     switch (G) {
@@ -505,7 +509,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
                   (K3Global*)ctx->d_k3_glob.p, (u32)n_items, k3_tiles, (u32)n};
   }
   if ((r = record(ctx, 2))) return r;
-  if ((r = launch_k1((const Item*)ctx->d_items.p, (SegResult*)ctx->d_res.p, n_items))) return r;
+  if ((r = launch_k1((const Item*)ctx->d_items.p, (SegResult*)ctx->d_res.p, n_items, false))) return r;
   TBZ_HIP(hipGetLastError());
   if ((r = record(ctx, 3))) return r;
   ctx->tim.huff_launches = 1;
@@ -522,13 +526,13 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     simple = h_glob->not_simple == 0;
   }
   // what a stream reports once its status is known (both layout paths)
-  auto fill_result = [&](size_t s, int32_t status, uint32_t nseg) {
+  auto fill_result = [&](size_t s, int32_t status, uint32_t nseg, bool error_first = false) {
     StreamPlan& S = sp[s];
     tbz_result& R = results[s];
     // 3bz decodes front to back: it reports overflow as soon as a token does not fit, before it
     // could meet a later error / underrun
     uint64_t cap = S.out_cap;
-    bool overflow = S.total_out > cap;
+    bool overflow = S.total_out > cap && !error_first;
     if (overflow) status = TBZ_OUTPUT_OVERFLOW;
     R.status = status;
     R.segments = nseg;
@@ -553,7 +557,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       if (!d_out) return TBZ_E_ARG;
       const u32 n_it = (u32)n_items;
       fused_adler = format == TBZ_FORMAT_ZLIB && !ctx->k2_single && h_glob->n_big == 0 && !getenv("TBZ_NO_FUSED_ADLER");
-      K2Params k2{(const u16*)ctx->d_tok.p, (const RunRec*)ctx->d_runs.p, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, nullptr,
+      K2Params k2{(const u16*)ctx->d_tok.p, (const RunRec*)ctx->d_runs.p, nullptr, nullptr, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, nullptr,
                   (const u8*)d_in, (u8*)d_out, n_it, 0, 0, nullptr, nullptr};
       if (h_glob->n_big < n_it) {
         k2.win_bytes = (u32)((h_glob->max_small + K2_SLACK + 63) & ~63ull);
@@ -603,7 +607,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
                          ctx->stream));
   TBZ_HIP(hipStreamSynchronize(ctx->stream));
   huff_ms = elapsed(ctx, 2, 3);
-  if ((r = redo(items, res))) return r;
+  if ((r = redo(items, res, false))) return r;
 
   // ---------------------------------------------------------------- chain walk (+ fix-up rounds)
   std::vector<SegHost> segs;
@@ -615,11 +619,12 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     h.seg.tok_words = q.tok_words;
     h.seg.out_bytes = q.out_bytes;
     h.seg.n_runs = q.n_runs;
-    h.seg.pad = 0;
+    h.seg.pool = is_fixup ? 1u : 0u;
     h.stream = (uint32_t)s;
     h.deficit = q.max_deficit;
     h.continues = S.next_continues;
     S.next_continues = false;
+    if (getenv("TBZ_DEBUG2")) fprintf(stderr, "consume: start_bit %llu status %d end_bit %llu out %llu tok %llu runs %u deficit %u fixup %d\n", (unsigned long long)it.start_bit, q.status, (unsigned long long)q.end_bit, (unsigned long long)q.out_bytes, (unsigned long long)q.tok_words, q.n_runs, q.max_deficit, (int)is_fixup);
     if (q.tok_words || q.out_bytes) per_stream[s].push_back(h);
     else if (h.continues) S.next_continues = true;  // nothing emitted: carry the flag forward
     S.total_out += q.out_bytes;
@@ -687,7 +692,9 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if ((r = upload(ctx, ctx->d_items, fix))) return r;
     if ((r = ensure(ctx, ctx->d_res, fix.size() * sizeof(SegResult)))) return r;
     if ((r = record(ctx, 2))) return r;
-    if ((r = launch_k1((const Item*)ctx->d_items.p, (SegResult*)ctx->d_res.p, fix.size()))) return r;
+    if ((r = ensure(ctx, ctx->d_tok2, (size_t)in_extent * 16 + 64))) return r;
+    if ((r = ensure(ctx, ctx->d_runs2, (((size_t)in_extent * 8) >> RUN_SHIFT) * sizeof(RunRec) + 1024))) return r;
+    if ((r = launch_k1((const Item*)ctx->d_items.p, (SegResult*)ctx->d_res.p, fix.size(), true))) return r;
     TBZ_HIP(hipGetLastError());
     if ((r = record(ctx, 3))) return r;
     ctx->tim.huff_launches++;
@@ -696,7 +703,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
                            ctx->stream));
     TBZ_HIP(hipStreamSynchronize(ctx->stream));
     huff_ms += elapsed(ctx, 2, 3);
-    if ((r = redo(fix, fr))) return r;
+    if ((r = redo(fix, fr, true))) return r;
     for (size_t k = 0; k < fix.size(); k++) {
       size_t s = fix_stream[k];
       StreamPlan& S = sp[s];
@@ -724,12 +731,20 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     auto& v = per_stream[s];
     uint64_t produced = 0;
     int32_t status = S.status;
-    // history check (deflate.lisp:343-345): a match may not reach before the stream's first octet
+    // history check (deflate.lisp:343-345): a match may not reach before the stream's first octet.  Every
+    // segment here lies before the point where the stream ended / failed, so a front-to-back decoder meets
+    // this error first (and before it would overflow a buffer that ends after the offending segment starts)
+    bool dist_err = false;
+    uint64_t dist_at = 0;
     for (auto& h : v) {
-      if (h.deficit && (uint64_t)h.deficit > produced && status >= 0) status = TBZ_E_DISTANCE;
+      if (!dist_err && h.deficit && (uint64_t)h.deficit > produced) {
+        dist_err = true;
+        dist_at = produced;
+      }
       produced += h.seg.out_bytes;
     }
-    status = fill_result(s, status, (uint32_t)v.size());
+    if (dist_err) status = TBZ_E_DISTANCE;
+    status = fill_result(s, status, (uint32_t)v.size(), dist_err && dist_at < S.out_cap);
     if (status < 0) continue;  // reference signals an error: no partial-result contract
     if (size_only) continue;
     // groups: a segment that needs history (or continues a repaired block) joins its predecessor
@@ -778,8 +793,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     std::vector<uint32_t> order(order_small);
     order.insert(order.end(), order_big.begin(), order_big.end());
     if ((r = upload(ctx, ctx->d_order, order))) return r;
-    K2Params k2{(const u16*)ctx->d_tok.p, (const RunRec*)ctx->d_runs.p, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p,
-                (const u32*)ctx->d_order.p, (const u8*)d_in, (u8*)d_out, 0, 0, 0, nullptr, nullptr};
+    K2Params k2{(const u16*)ctx->d_tok.p, (const RunRec*)ctx->d_runs.p, (const u16*)ctx->d_tok2.p, (const RunRec*)ctx->d_runs2.p,
+                (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, (const u32*)ctx->d_order.p, (const u8*)d_in, (u8*)d_out, 0, 0, 0, nullptr, nullptr};
     if (!order_small.empty()) {
       k2.n_groups = (u32)order_small.size();
       k2.win_bytes = (u32)((max_small + K2_SLACK + 63) & ~63ull);
@@ -953,7 +968,7 @@ void tbz_ctx_destroy(tbz_ctx* ctx) {
                          &ctx->d_segs, &ctx->d_groups, &ctx->d_ck_chunks, &ctx->d_ck_parts, &ctx->d_ck_streams,
                          &ctx->d_ck_out, &ctx->d_crc_tab, &ctx->d_in_stage, &ctx->d_out_stage, &ctx->d_k3_fi, &ctx->d_k3_ni,
                          &ctx->d_k3_oo, &ctx->d_k3_oc, &ctx->d_k3_sums, &ctx->d_k3_flags, &ctx->d_k3_gscan, &ctx->d_k3_gne,
-                         &ctx->d_k3_streams, &ctx->d_k3_glob, &ctx->d_redo_items, &ctx->d_redo_res, &ctx->d_k0_slots, &ctx->d_k0_fm, &ctx->d_hdr, &ctx->d_gck, &ctx->d_gchunks, &ctx->d_ck_l1};
+                         &ctx->d_k3_streams, &ctx->d_k3_glob, &ctx->d_redo_items, &ctx->d_redo_res, &ctx->d_k0_slots, &ctx->d_k0_fm, &ctx->d_hdr, &ctx->d_gck, &ctx->d_gchunks, &ctx->d_ck_l1, &ctx->d_tok2, &ctx->d_runs2};
   for (auto* b : bufs)
     if (b->p) hipFree(b->p);
   if (ctx->h_pin) hipHostFree(ctx->h_pin);

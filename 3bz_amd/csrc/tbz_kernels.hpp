@@ -871,7 +871,7 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
   st.limit_bit = fixup ? ~0ull : it.limit_bit;
   st.produced = 0;
   st.deficit = 0;
-  st.tok0 = P.tok + it.start_bit;
+  st.tok0 = P.tok + (it.start_bit & ~7ull);  // token base: the 8-word granule of the start (fix-up items start mid-octet)
   st.tok = st.tok0;
   st.fail_pos = it.start_bit;
 
@@ -1466,6 +1466,7 @@ TBZ_DEV i32 kg_dynamic_header(GangTables& gt, GangState& gs, K1State& st) {
     }
     if (slow) {
       st.br = save;
+      br_seek_fill(st.br, save.pos);  // the LDS window has moved on since `save` was taken
       i = 0;
       last = 0xff;
     }
@@ -1606,7 +1607,11 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, T
       // a second literal rides along when the code after a literal is a first-level literal too (it must
       // start before the target and end inside the limit): literal-dense sub-ranges are the slow lanes
       const u32 L2 = e2 & 15;
+#ifdef KG_NO_PAIR
+      const bool pair = false;
+#else
       const bool pair = !isM & (L2 != 0) & (e2 < 0x1000u) & (rel + L < tgt) & (rem1 >= (i32)L2);
+#endif
       const u32 nbits = nb1 + (pair ? L2 : 0u);
       const i32 rem2 = rem - (i32)nbits;
       rem = rem2;
@@ -1881,7 +1886,7 @@ TBZ_DEV void kg_leader_header(GangTables& gt, GangState& gs, K1State& st, const 
     if (ncopy) {
       // a run of its own: one 8-word piece at the first granule at or after the block header (the block
       // is at least 35 bits long, so the piece ends before anything that follows can start)
-      const u64 x = ((gs.blk_pos - it.start_bit) + 7) & ~7ull;
+      const u64 x = ((gs.blk_pos - (it.start_bit & ~7ull)) + 7) & ~7ull;
       if (gs.nruns + 1 > kg_run_slots(it, byte0 * 8)) { gs.status = SEG_REDO; gs.mode = GM_DONE; return; }
       u16* t = tok0 + x;
       t[0] = (u16)(TOK_STORED | (ncopy & 0x3fff));
@@ -1955,7 +1960,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
   if (have) it = P.items[idx];
   const u32 fmt = (it.flags >> ITEM_FMT_SHIFT) & 3;
   const bool fixup = (it.flags & ITEM_FIXUP) != 0;
-  u16* tok0 = P.tok + it.start_bit;
+  u16* tok0 = P.tok + (it.start_bit & ~7ull);  // token base: the 8-word granule of the start (fix-up items start mid-octet)
   K1State st;
   br_init(st.br, P.in_base, it.end_byte, S.inbuf);
   st.end_bit = it.end_byte * 8;
@@ -2092,9 +2097,12 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     // and the table must not outgrow the item's span; else the item is left to the one-lane kernel
     const u64 end_lv = tbz_shfl64(s_lo + nn, (int)lv);
     const bool fits = !inblk || (end_lv <= (e_last & ~7ull) && gs.nruns + tot_r <= kg_run_slots(it, e_last));
+#ifdef TBZ_EMU_TRACE
+    if (getenv("TBZ_DEBUG3") && inblk) fprintf(stderr, "k1g item %llu Pb %llu lane g %u valid %d c %llu e %llu n %u out %u flag %u mdef %d\n", (unsigned long long)it.start_bit, (unsigned long long)Pb, g, (int)valid, (unsigned long long)ro.c, (unsigned long long)ro.e, ro.n, ro.out, ro.flag, ro.mdef);
+#endif
     if (hasrun && fits) {  // (the lane has padded its run to the granule already)
       RunRec rr;
-      rr.off8 = (u32)((s_lo - it.start_bit) >> 3);
+      rr.off8 = (u32)((s_lo - (it.start_bit & ~7ull)) >> 3);
       rr.n8 = n8;
       (P.runs + (it.start_bit >> RUN_SHIFT))[gs.nruns + rank] = rr;
     }
@@ -2205,6 +2213,8 @@ constexpr u32 K2_SMALL_MAX = 32768;  // groups producing at most this much (incl
 struct K2Params {
   const u16* tok;
   const RunRec* runs; // run tables (see RunRec)
+  const u16* tok2;    // the repair launches' token pool and run tables (segments with pool = 1)
+  const RunRec* runs2;
   const Seg* segs;
   const Group* groups;
   const u32* order;   // group indices this launch handles
@@ -2380,8 +2390,10 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
     // except at the start of a segment.  A cache of 64 run records (inclusive piece counts rE, offsets rO,
     // in LDS) maps logical pieces to addresses; it is re-based when a chunk reaches past it.
     const u64 npieces = sg.tok_words >> 3;
-    const RunRec* rt = P.runs + (sg.tok_index >> RUN_SHIFT);
-    const u16* tbase = P.tok + sg.tok_index;
+    // (a repaired segment's tokens live in the repair launches' own pool: a gang that repairs runs past the
+    // marker it will land on, and must not scribble over the tokens of the items that start there)
+    const RunRec* rt = (sg.pool ? P.runs2 : P.runs) + (sg.tok_index >> RUN_SHIFT);
+    const u16* tbase = (sg.pool ? P.tok2 : P.tok) + (sg.tok_index & ~7ull);  // run offsets count 8-word granules from here
     u32* rE = rcache;
     u32* rO = rcache + 64;
     u32 rbase = 0, ctot = 0;
@@ -2391,6 +2403,9 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
       rr.off8 = 0;
       rr.n8 = 0;
       if (rbase + lane < sg.n_runs) rr = rt[rbase + lane];
+#ifdef TBZ_EMU_TRACE
+      if (getenv("TBZ_DEBUG3") && rbase + lane < sg.n_runs) fprintf(stderr, "k2 run[%u] of seg tok_index %llu words %llu: off8 %u n8 %u\n", rbase + lane, (unsigned long long)sg.tok_index, (unsigned long long)sg.tok_words, rr.off8, rr.n8);
+#endif
       const u32 inc = tbz_wave_incl_scan_u32(rr.n8);
       tbz_sync();
       rE[lane] = inc;
@@ -2855,7 +2870,7 @@ TBZ_KERNEL void tbz_k3_emit(K3Params P) {
     sg.tok_words = q.tok_words;
     sg.out_bytes = q.out_bytes;
     sg.n_runs = q.n_runs;
-    sg.pad = 0;
+    sg.pool = 0;
     P.segs[i] = sg;
     Group g;
     g.out_abs = P.out_off[s] + rel;

@@ -60,7 +60,7 @@ struct SegResult {
   uint64_t reserved;     // K1g diagnostics: rounds << 32 | committed lanes
 };
 
-// One contiguous piece of an item's token stream: n8 * 8 words at tok[item.start_bit + off8 * 8 ...].
+// One contiguous piece of an item's token stream: n8 * 8 words at tok[(item.start_bit & ~7) + off8 * 8 ...].
 // An item's table starts at runs[item.start_bit >> RUN_SHIFT] (position-addressed like the token pool:
 // a token-bearing item spans more than 2^RUN_SHIFT bits, and K1 declines items that would need more runs
 // than their span holds slots).
@@ -75,7 +75,7 @@ struct Seg {
   uint64_t tok_words;  // logical token words (multiple of 8)
   uint64_t out_bytes;
   uint32_t n_runs;
-  uint32_t pad;
+  uint32_t pool;       // 0: the call's token pool / run tables; 1: those of the repair (fix-up) launches
 };
 
 struct Group {

@@ -427,10 +427,37 @@ def case_chunked_resume(eng, n=90_000):
     _chunked_lockstep(eng, blobs[0][1][: len(blobs[0][1]) // 2], "zlib", [5000], [n + 10], "truncated zlib in chunks")
 
 
+def case_fuzz(eng, seed=7, n=30):
+    """random corruptions (bit flips, truncation, inserted 00 00 FF FF markers, overwritten octets) of four stream
+    shapes: whatever the reference makes of them — finished with some octets, underrun, one of its errors — the engine
+    must make the same.  Seed 7 / case 26 is the stream that exposed the one parity bug of the round (a repair item
+    starts mid-octet; its run offsets were taken from the unaligned start)."""
+    rng = random.Random(seed)
+    plain = _mixed_plain(60000, 9)
+    bases = [("zlib", zlib.compress(plain, 6)), ("zlib", K.zlib_flush_stream(50000, block=4096)[0]),
+             ("deflate", zlib.compress(plain, 1)[2:-4]),
+             ("zlib", K.zlib_flush_stream(30000, block=1000, flush=zlib.Z_SYNC_FLUSH)[0])]
+    for k in range(n):
+        fmt, b = rng.choice(bases)
+        b = bytearray(b)
+        for _ in range(rng.randrange(1, 4)):
+            mode = rng.randrange(4)
+            if mode == 0:
+                b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+            elif mode == 1:
+                b = b[: rng.randrange(1, len(b))]
+            elif mode == 2:
+                i = rng.randrange(len(b))
+                b[i:i] = bytes([0, 0, 255, 255])
+            else:
+                b[rng.randrange(len(b))] = rng.randrange(256)
+        assert_same(eng, bytes(b), fmt, 70000, what="fuzz seed %d case %d" % (seed, k))
+
+
 ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,
              case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_device_buffers,
-             case_checksum_kernels, case_deep_codes, case_chunked_resume]
+             case_checksum_kernels, case_deep_codes, case_chunked_resume, case_fuzz]
 # the cases whose behaviour depends on the K1 flavour (forced-flavour runs skip the rest: checksums, device
 # buffers and the replay protocol go through the same engine calls whatever decodes the Huffman codes)
 K1_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,
-            case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_deep_codes]
+            case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_deep_codes, case_fuzz]

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 
 
-@pytest.fixture(scope="module", params=["auto", "hostlayout", "k2single", "gang8", "gang16", "gang64", "lane"])
+@pytest.fixture(scope="module", params=["auto", "hostlayout", "k2single", "gang8", "gang16", "lane"])
 def eng(request):
     """the three K1 flavours (TBZ_K1_MODE is read when a context is created)"""
     subprocess.check_call(["make", "-C", EMU_DIR, "libtbz_emu.so"], stdout=subprocess.DEVNULL)

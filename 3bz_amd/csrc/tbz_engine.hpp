@@ -160,6 +160,7 @@ struct StreamPlan {
 
 struct SegHost {
   Seg seg;
+  Item item;  // the K1 item that produced it (re-decoded to locate a distance error exactly)
   uint32_t stream;
   uint32_t deficit;
   bool continues;  // must share the window with the previous segment (fix-up continuation)
@@ -615,6 +616,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   std::vector<std::vector<SegHost>> per_stream(n);
   auto consume = [&](StreamPlan& S, size_t s, const Item& it, const SegResult& q, bool is_fixup) {
     SegHost h;
+    h.item = it;
     h.seg.tok_index = it.start_bit;
     h.seg.tok_words = q.tok_words;
     h.seg.out_bytes = q.out_bytes;
@@ -722,6 +724,59 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   ctx->tim.huff_ms = huff_ms;
   if (getenv("TBZ_DEBUG")) fprintf(stderr, "tbz: gang rounds %llu, committed lanes %llu (%.2f per round)\n", (unsigned long long)ctx->gang_rounds, (unsigned long long)ctx->gang_valid, ctx->gang_rounds ? (double)ctx->gang_valid / ctx->gang_rounds : 0.0);
 
+  // ---------------------------------------------------------------- distance errors vs output overflow
+  // history check (deflate.lisp:343-345): a match may not reach before the stream's first octet.  Every segment
+  // here lies before the point where the stream ended / failed, so a front-to-back decoder meets this error
+  // before any later one — and before output-overflow iff the offending match STARTS at or before the buffer's
+  // end.  K1 reports per item only the largest reach-back; when the buffer ends inside the offending segment
+  // that item is decoded once more by the one-lane kernel, told how many octets precede it (ITEM_HIST), which
+  // then reports the first offending match's output offset.
+  enum { DIST_NONE = 0, DIST_FIRST = 1, DIST_AFTER_OVERFLOW = 2 };
+  std::vector<uint8_t> dist_first(n, DIST_NONE);
+  {
+    struct Probe { size_t s, seg; uint64_t before; };
+    std::vector<Probe> probes[2];  // per token pool
+    for (size_t s = 0; s < n; s++) {
+      uint64_t produced = 0;
+      for (size_t i = 0; i < per_stream[s].size(); i++) {
+        const SegHost& h = per_stream[s][i];
+        if (h.deficit && (uint64_t)h.deficit > produced) {
+          const uint64_t end = produced + h.seg.out_bytes, cap = sp[s].out_cap;
+          if (cap >= end) dist_first[s] = DIST_FIRST;
+          else if (cap < produced) dist_first[s] = DIST_AFTER_OVERFLOW;
+          else probes[h.seg.pool & 1].push_back({s, i, produced});
+          break;
+        }
+        produced += h.seg.out_bytes;
+      }
+    }
+    for (int pool = 0; pool < 2; pool++) {
+      auto& pv = probes[pool];
+      if (pv.empty()) continue;
+      std::vector<Item> its(pv.size());
+      for (size_t k = 0; k < pv.size(); k++) {
+        its[k] = per_stream[pv[k].s][pv[k].seg].item;
+        its[k].flags |= (uint32_t)pv[k].before << ITEM_HIST_SHIFT;  // < 32768: the item's reach-back exceeds it
+      }
+      if ((r = upload(ctx, ctx->d_redo_items, its))) return r;
+      if ((r = ensure(ctx, ctx->d_redo_res, its.size() * sizeof(SegResult)))) return r;
+      if ((r = launch_lane((const Item*)ctx->d_redo_items.p, (SegResult*)ctx->d_redo_res.p, its.size(), pool == 1))) return r;
+      std::vector<SegResult> pr(its.size());
+      TBZ_HIP(hipMemcpyAsync(pr.data(), ctx->d_redo_res.p, pr.size() * sizeof(SegResult), hipMemcpyDeviceToHost,
+                             ctx->stream));
+      TBZ_HIP(hipStreamSynchronize(ctx->stream));
+      ctx->tim.huff_launches++;
+      for (size_t k = 0; k < pv.size(); k++) {
+        SegHost& h = per_stream[pv[k].s][pv[k].seg];
+        // the item's tokens are now the one-lane kernel's (same octets, one run)
+        h.seg.tok_words = pr[k].tok_words;
+        h.seg.n_runs = pr[k].n_runs;
+        const uint64_t at = pr[k].reserved;  // octets into the item; ~0: none found (cannot happen)
+        dist_first[pv[k].s] = (at != ~0ull && pv[k].before + at > sp[pv[k].s].out_cap) ? DIST_AFTER_OVERFLOW : DIST_FIRST;
+      }
+    }
+  }
+
   // ---------------------------------------------------------------- per-stream layout, groups, status
   std::vector<Seg> h_segs;
   std::vector<Group> h_groups;
@@ -729,22 +784,9 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     StreamPlan& S = sp[s];
     tbz_result& R = results[s];
     auto& v = per_stream[s];
-    uint64_t produced = 0;
     int32_t status = S.status;
-    // history check (deflate.lisp:343-345): a match may not reach before the stream's first octet.  Every
-    // segment here lies before the point where the stream ended / failed, so a front-to-back decoder meets
-    // this error first (and before it would overflow a buffer that ends after the offending segment starts)
-    bool dist_err = false;
-    uint64_t dist_at = 0;
-    for (auto& h : v) {
-      if (!dist_err && h.deficit && (uint64_t)h.deficit > produced) {
-        dist_err = true;
-        dist_at = produced;
-      }
-      produced += h.seg.out_bytes;
-    }
-    if (dist_err) status = TBZ_E_DISTANCE;
-    status = fill_result(s, status, (uint32_t)v.size(), dist_err && dist_at < S.out_cap);
+    if (dist_first[s] != DIST_NONE) status = TBZ_E_DISTANCE;
+    status = fill_result(s, status, (uint32_t)v.size(), dist_first[s] == DIST_FIRST);
     if (status < 0) continue;  // reference signals an error: no partial-result contract
     if (size_only) continue;
     // groups: a segment that needs history (or continues a repaired block) joins its predecessor

@@ -545,6 +545,8 @@ struct K1State {
   u16* tok;      // next token word of this item
   u16* tok0;
   u32 deficit;
+  u32 hist0;     // octets of the stream before this item, when the host knows (ITEM_HIST; else 0): with it the
+  u64 viol_out;  // first match that reaches before the stream's start is located exactly (octets into the item)
 };
 
 // availability / landing-limit test after consuming bits for a token or header field that started
@@ -673,7 +675,8 @@ TBZ_DEV i32 k1_decode_block(K1Lds& S, K1State& st, const K1Tables& T, u8* sc) {
     i32 rem = lim64 <= B.pos ? 0 : ((lim64 - B.pos) > 0x7fffff00ull ? 0x7fffff00 : (i32)(lim64 - B.pos));
     const i32 rem_start = rem;
     i32 rem_tok = rem;  // value of rem when the current token started
-    u32 hist = st.produced > 32768 ? 32768u : (u32)st.produced;  // history available inside this item (saturated)
+    const u64 hist64 = st.produced + st.hist0;
+    u32 hist = hist64 > 32768 ? 32768u : (u32)hist64;  // history available to this item (saturated)
     u32 prod = 0;       // octets produced in this phase
     u32 deficit = st.deficit;
     u16* tp = st.tok;
@@ -744,6 +747,7 @@ TBZ_DEV i32 k1_decode_block(K1Lds& S, K1State& st, const K1Tables& T, u8* sc) {
         if (dist > h) {
           u32 d = dist - h;
           deficit = d > deficit ? d : deficit;
+          if (st.viol_out == ~0ull) st.viol_out = st.produced + prod;
         }
         tp[0] = (u16)(TOK_MATCH | (len - 3));
         tp[1] = (u16)(dist - 1);
@@ -874,6 +878,8 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
   st.tok0 = P.tok + (it.start_bit & ~7ull);  // token base: the 8-word granule of the start (fix-up items start mid-octet)
   st.tok = st.tok0;
   st.fail_pos = it.start_bit;
+  st.hist0 = it.flags >> ITEM_HIST_SHIFT;
+  st.viol_out = ~0ull;
 
   i32 status = 0;
   u32 land = 0xFFFFFFFFu, tr0 = 0, tr1 = 0, tr_have = 0;
@@ -1002,7 +1008,7 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
   r.trailer1 = tr1;
   r.trailer_have = tr_have;
   r.land_marker = land;
-  r.reserved = 0;
+  r.reserved = st.viol_out;  // (the gang kernel keeps its diagnostics here)
   P.res[idx] = r;
 }
 // K1h — header pre-pass for the gang kernel.  Parsing a dynamic block's code lengths is a serial job for ONE
@@ -1040,6 +1046,8 @@ TBZ_KERNEL void tbz_k1h_headers(K1hParams P) {
   st.limit_bit = (it.flags & ITEM_FIXUP) ? ~0ull : it.limit_bit;
   st.produced = 0;
   st.deficit = 0;
+  st.hist0 = 0;
+  st.viol_out = ~0ull;
   st.tok0 = st.tok = nullptr;
   st.fail_pos = it.start_bit;
   HdrRec h;
@@ -1967,6 +1975,8 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
   st.limit_bit = fixup ? ~0ull : it.limit_bit;
   st.produced = 0;
   st.deficit = 0;
+  st.hist0 = 0;
+  st.viol_out = ~0ull;
   st.tok0 = tok0;
   st.tok = tok0;
   st.fail_pos = it.start_bit;

@@ -237,6 +237,33 @@ def case_errors(eng):
     w.end_block()
     w.align()
     mut.append(("deflate", w.getvalue()))
+    # ... and the same error against output-overflow: 3bz meets whichever comes first in the octet order, i.e. the
+    # error iff the offending match STARTS at or before the end of the buffer (copy-history checks the source
+    # before it copies, deflate.lisp:343-345).  One segment, and the match in the second of two segments.
+    for lead in (0, 10):
+        w = K.FixedHuffmanWriter()
+        if lead:
+            w.begin_block(False)
+            for i in range(lead):
+                w.literal(97 + i)
+            w.end_block()
+            w.bits(0, 3)  # empty stored block = sync-flush marker: the second segment starts after it
+            w.align()
+            w.buf += b"\x00\x00\xff\xff"
+        w.begin_block(True)
+        for i in range(20):
+            w.literal(65 + i)
+        w.match(5, 4)              # fine
+        w.match(5, lead + 26)      # starts at octet lead+25 and reaches one octet before the stream's first
+        for i in range(20):
+            w.literal(48 + i)
+        w.end_block()
+        w.align()
+        blob = w.getvalue()
+        for cap in (0, 1, lead, lead + 19, lead + 24, lead + 25, lead + 26, lead + 29, lead + 30, lead + 31, lead + 60):
+            assert_same(eng, blob, "deflate", cap, what="distance error vs overflow, lead %d cap %d" % (lead, cap))
+        assert assert_same(eng, blob, "deflate", lead + 25)["flag"] == "error"
+        assert assert_same(eng, blob, "deflate", lead + 24)["flag"] == "overflow"
     # bit flips inside compressed data: whatever 3bz does (error, underrun, garbage+adler error), we do
     rng = random.Random(11)
     c = zlib.compressobj(6, zlib.DEFLATED, -15)

@@ -153,6 +153,7 @@ struct StreamPlan {
   int32_t status = 0;             // final per-stream status once done
   uint64_t total_out = 0;
   uint64_t in_end_bit = 0;
+  uint64_t boundary_bit = 0;  // last flush boundary the chain is known to have landed on (resume / shard seam)
   uint32_t trailer0 = 0, trailer1 = 0, trailer_have = 0;
   bool saw_final = false;
   uint32_t seg_first = 0, seg_count = 0;
@@ -539,7 +540,10 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     R.segments = nseg;
     R.out_total = S.total_out;
     R.out_len = overflow ? cap : S.total_out;
-    R.in_consumed = S.saw_final ? (S.in_end_bit / 8 - S.in_off) : 0;
+    // not finished: the last flush boundary (octet offset just after its 00 00 FF FF) the block chain landed on
+    // — everything before it is decoded and delivered, a decoder may be restarted there (tbz_amd.h)
+    R.in_consumed = S.saw_final ? (S.in_end_bit / 8 - S.in_off)
+                                : (S.boundary_bit / 8 > S.in_off ? S.boundary_bit / 8 - S.in_off : 0);
     R.trailer_check = S.trailer0;
     R.trailer_isize = S.trailer1;
     if (S.saw_final) R.flags |= 2;
@@ -592,14 +596,16 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       StreamPlan& S = sp[s];
       const K3Stream& k = h_k3s[s];
       S.total_out = k.total_out;
-      S.saw_final = true;
+      S.saw_final = k.last.status == SEG_FINAL;  // else: the last item ran out of input (every other one landed)
       S.trailer0 = k.last.trailer0;
       S.trailer1 = k.last.trailer1;
       S.trailer_have = k.last.trailer_have;
       S.in_end_bit = k.last.end_bit;
-      S.status = TBZ_FINISHED;
+      S.boundary_bit = S.n_items > 1 ? k.last_start : 0;
+      if (k.last.status == SEG_UNDERRUN && k.last.pad && !(k.last.end_bit & 7)) S.boundary_bit = k.last.end_bit;
+      S.status = S.saw_final ? TBZ_FINISHED : TBZ_INPUT_UNDERRUN;
       S.done = true;
-      fill_result(s, TBZ_FINISHED, (uint32_t)k.nonempty);
+      fill_result(s, S.status, (uint32_t)k.nonempty);
     }
   } else {
   if ((r = fetch_host_tables())) return r;
@@ -637,6 +643,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       uint32_t mk = is_fixup ? q.land_marker : 0;
       if (is_fixup) S.cur_item = S.first_item + 1 + (mk - S.first_marker);
       else S.cur_item += 1;
+      if (S.cur_item < S.first_item + S.n_items) S.boundary_bit = items[S.cur_item].start_bit;
       return;
     }
     if (q.status == SEG_FINAL) {
@@ -658,6 +665,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if (q.status == SEG_UNDERRUN) {
       S.status = TBZ_INPUT_UNDERRUN;
       S.in_end_bit = q.end_bit;
+      if (q.pad && !(q.end_bit & 7)) S.boundary_bit = q.end_bit;  // ran out exactly at an octet-aligned block start
       S.done = true;
       return;
     }
@@ -880,6 +888,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     }
     for (size_t s = 0; s < n; s++) {
       tbz_result& R = results[s];
+      if (cl[s] == 0) sums[s] = init[s];  // (the fused partials cover whatever K2 wrote)
       if (format == TBZ_FORMAT_ZLIB) R.adler32 = sums[s];
       else R.crc32 = sums[s];
     }

@@ -1001,7 +1001,7 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
   }
   r.tok_words = T8 * 8;
   r.n_runs = T8 ? 1u : 0u;
-  r.pad = 0;
+  r.pad = (status == SEG_UNDERRUN && st.fail_pos == blk_pos) ? 1u : 0u;  // ran out exactly where a block starts
   r.status = status;
   r.max_deficit = st.deficit;
   r.trailer0 = tr0;
@@ -2174,7 +2174,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
       r.tok_words = gs.T;
       r.n_runs = gs.nruns;
     }
-    r.pad = 0;
+    r.pad = (gs.status == SEG_UNDERRUN && gs.fail_pos == gs.blk_pos) ? 1u : 0u;  // ran out exactly where a block starts
     r.status = gs.status;
     r.max_deficit = gs.deficit;
     r.trailer0 = gs.tr0;
@@ -2733,13 +2733,14 @@ TBZ_KERNEL_WG(128, 2) void tbz_k2_lz77_dual(K2Params P) {
 // decoded the final block and no match reaches behind its own segment, that chain is the identity:
 // these kernels prove it, scan the segment sizes and write K2's Seg/Group tables themselves, so
 // the host reads back one small record per stream instead of walking 64 bytes per segment.
-// Anything else (false markers, repairs, sync-flush history, errors, underrun) -> glob.not_simple
+// Anything else (false markers, repairs, sync-flush history, errors) -> glob.not_simple
 // and the host's general path decides.
 // ================================================================================================
 constexpr u32 K3_TILE = 1024;  // items per workgroup
 struct K3Stream {              // per stream, written by the device
   u64 total_out, tok_words, nonempty;
   SegResult last;              // result of the stream's last item (trailer, end position)
+  u64 last_start;              // where that item starts (bit): the last flush boundary the chain landed on
 };
 struct K3Global {
   u32 not_simple, n_big;
@@ -2772,7 +2773,8 @@ TBZ_KERNEL void tbz_k3_tile_sums(K3Params P) {
     const SegResult q = P.res[i];
     const u32 s = P.items[i].stream;
     const bool last = i - P.first_item[s] == P.n_items_s[s] - 1;
-    const bool ok = q.status == (last ? SEG_FINAL : SEG_LANDED) && q.max_deficit == 0;
+    // (a last item that ran out of input is as good as one that met the final block: its tokens stand)
+    const bool ok = (q.status == (last ? SEG_FINAL : SEG_LANDED) || (last && q.status == SEG_UNDERRUN)) && q.max_deficit == 0;
     bad |= ok ? 0u : 1u;
     so += q.out_bytes;
     sw += q.tok_words;
@@ -2894,6 +2896,7 @@ TBZ_KERNEL void tbz_k3_emit(K3Params P) {
       st.tok_words = 0;   // token words are only totalled for the whole call (below)
       st.nonempty = P.gne[i] - P.gne[f] + ((q.out_bytes | q.tok_words) ? 1u : 0u);
       st.last = q;
+      st.last_start = im.start_bit;
       P.streams[s] = st;
     }
   }
@@ -2903,6 +2906,7 @@ TBZ_KERNEL void tbz_k3_emit(K3Params P) {
     tot.tok_words = P.tile_sums[T1 + P.n_tiles];
     tot.nonempty = P.tile_sums[2 * T1 + P.n_tiles];
     tot.last = SegResult{};
+    tot.last_start = 0;
     P.streams[P.n_streams] = tot;
   }
 }

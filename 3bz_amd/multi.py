@@ -58,3 +58,183 @@ def exchange_results(local_results, owner, rank, world, dist, torch, device="cpu
         for k, i in enumerate(per_rank[r]):
             out[i] = recs[k]
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# ONE flush-delimited stream across ranks: contiguous ranges of its segments per
+# rank, one exchange of fixed-size records, seams proven by the ranks' own results.
+#
+# A deflate stream may be entered at any block boundary (deflate.lisp:518-528 reads BFINAL/BTYPE with no
+# other state), and the octet after a flush marker 00 00 FF FF is one — if the marker is real.  So rank r
+# decodes [cut_r, cut_r+1) where cut_r is the end of the first marker at or after r*C/W: rank 0 in the
+# stream's own format (container header), the others as raw deflate.  Nobody trusts a cut: a rank that
+# is not the last reports `input-underrun` with in_consumed == its range length exactly when its block
+# chain — started at cut_r — ran out of input just where a block starts (tbz_amd.h).  By induction from
+# rank 0's true start, all seams clean  =>  every cut is a true block boundary and the concatenation of
+# the parts is what a front-to-back decoder produces; a match that reaches before a cut (sync-flush
+# history) is `distance before start` on that rank, which is not clean.  Anything not clean — false
+# marker at a cut, history across a cut, any error, trailer or checksum mismatch — and rank 0 decodes
+# the whole stream by the ordinary path, so statuses and errors are exactly the single-GPU ones.
+# Exchange: one all_gather of 8 x int64 per rank (status, lengths, checksum partial); the checksum of
+# the whole is the ordered combine of the partials (adler32: zlib.lisp:97-102 / crc32: gzip.lisp:80-81
+# chain per call in the reference; here they combine algebraically).
+# ------------------------------------------------------------------------------------------------
+MARK = b"\x00\x00\xff\xff"
+FMT_DEFLATE, FMT_ZLIB, FMT_GZIP = 0, 1, 2
+_BASE = 65521
+
+
+def adler32_combine(a1, a2, len2):
+    """adler32 of A||B from adler32(A), adler32(B), len(B)   (s1 | s2 << 16, checksums.lisp:18-62)"""
+    s1a, s2a, s1b, s2b = a1 & 0xFFFF, a1 >> 16, a2 & 0xFFFF, a2 >> 16
+    s1 = (s1a + s1b - 1) % _BASE
+    s2 = (s2a + s2b + (len2 % _BASE) * (s1a - 1)) % _BASE
+    return s1 | (s2 << 16)
+
+
+def _gf2_times(mat, vec):
+    s, i = 0, 0
+    while vec:
+        if vec & 1:
+            s ^= mat[i]
+        vec >>= 1
+        i += 1
+    return s
+
+
+def crc32_combine(c1, c2, len2):
+    """crc32 of A||B from the finalised crc32(A), crc32(B), len(B): multiply c1 by x^(8 len2) mod the
+    reflected polynomial #xedb88320 (checksums.lisp:177-193) by repeated squaring of the shift operator"""
+    if len2 <= 0:
+        return c1
+    odd = [0xEDB88320] + [1 << i for i in range(31)]           # shift by one zero bit
+    even = [_gf2_times(odd, odd[i]) for i in range(32)]        # two
+    odd = [_gf2_times(even, even[i]) for i in range(32)]       # four
+    while True:
+        even = [_gf2_times(odd, odd[i]) for i in range(32)]    # first pass: one zero OCTET
+        if len2 & 1:
+            c1 = _gf2_times(even, c1)
+        len2 >>= 1
+        if not len2:
+            break
+        odd = [_gf2_times(even, even[i]) for i in range(32)]
+        if len2 & 1:
+            c1 = _gf2_times(odd, c1)
+        len2 >>= 1
+        if not len2:
+            break
+    return c1 ^ c2
+
+
+def shard_plan(data, world, start=0, end=None):
+    """world+1 cut points in `data[start:end]`: cut_r = end of the first flush marker at or after the r-th
+    equal share of the compressed octets (a range may be empty when markers are scarce)"""
+    end = len(data) if end is None else end
+    cuts = [start]
+    for r in range(1, world):
+        target = max(cuts[-1], start + (end - start) * r // world)
+        p = data.find(MARK, target, end)
+        cuts.append(end if p < 0 else p + 4)
+    cuts.append(end)
+    return cuts
+
+
+def shard_decode(eng, data, fmt, cuts, r):
+    """rank r's part: decode data[cuts[r]:cuts[r+1]] into a device buffer of exactly its size.
+    Returns (record, d_out, n): record = 8 ints for the exchange; the caller owns d_out (eng.free)."""
+    lo, hi = cuts[r], cuts[r + 1]
+    f = fmt if r == 0 else FMT_DEFLATE
+    if hi == lo and r > 0:
+        return [1, 0, 0, 0, 0, 0, 0, 0], None, 0   # nothing to do: trivially clean
+    sz = eng.inflate_size(data, f, lo, hi)          # K1 only: how much output this range makes
+    n = int(sz.out_total) if sz.status >= 0 else 0
+    d_in = eng.malloc(hi - lo + 64)
+    d_out = eng.malloc(n + 64)
+    try:
+        eng.h2d(d_in, memoryview(data)[lo:hi] if not isinstance(data, bytes) else data[lo:hi])
+        res = eng.inflate_device(d_in, hi - lo, d_out, n, f)
+    finally:
+        eng.free(d_in)
+    got = int(res.out_len) if res.status >= 0 else 0
+    ck = 0
+    if res.status in (0, 1) and fmt != FMT_DEFLATE:
+        if fmt == FMT_ZLIB:
+            s1, s2 = eng.adler32_device(d_out, got, 1, 0)
+            ck = s1 | (s2 << 16)
+        else:
+            ck = eng.crc32_device(d_out, got, 0)
+    rec = [int(res.status), got, int(res.in_consumed), hi - lo, ck, int(res.flags), 0, 0]
+    return rec, d_out, got
+
+
+def shard_verdict(recs, data, fmt, cuts):
+    """the same decision on every rank from the gathered records: {"ok": bool, ...}.  ok => "offsets"
+    (where each rank's part starts in the output), "total", "check", "in_consumed"."""
+    world = len(recs)
+    live = [r for r in range(world) if cuts[r + 1] > cuts[r] or r == 0]
+    last = live[-1]
+    for r in live:
+        status, got, consumed, rlen = recs[r][0], recs[r][1], recs[r][2], recs[r][3]
+        if r != last and not (status == 1 and consumed == rlen):
+            return {"ok": False, "why": "seam after rank %d not clean (status %d)" % (r, status)}
+        if r == last and status != 0:
+            return {"ok": False, "why": "last part: status %d" % status}
+    offsets, total = [], 0
+    for r in range(world):
+        offsets.append(total)
+        total += recs[r][1]
+    check = None
+    consumed = cuts[last] - cuts[0] + recs[last][2]
+    if fmt != FMT_DEFLATE and last != 0:   # (last == 0: the engine itself checked the trailer)
+        comb = adler32_combine if fmt == FMT_ZLIB else crc32_combine
+        check = recs[live[0]][4]
+        for r in live[1:]:
+            check = comb(check, recs[r][4], recs[r][1])
+        at = cuts[last] + recs[last][2]    # the raw-deflate part ends at its final block: the trailer follows
+        need = 4 if fmt == FMT_ZLIB else 8
+        if at + need > cuts[-1]:
+            return {"ok": False, "why": "trailer incomplete"}
+        stored = int.from_bytes(data[at:at + 4], "big" if fmt == FMT_ZLIB else "little")
+        if stored != check:
+            return {"ok": False, "why": "checksum mismatch"}
+        consumed += need
+    elif fmt != FMT_DEFLATE:
+        check = recs[0][4]
+    return {"ok": True, "offsets": offsets, "total": total, "check": check, "in_consumed": consumed}
+
+
+def inflate_sharded(eng, data, fmt, rank, world, dist, torch, device="cpu"):
+    """decode ONE stream with all ranks.  Returns a dict: "sharded" (bool), "status", "total", "check",
+    and this rank's part: "d_out" (device pointer or None), "offset", "len".  When the stream does not
+    shard (see above) rank 0 holds everything and "status" is the ordinary single-GPU status."""
+    cuts = shard_plan(data, world)
+    rec, d_out, n = shard_decode(eng, data, fmt, cuts, rank)
+    mine = torch.tensor(rec, dtype=torch.int64, device=device)
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    recs = [[int(x) for x in g.cpu().tolist()] for g in gathered]
+    v = shard_verdict(recs, data, fmt, cuts)
+    if v["ok"]:
+        return {"sharded": True, "status": 0, "total": v["total"], "check": v["check"],
+                "in_consumed": v["in_consumed"], "d_out": d_out, "offset": v["offsets"][rank], "len": n}
+    if d_out is not None:
+        eng.free(d_out)
+    out = {"sharded": False, "why": v["why"], "d_out": None, "offset": 0, "len": 0}
+    rec = [0] * 8
+    if rank == 0:   # the ordinary path, on one GPU: its result IS the answer
+        sz = eng.inflate_size(data, fmt)
+        cap = int(sz.out_total) if sz.status >= 0 else 0
+        d_in, d_o = eng.malloc(len(data) + 64), eng.malloc(cap + 64)
+        try:
+            eng.h2d(d_in, data)
+            res = eng.inflate_device(d_in, len(data), d_o, cap, fmt)
+        finally:
+            eng.free(d_in)
+        got = int(res.out_len) if res.status >= 0 else 0
+        rec = [int(res.status), got, int(res.in_consumed), len(data), int(res.adler32 if fmt == FMT_ZLIB else res.crc32), 0, 0, 0]
+        out.update(d_out=d_o, len=got)
+    t = torch.tensor(rec, dtype=torch.int64, device=device)
+    dist.broadcast(t, src=0)
+    rec = [int(x) for x in t.cpu().tolist()]
+    out.update(status=rec[0], total=rec[1], check=rec[4], in_consumed=rec[2])
+    return out

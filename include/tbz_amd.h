@@ -73,7 +73,13 @@ typedef struct tbz_result {
   uint64_t out_len;      /* octets valid in the output = what `decompress` returns
                             (deflate.lisp:730); for gzip/zlib early returns see api notes */
   uint64_t out_total;    /* full decompressed size when known (== out_len when finished) */
-  uint64_t in_consumed;  /* input octets consumed including header and trailer */
+  uint64_t in_consumed;  /* finished: input octets consumed including header and trailer.  Otherwise the
+                            latest octet-aligned block boundary the decoder is sure of: the offset just
+                            after the last flush marker (00 00 FF FF) the block chain landed on, or the
+                            end of the input when it ran out exactly where a block starts; 0 if none.
+                            Everything before it is decoded and delivered.  (in_consumed == in_len with
+                            status input-underrun: the input is a whole number of blocks — this is how a
+                            stream sharded across GPUs proves its seams, 3bz_amd/multi.py) */
   uint32_t adler32;      /* computed over the output (zlib.lisp:97-102), s1 | s2<<16 */
   uint32_t crc32;        /* computed over the output (gzip.lisp:80-81) */
   uint32_t trailer_check;/* checksum stored in the stream trailer (0 if not reached) */

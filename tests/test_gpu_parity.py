@@ -65,3 +65,10 @@ def test_gpu_config2_128mib_properties(eng):
     assert res.status == 0 and res.out_len == n and res.segments == n // 16384
     assert res.adler32 == a == zlib.adler32(bytes(got))
     assert bytes(got) == p
+
+
+def test_gpu_one_stream_across_ranks(eng):
+    """SURVEY §8e row 2 on the card: the parts of ONE stream that 1/2/3/4/8 ranks would decode, decoded in turn
+    by this GPU; verdict, offsets, combined checksum and octets (the two-process run is tests/test_multirank_gloo.py)"""
+    from tests.test_sharded_stream import shard_cases
+    shard_cases(eng, n=6 << 20)

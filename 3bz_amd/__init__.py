@@ -5,7 +5,8 @@
 The package holds only what the hot path needs: csrc/ (HIP kernels + host engine + C ABI),
 the ctypes binding and the host-side mirror of the reference's API.
 """
-from .api import (Engine, EngineError, ThreeBzError, decompress, decompress_vector, default_engine,  # noqa: F401
+from .api import (Engine, EngineError, ThreeBzError, decompress, decompress_gzip_members, decompress_vector,  # noqa: F401
+                  default_engine,
                   finished, input_underrun, make_deflate_state, make_gzip_state, make_octet_vector_context,
                   make_zlib_state, output_overflow, replace_output_buffer, set_default_engine)
 from ._lib import FORMATS, Result, Timings  # noqa: F401

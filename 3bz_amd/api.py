@@ -355,3 +355,67 @@ def decompress_vector(compressed, format="zlib", start=0, end=None, output=None,
     if res.status != _lib.FINISHED:
         raise ThreeBzError(-20, "incomplete %s stream" % name)
     return buf, res.out_len
+
+
+# ------------------------------------------------------------------------------------------------
+# Multi-member gzip.  3bz decodes the first member and stops (gzip.lisp:277-286): the
+# caller is expected to call again with :start at the next member.  A file of many members is a batch
+# of independent streams once their starts are known — and they are not (a member's length is only
+# known after decoding it).  Same move as for flush markers: every `1f 8b 08` is a CANDIDATE start;
+# all candidate ranges are decoded in one batch call, and a range is a member iff it FINISHED having
+# consumed exactly its octets (header, blocks, CRC32, ISIZE — all verified by the engine).  The walk
+# from offset 0 accepts proven members; a candidate inside a member's data (false magic) shows as a
+# range that did not finish, and the member is decoded again over the merged range.
+# ------------------------------------------------------------------------------------------------
+GZIP_MAGIC = b"\x1f\x8b\x08"
+
+
+def decompress_gzip_members(compressed, start=0, end=None, engine=None):
+    """every member of a gzip file, in order: a list of bytearrays.  Each member is exactly what
+    `(decompress-vector v :format :gzip :start member-offset)` returns; a damaged or incomplete member
+    raises what that call would.  Octets after the last member that do not start a member are ignored
+    (as gzip(1) does)."""
+    eng = engine or default_engine()
+    end = len(compressed) if end is None else end
+    data = bytes(compressed[start:end])
+    cands, p = [0], data.find(GZIP_MAGIC, 1)   # offset 0 is taken as given: the engine reports a bad magic there
+    while p >= 0:
+        cands.append(p)
+        p = data.find(GZIP_MAGIC, p + 1)
+    bounds = cands + [len(data)]
+
+    def isize_hint(lo, hi):  # ISIZE (gzip.lisp:96-101, unchecked there) sizes the buffer; a wrong one just fails the range
+        n = int.from_bytes(data[hi - 4:hi], "little") if hi - lo >= 18 else 0
+        return n if n <= 1032 * (hi - lo) + 64 else 0
+
+    ins = [data[bounds[i]:bounds[i + 1]] for i in range(len(cands))]
+    outs = [bytearray(isize_hint(bounds[i], bounds[i + 1])) for i in range(len(cands))]
+    res = eng.inflate_batch(ins, FORMATS["gzip"], outs)
+    members, i = [], 0
+    while i < len(cands):
+        lo = bounds[i]
+        if res[i].status == _lib.FINISHED and res[i].in_consumed == bounds[i + 1] - lo:
+            del outs[i][res[i].out_len:]   # (ISIZE is not checked by 3bz: it may overstate)
+            members.append(outs[i])
+            i += 1
+            continue
+        # not a whole member: a later candidate lies inside this member's data, or the member is damaged,
+        # or garbage follows it.  Decode from `lo` to the end (the ordinary one-stream call decides).
+        q = eng.inflate_size(data, FORMATS["gzip"], start=lo)
+        if q.status < 0:
+            raise ThreeBzError(q.status, eng.strerror(q.status))
+        if q.status == _lib.INPUT_UNDERRUN:
+            raise ThreeBzError(-20, "incomplete gzip stream")
+        buf = bytearray(q.out_total)
+        r = eng.inflate(data, FORMATS["gzip"], buf, start=lo)
+        if r.status < 0:
+            raise ThreeBzError(r.status, eng.strerror(r.status))
+        if r.status != _lib.FINISHED:
+            raise ThreeBzError(-20, "incomplete gzip stream")
+        members.append(buf)
+        nxt = lo + r.in_consumed
+        while i < len(cands) and bounds[i] < nxt:
+            i += 1
+        if i < len(cands) and bounds[i] != nxt:
+            break  # what follows the member is not a member
+    return members

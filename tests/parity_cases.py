@@ -481,9 +481,43 @@ def case_fuzz(eng, seed=7, n=30):
         assert_same(eng, bytes(b), fmt, 70000, what="fuzz seed %d case %d" % (seed, k))
 
 
+def case_gzip_members(eng, n_members=8, max_len=12_000, n_false=300):
+    """many-member gzip file (SURVEY §8d config 3 as a public call, §8f-4): member starts are found speculatively
+    (every 1f 8b 08 is a candidate, a candidate range is a member iff it finishes having consumed exactly its
+    octets).  Parity is per member: member i must be what the reference yields for
+    (decompress-vector v :format :gzip :start offset_i) — checked against the oracle at the true offsets."""
+    rng = random.Random(0x3B3)
+    plains = [K.enwik_like(rng.randrange(1, max_len), seed=100 + i) for i in range(n_members)] + [b""]
+    plains.insert(3, A.GZIP_MAGIC * n_false)   # a stored member made of magics: false candidates inside it
+    plains.insert(7, bytes(rng.randrange(256) for _ in range(3000)))
+    parts = [pygzip.compress(p, 0 if p[:3] == A.GZIP_MAGIC else rng.choice([1, 6, 9]), mtime=0) for p in plains]
+    blob = b"".join(parts)
+    got = A.decompress_gzip_members(blob, engine=eng)
+    assert len(got) == len(plains)
+    off = 0
+    for g, p, part in zip(got, plains, parts):
+        w = oracle_oneshot(blob, "gzip", len(p) + 8, start=off)
+        assert w["flag"] == "finished" and w["bytes"] == p == bytes(g), ("member at", off)
+        off += len(part)
+    assert [bytes(m) for m in A.decompress_gzip_members(blob + b"\x00trailing", engine=eng)] == plains
+    assert [bytes(m) for m in A.decompress_gzip_members(b"xx" + blob, start=2, engine=eng)] == plains
+    # a damaged / truncated member raises what the one-member call at its offset raises
+    for bad, start in ((blob[:-3], len(blob) - len(parts[-1])), (blob[:len(parts[0]) - 8] + b"\x00" + blob[len(parts[0]) - 7:], 0),
+                       (b"\x1f\x8c" + blob[2:], 0)):
+        w = oracle_oneshot(bad, "gzip", max_len + 8, start=start)
+        try:
+            A.decompress_gzip_members(bad, engine=eng)
+            raise AssertionError("damaged member accepted")
+        except A.ThreeBzError as e:
+            if w["flag"] == "error":
+                assert e.code == w["code"], (e.code, w["code"])
+            else:
+                assert w["flag"] == "underrun" and e.code == -20
+
+
 ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,
              case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_device_buffers,
-             case_checksum_kernels, case_deep_codes, case_chunked_resume, case_fuzz]
+             case_checksum_kernels, case_deep_codes, case_chunked_resume, case_gzip_members, case_fuzz]
 # the cases whose behaviour depends on the K1 flavour (forced-flavour runs skip the rest: checksums, device
 # buffers and the replay protocol go through the same engine calls whatever decodes the Huffman codes)
 K1_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,

@@ -46,6 +46,7 @@ def test_gpu_larger_sizes(eng):
     P.case_containers_and_levels(eng, n=2_000_000)
     P.case_configs_1_3_5(eng, adv_total=8 << 20)
     P.case_device_buffers(eng, n=4 << 20)
+    P.case_gzip_members(eng, n_members=40, max_len=400_000, n_false=3000)
 
 
 def test_gpu_config2_128mib_properties(eng):
@@ -72,3 +73,44 @@ def test_gpu_one_stream_across_ranks(eng):
     by this GPU; verdict, offsets, combined checksum and octets (the two-process run is tests/test_multirank_gloo.py)"""
     from tests.test_sharded_stream import shard_cases
     shard_cases(eng, n=6 << 20)
+
+
+_RCCL_WORKER = r'''
+import importlib, os, sys, zlib
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from tools import corpus as K
+T = importlib.import_module("3bz_amd")
+M = importlib.import_module("3bz_amd.multi")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+eng = T.Engine(0)
+s, p, a = K.zlib_flush_stream(4 << 20, seed=0x3B9, block=16384)
+o = M.inflate_sharded(eng, s, 1, 0, 1, dist, torch, device="cuda")
+assert o["sharded"] and o["status"] == 0 and o["total"] == len(p) and o["check"] == a and o["len"] == len(p), o
+out = bytearray(len(p))
+eng.d2h(out, o["d_out"], len(p))
+eng.free(o["d_out"])
+assert bytes(out) == p
+bad = s[:-1] + bytes([s[-1] ^ 1])
+o = M.inflate_sharded(eng, bad, 1, 0, 1, dist, torch, device="cuda")
+assert not o["sharded"] and o["status"] == -11, o
+recs = M.exchange_results([eng.inflate(s, 1, out)], [0], 0, 1, dist, torch, device="cuda")
+assert recs[0].status == 0 and recs[0].adler32 == a
+dist.destroy_process_group()
+print("RCCL_OK")
+'''
+
+
+def test_gpu_record_exchange_over_rccl(tmp_path):
+    """the two exchanges of 3bz_amd/multi.py (result records; one stream across ranks) with CUDA tensors over
+    the "nccl" backend (= RCCL), one rank — the only world size a one-GPU box offers; world_size 2 runs over gloo
+    in tests/test_multirank_gloo.py, N = 2/4/8 over xGMI in bench.py under the driver"""
+    import subprocess
+    import sys
+    w = tmp_path / "rccl_worker.py"
+    w.write_text(_RCCL_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(w), root], capture_output=True, text=True, env=env, timeout=600)
+    assert "RCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

@@ -1192,6 +1192,15 @@ TBZ_DEV u32 kg_lit_entry(u32 sym, u32 L) {
   return sym < 256 ? (L | (sym << 4)) : sym == 256 ? (L | (7u << 12)) : sym > 285 ? (L | (6u << 12)) : m;
 }
 
+// first-/second-level entry of a distance code: everything the hot loop needs, pre-chewed —
+// bits 0-3 code length | 4-8 symbol | 9-12 extra-bit count | 13-14 mantissa m | 15 valid (symbol < 30), with
+// distance - 1 = (m << extra-bit count) + extra bits  (RFC 1951 3.2.5: m = 2|(sym&1) from symbol 2 on)
+TBZ_DEV u32 kg_dist_entry(u32 sym, u32 L) {
+  const u32 DX = sym < 4 ? 0u : (sym >> 1) - 1;
+  const u32 m = sym < 2 ? sym : (2u | (sym & 1));
+  return L | (sym << 4) | (DX << 9) | (m << 13) | (sym < 30 ? 0x8000u : 0u);
+}
+
 // Canonical code of one alphabet built by the G lanes of a gang (same acceptance rules as build_canon:
 // huffman-tree.lisp:112-122), plus its two-level lookup table.  EVERY lane of the wave calls this (it
 // contains wave collectives); a gang that is not building passes n = 0 and touches nothing.
@@ -1315,7 +1324,7 @@ TBZ_DEV i32 kg_build(const u8* lens, u32 n, SymT* sorted, u32* lim, u16* dlt, u1
         if (L <= TB) {
           const u32 slot = ((r16 >> (16 - L)) + dlt[L]) & 0xffffu;
           const u32 sym = sorted[slot < n ? slot : 0];
-          entry = LIT ? kg_lit_entry(sym, L) : (L | (sym << 4));
+          entry = LIT ? kg_lit_entry(sym, L) : kg_dist_entry(sym, L);
           end_r = ((r >> (TB - L)) + 1) << (TB - L);
         } else {
           const u32 last = r16 | ((1u << SH) - 1);
@@ -1347,7 +1356,7 @@ TBZ_DEV i32 kg_build(const u8* lens, u32 n, SymT* sorted, u32* lim, u16* dlt, u1
       const u32 b = (e1 >> 4) & 7, po = e1 >> 7, xl = L - TB;
       const u32 j0 = tbz_brev32(cd & ((1u << xl) - 1)) >> (32 - xl);
       const u32 sym = sorted[k];
-      const u32 entry = LIT ? kg_lit_entry(sym, L) : (L | (sym << 4));
+      const u32 entry = LIT ? kg_lit_entry(sym, L) : kg_dist_entry(sym, L);
       for (u32 j = j0; j < (1u << b); j += 1u << xl) fast[(1u << TB) + po + j] = (u16)entry;
     }
   }
@@ -1590,7 +1599,7 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, T
       if (((e & 15) == 0) & (e != 0)) e = gt.lfast[(1u << KG_TBL) + (e >> 7) + tbz_bfe(pk, KG_TBL, (e >> 4) & 7)];
       const u32 L = e & 15;
       const bool isM = e >= 0x8000u;
-      const u32 X = (e >> 12) & (isM ? 7u : 0u);
+      const u32 X = tbz_bfe(e, 12, 3);  // literals carry 0 here; end-of-block / invalid entries are not `good` below
       const u32 lenx = ((e >> 4) & 0xffu) + tbz_bfe(pk, L, X);  // literal octet, or match length - 3
       const u32 n1 = L + X, o2 = o + n1;
       const u32 pa = tbz_alignbit(hi, lo, o2 & 31), pb = tbz_alignbit(nx, hi, o2 & 31);
@@ -1599,13 +1608,10 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, T
       const u32 e2 = gt.lfast[(pk >> L) & ((1u << KG_TBL) - 1)];
       u32 ed = gt.dfast[pd & ((1u << KG_TBD) - 1)];
       if (isM & ((ed & 15) == 0) & (ed != 0)) ed = gt.dfast[(1u << KG_TBD) + (ed >> 7) + tbz_bfe(pd, KG_TBD, (ed >> 4) & 7)];
-      const u32 DL = ed & 15, ds = (ed >> 4) & 31;
-      const u32 de = ds >> 1;                       // RFC 1951 distance base / extra bits, as dist_base_extra
-      const u32 DX = ds < 4 ? 0u : de - 1;
-      const u32 dbase = ds < 4 ? ds + 1 : 1 + ((2 + (ds & 1)) << ((de - 1) & 15));
-      const u32 dist = dbase + tbz_bfe(pd, DL, DX);
+      const u32 DL = ed & 15, DX = tbz_bfe(ed, 9, 4);                      // kg_dist_entry
+      const u32 dm1 = (tbz_bfe(ed, 13, 2) << DX) + tbz_bfe(pd, DL, DX);  // distance - 1
       const u32 nb1 = isM ? n1 + DL + DX : L;
-      const bool okm = (DL != 0) & (ds < 30), okl = e < 0x1000u;
+      const bool okm = ed >= 0x8000u, okl = e < 0x1000u;
       const i32 rem1 = rem - (i32)nb1;
       const bool good = (L != 0) & (isM ? okm : okl) & (rem1 >= 0);
       if (!good) {
@@ -1639,9 +1645,9 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, T
         // literal: 0x00bb (the high half is the second literal of a pair, or overwritten by the next token);
         // match: head | payload << 16
 #if KG_EXP != 4
-        tok_put2(to, isM ? (TOK_MATCH | lenx | ((dist - 1) << 16)) : (lenx | (((e2 >> 4) & 0xffu) << 16)));
+        tok_put2(to, isM ? (TOK_MATCH | lenx | (dm1 << 16)) : (lenx | (((e2 >> 4) & 0xffu) << 16)));
 #endif
-        const i32 d = (i32)dist - (i32)out;
+        const i32 d = (i32)dm1 + 1 - (i32)out;
         mdef = isM & (d > mdef) ? d : mdef;
         n += (isM | pair) ? 2u : 1u;
         out += isM ? lenx + 3 : (pair ? 2u : 1u);

@@ -1096,12 +1096,6 @@ TBZ_KERNEL void tbz_k1h_headers(K1hParams P) {
 // SUB adapts to what is left of the item (the next marker is where the segment is expected to end),
 // so a 16 KiB-segment item is one round.
 // ================================================================================================
-#ifndef K2_EXP
-#define K2_EXP 0
-#endif
-#ifndef KG_EXP
-#define KG_EXP 0
-#endif
 constexpr u32 KG_TBL = 9;               // index bits of the literal/length lookup table (first level)
 constexpr u32 KG_TBD = 8;               // index bits of the distance lookup table (first level)
 constexpr u32 KG_LPOOL = 352;           // second-level entries (codes longer than the index); zlib's ENOUGH bound is 340
@@ -1109,10 +1103,7 @@ constexpr u32 KG_DPOOL = 128;           //   … if a code needs more, its long 
 constexpr u32 KG_RING_STRIDE = 36;     // LDS octets per lane of the token output ring (16 words + one dword of skew)
 constexpr u32 KG_SUB_MIN = 1024;        // bits of bitstream per lane per round
 constexpr u32 KG_SUB_MAX = 8192;
-#ifndef KG_OVL_BITS
-#define KG_OVL_BITS 512
-#endif
-constexpr u32 KG_OVL = KG_OVL_BITS;             // run-up bits before a lane's sub-range
+constexpr u32 KG_OVL = 512;             // run-up bits before a lane's sub-range
 
 // lookup entries (u16).  bits 0-3: code length; 0 = not a symbol:
 //     whole entry 0          unassigned pattern, or a long code without a second-level table -> exact step
@@ -1621,11 +1612,7 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, T
       // a second literal rides along when the code after a literal is a first-level literal too (it must
       // start before the target and end inside the limit): literal-dense sub-ranges are the slow lanes
       const u32 L2 = e2 & 15;
-#ifdef KG_NO_PAIR
-      const bool pair = false;
-#else
       const bool pair = !isM & (L2 != 0) & (e2 < 0x1000u) & (rel + L < tgt) & (rem1 >= (i32)L2);
-#endif
       const u32 nbits = nb1 + (pair ? L2 : 0u);
       const i32 rem2 = rem - (i32)nbits;
       rem = rem2;
@@ -1644,9 +1631,7 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, T
       if (REC) {
         // literal: 0x00bb (the high half is the second literal of a pair, or overwritten by the next token);
         // match: head | payload << 16
-#if KG_EXP != 4
         tok_put2(to, isM ? (TOK_MATCH | lenx | (dm1 << 16)) : (lenx | (((e2 >> 4) & 0xffu) << 16)));
-#endif
         const i32 d = (i32)dm1 + 1 - (i32)out;
         mdef = isM & (d > mdef) ? d : mdef;
         n += (isM | pair) ? 2u : 1u;
@@ -2023,9 +2008,6 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     if (tbz_ballot(gs.mode != GM_DONE) == 0) break;
     // ---- H: leaders whose gang is between blocks parse the next header
     if (leader && gs.mode == GM_HEADER) kg_leader_header(gt, gs, st, it, P, tok0, fmt, fixup, idx);
-#if KG_EXP == 3
-    if (leader) { gs.mode = GM_DONE; if (gs.status == 0) gs.status = E_BTYPE; }
-#endif
     tbz_sync();
     // ---- B: gangs with a new code build it together (wave-uniform branch: collectives inside)
     const bool building = gs.mode == GM_BUILD;
@@ -2053,10 +2035,6 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
       }
       tbz_sync();
     }
-#if KG_EXP == 2
-    if (leader) { gs.mode = GM_DONE; if (gs.status == 0) gs.status = E_BTYPE; }
-    tbz_sync();
-#endif
     // ---- R: one round for the gangs that are inside a Huffman block
     const bool inblk = gs.mode == GM_BLOCK;
     const u64 Pb = gs.P;
@@ -2113,9 +2091,6 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     // and the table must not outgrow the item's span; else the item is left to the one-lane kernel
     const u64 end_lv = tbz_shfl64(s_lo + nn, (int)lv);
     const bool fits = !inblk || (end_lv <= (e_last & ~7ull) && gs.nruns + tot_r <= kg_run_slots(it, e_last));
-#ifdef TBZ_EMU_TRACE
-    if (getenv("TBZ_DEBUG3") && inblk) fprintf(stderr, "k1g item %llu Pb %llu lane g %u valid %d c %llu e %llu n %u out %u flag %u mdef %d\n", (unsigned long long)it.start_bit, (unsigned long long)Pb, g, (int)valid, (unsigned long long)ro.c, (unsigned long long)ro.e, ro.n, ro.out, ro.flag, ro.mdef);
-#endif
     if (hasrun && fits) {  // (the lane has padded its run to the granule already)
       RunRec rr;
       rr.off8 = (u32)((s_lo - (it.start_bit & ~7ull)) >> 3);
@@ -2322,13 +2297,7 @@ TBZ_DEV void k2_resolve(u8* win, u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist
   // writes that cover exactly [rd, rd + len)
   const bool fastable = len <= K2_SHORT && dist >= len && (LINEAR || (rs + 32 <= K2_WIN && rd + 32 <= K2_WIN));
   tbz_sync();
-#if K2_EXP == 1
-  if (pend) {
-#elif K2_EXP == 2
-  if (false) {
-#else
   while (pend) {
-#endif
     const u32 first = (u32)tbz_ffs64(pend) - 1;
     const i32 hwm = (i32)tbz_readlane(dofs, first);
     const bool ready = (pend & lane_bit) && need <= hwm;
@@ -2419,9 +2388,6 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
       rr.off8 = 0;
       rr.n8 = 0;
       if (rbase + lane < sg.n_runs) rr = rt[rbase + lane];
-#ifdef TBZ_EMU_TRACE
-      if (getenv("TBZ_DEBUG3") && rbase + lane < sg.n_runs) fprintf(stderr, "k2 run[%u] of seg tok_index %llu words %llu: off8 %u n8 %u\n", rbase + lane, (unsigned long long)sg.tok_index, (unsigned long long)sg.tok_words, rr.off8, rr.n8);
-#endif
       const u32 inc = tbz_wave_incl_scan_u32(rr.n8);
       tbz_sync();
       rE[lane] = inc;

@@ -18,7 +18,7 @@ class Result(C.Structure):
     _fields_ = [("status", C.c_int32), ("segments", C.c_uint32), ("out_len", C.c_uint64),
                 ("out_total", C.c_uint64), ("in_consumed", C.c_uint64), ("adler32", C.c_uint32),
                 ("crc32", C.c_uint32), ("trailer_check", C.c_uint32), ("trailer_isize", C.c_uint32),
-                ("flags", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+                ("flags", C.c_uint32), ("reserved", C.c_uint32), ("boundary_out", C.c_uint64)]
 
 
 class Timings(C.Structure):

@@ -195,8 +195,15 @@ class DeflateState:
         self._calls = 0
         self.result = None
         self._seen = bytearray()   # every input octet given to this state (resume replays it)
-        self._full = None          # scratch vector of the last replay
+        self._full = None          # scratch vector of the last replay: output octets from _full_out on
+        self._full_out = 0
         self._delivered = 0        # output octets handed out so far
+        # resume base: a proven block boundary (tbz_result.in_consumed) from which replays start
+        self._base_in = 0          # input octets before it
+        self._base_out = 0         # output octets before it
+        self._base_ck = None       # checksum of those output octets (None: the format's initial value)
+        self._cand = None          # (in, out, ck) of the latest boundary reported, adopted once its output is delivered
+        self._no_base = False      # the stream needs history across boundaries (or failed): replay from 0
 
 
 class ZlibState(DeflateState):
@@ -247,6 +254,79 @@ def replace_output_buffer(state, buffer):
     state.output_overflow = False
 
 
+def _chain_checksum(eng, fmt, d_buf, n, ck):
+    """checksum of n more output octets at d_buf, continuing from ck (None = initial value)"""
+    if fmt == FORMATS["zlib"]:
+        a = 1 if ck is None else ck
+        s1, s2 = eng.adler32_device(d_buf, n, a & 0xFFFF, a >> 16)
+        return s1 | (s2 << 16)
+    return eng.crc32_device(d_buf, n, 0 if ck is None else ck)
+
+
+def _replay(eng, state):
+    """decode everything the state has seen from its resume base on (one engine call into a device scratch
+    buffer).  Leaves the octets in state._full (they continue the output at state._full_out), the status in
+    state._full_status / _full_flags and the latest proven boundary in state._cand."""
+    deflate = FORMATS["deflate"]
+    while True:
+        base_in, base_out = state._base_in, state._base_out
+        tail = bytes(state._seen[base_in:])
+        fmt = state.format if base_in == 0 else deflate   # past the container header: blocks only
+        status, flags, full, cand = 0, 0, bytearray(0), None
+        size = eng.inflate_size(tail, fmt)
+        res = size
+        status = size.status
+        if status >= 0:
+            n = int(size.out_total)
+            d_in, d_out = eng.malloc(len(tail) + 64), eng.malloc(n + 64)
+            try:
+                eng.h2d(d_in, tail)
+                res = eng.inflate_device(d_in, len(tail), d_out, n, fmt)
+                status, flags = res.status, res.flags
+                got = int(res.out_len) if status >= 0 else 0
+                if status == _lib.FINISHED and base_in and state.format != deflate:
+                    # the engine decoded raw blocks: the container's trailer is checked here as zlib.lisp:80-95 /
+                    # gzip.lisp:78-106 do (checksum of ALL output = the base's, continued over these octets)
+                    ck = _chain_checksum(eng, state.format, d_out, got, state._base_ck)
+                    end = int(res.in_consumed)
+                    have = len(tail) - end
+                    flags |= 2
+                    if state.format == FORMATS["zlib"]:
+                        if have < 4:
+                            status = _lib.INPUT_UNDERRUN
+                        elif int.from_bytes(tail[end:end + 4], "big") != ck:
+                            status = -11
+                    else:
+                        if have < 4:
+                            status = _lib.INPUT_UNDERRUN
+                        elif int.from_bytes(tail[end:end + 4], "little") != ck:
+                            status = -16
+                        elif have < 8:
+                            status = _lib.INPUT_UNDERRUN
+                elif status == _lib.INPUT_UNDERRUN and not (flags & 2) and res.in_consumed > 0 and not state._no_base:
+                    b_out = int(res.boundary_out)
+                    ck = None if state.format == deflate else _chain_checksum(eng, state.format, d_out, b_out,
+                                                                              state._base_ck)
+                    cand = (base_in + int(res.in_consumed), base_out + b_out, ck)
+                if status >= 0 and got:
+                    full = bytearray(got)
+                    eng.d2h(full, d_out, got)
+            finally:
+                eng.free(d_in)
+                eng.free(d_out)
+        if status < 0 and base_in:
+            # blocks that reach back across the boundary (sync-flush history) fail as "distance before start";
+            # whatever the reason, the whole stream decides: replay from the first octet, for good
+            state._base_in, state._base_out, state._base_ck, state._cand, state._no_base = 0, 0, None, None, True
+            continue
+        state.result = res
+        state._full, state._full_out = full, base_out
+        state._full_status, state._full_flags = status, flags
+        if cand is not None:
+            state._cand = cand
+        return
+
+
 def decompress(context, state, engine=None):
     """api.lisp:3-10.  One call over everything the context holds, on the device.
 
@@ -254,15 +334,20 @@ def decompress(context, state, engine=None):
     octet count, the correct prefix in the buffer.
 
     RESUMING (the chunked protocol of deflate.lisp:114-137: more input after input-underrun, a new buffer after
-    output-overflow) is done by REPLAY on the device: the state keeps every input octet it has been given; a call
-    that brings new input decodes the whole prefix again (one engine call into a scratch vector) and hands out
-    the octets beyond those already delivered; a call that only brings a new output buffer hands out the next
-    slice of the scratch vector.  Same flags, counts and octets as the reference call by call on valid streams
-    (tests: case_chunked_resume); cost O(prefix) per call that brings input, so it suits a few large chunks —
-    a device-resident session that restarts at the last block boundary is SURVEY §8f-2, next.  Deviation: a
-    stream that turns out to be INVALID is reported when the replay first meets the error, which can be a call
-    earlier than the reference (which first hands out the output before the error, and a checksum
-    mismatch only after the last octet)."""
+    output-overflow) is done by REPLAY on the device from the last proven block boundary: the state keeps the
+    input octets it has been given; a call that brings new input decodes again from the resume base (one engine
+    call into a device scratch buffer) and hands out the octets beyond those already delivered; a call that only
+    brings a new output buffer hands out the next slice.  The resume base is the boundary the engine reports for
+    an unfinished stream (tbz_result.in_consumed / boundary_out: the chain of blocks landed there), adopted once
+    all output before it has been delivered; the tail is then decoded as raw deflate, the checksum continues from
+    the base's (tbz_adler32_device / tbz_crc32_device chain) and the container trailer is compared here.  A tail
+    that fails for any reason — blocks that copy from before the boundary, as after Z_SYNC_FLUSH, fail as
+    "distance before start" — sends the state back to replaying from the first octet, so the answer is always
+    the whole stream's.  Cost per call that brings input: O(octets since the last flush boundary) for
+    flush-delimited streams, O(prefix) otherwise.  Same flags, counts and octets as the reference call by call on
+    valid streams (tests: case_chunked_resume).  Deviation: a stream that turns out to be INVALID is reported
+    when the replay first meets the error, which can be a call earlier than the reference (which first hands out
+    the output before the error, and a checksum mismatch only after the last octet)."""
     eng = engine or default_engine()
     first = state._calls == 0
     state._calls += 1
@@ -290,26 +375,23 @@ def decompress(context, state, engine=None):
         return res.out_len
     if state.finished:
         return state.output_offset
-    # ---- resume by replay
+    # ---- resume by replay from the base
     if new or state._full is None:
         state._seen += new
         context.offset = context.end
-        size = eng.inflate_size(bytes(state._seen), state.format)
-        if size.status < 0:
-            raise ThreeBzError(size.status, eng.strerror(size.status))
-        full = bytearray(size.out_total)
-        res = eng.inflate(bytes(state._seen), state.format, full)
-        state.result = res
-        state._full = full
-        state._full_status = res.status
-        state._full_flags = res.flags
+        c = state._cand
+        if c is not None and c[1] <= state._delivered and c[0] > state._base_in:
+            state._base_in, state._base_out, state._base_ck = c   # everything before it has been handed out
+        state._cand = None
+        _replay(eng, state)
     full, status = state._full, state._full_status
     if status < 0:
         raise ThreeBzError(status, eng.strerror(status))
-    avail = len(full)
+    avail = state._full_out + len(full)
     off = state.output_offset
     give = max(0, min(len(state.output_buffer) - off, avail - state._delivered))
-    state.output_buffer[off:off + give] = full[state._delivered:state._delivered + give]
+    src = state._delivered - state._full_out
+    state.output_buffer[off:off + give] = full[src:src + give]
     state.output_offset = off + give
     state._delivered += give
     pending = avail - state._delivered

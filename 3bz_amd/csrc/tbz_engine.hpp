@@ -28,6 +28,7 @@
 #include "../../include/tbz_amd.h"
 #include "tbz_kernels.hpp"
 
+static_assert(sizeof(tbz_result) == 64, "tbz_result is exchanged between ranks as 64-octet records");
 namespace tbz {
 
 struct DevBuf {
@@ -154,6 +155,7 @@ struct StreamPlan {
   uint64_t total_out = 0;
   uint64_t in_end_bit = 0;
   uint64_t boundary_bit = 0;  // last flush boundary the chain is known to have landed on (resume / shard seam)
+  uint64_t boundary_out = 0;  // output octets produced before it
   uint32_t trailer0 = 0, trailer1 = 0, trailer_have = 0;
   bool saw_final = false;
   uint32_t seg_first = 0, seg_count = 0;
@@ -544,6 +546,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     // — everything before it is decoded and delivered, a decoder may be restarted there (tbz_amd.h)
     R.in_consumed = S.saw_final ? (S.in_end_bit / 8 - S.in_off)
                                 : (S.boundary_bit / 8 > S.in_off ? S.boundary_bit / 8 - S.in_off : 0);
+    R.boundary_out = S.saw_final ? S.total_out : (S.boundary_bit / 8 > S.in_off ? S.boundary_out : 0);
     R.trailer_check = S.trailer0;
     R.trailer_isize = S.trailer1;
     if (S.saw_final) R.flags |= 2;
@@ -602,7 +605,11 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       S.trailer_have = k.last.trailer_have;
       S.in_end_bit = k.last.end_bit;
       S.boundary_bit = S.n_items > 1 ? k.last_start : 0;
-      if (k.last.status == SEG_UNDERRUN && k.last.pad && !(k.last.end_bit & 7)) S.boundary_bit = k.last.end_bit;
+      S.boundary_out = k.total_out - k.last.out_bytes;
+      if (k.last.status == SEG_UNDERRUN && k.last.pad && !(k.last.end_bit & 7)) {
+        S.boundary_bit = k.last.end_bit;
+        S.boundary_out = k.total_out;
+      }
       S.status = S.saw_final ? TBZ_FINISHED : TBZ_INPUT_UNDERRUN;
       S.done = true;
       fill_result(s, S.status, (uint32_t)k.nonempty);
@@ -643,7 +650,10 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       uint32_t mk = is_fixup ? q.land_marker : 0;
       if (is_fixup) S.cur_item = S.first_item + 1 + (mk - S.first_marker);
       else S.cur_item += 1;
-      if (S.cur_item < S.first_item + S.n_items) S.boundary_bit = items[S.cur_item].start_bit;
+      if (S.cur_item < S.first_item + S.n_items) {
+        S.boundary_bit = items[S.cur_item].start_bit;
+        S.boundary_out = S.total_out;
+      }
       return;
     }
     if (q.status == SEG_FINAL) {
@@ -665,7 +675,10 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if (q.status == SEG_UNDERRUN) {
       S.status = TBZ_INPUT_UNDERRUN;
       S.in_end_bit = q.end_bit;
-      if (q.pad && !(q.end_bit & 7)) S.boundary_bit = q.end_bit;  // ran out exactly at an octet-aligned block start
+      if (q.pad && !(q.end_bit & 7)) {  // ran out exactly at an octet-aligned block start
+        S.boundary_bit = q.end_bit;
+        S.boundary_out = S.total_out;
+      }
       S.done = true;
       return;
     }

@@ -85,7 +85,9 @@ typedef struct tbz_result {
   uint32_t trailer_check;/* checksum stored in the stream trailer (0 if not reached) */
   uint32_t trailer_isize;/* gzip ISIZE (read, never compared: gzip.lisp:95-106,:278) */
   uint32_t flags;        /* bit0: checksum verified against trailer; bit1: BFINAL block decoded */
-  uint32_t reserved[3];
+  uint32_t reserved;
+  uint64_t boundary_out; /* not finished: output octets produced by the input before in_consumed (a decoder
+                            restarted at that boundary continues the output there); finished: out_len */
 } tbz_result;
 
 /* durations of the device stages of the LAST call, from HIP events recorded on the

@@ -34,7 +34,7 @@
   (status :int32) (segments :uint32)
   (out-len :uint64) (out-total :uint64) (in-consumed :uint64)
   (adler32 :uint32) (crc32 :uint32) (trailer-check :uint32) (trailer-isize :uint32)
-  (flags :uint32) (reserved :uint32 :count 3))
+  (flags :uint32) (reserved :uint32) (boundary-out :uint64))
 
 (cffi:defcfun ("tbz_ctx_create" %ctx-create) :int (device :int) (out :pointer))
 (cffi:defcfun ("tbz_ctx_destroy" %ctx-destroy) :void (ctx :pointer))

@@ -427,6 +427,7 @@ def _chunked_lockstep(eng, blob, fmt, in_steps, out_sizes, what):
     got_o += bo[:so.output_offset]
     got_e += be[:se.output_offset]
     assert bytes(got_e) == bytes(got_o), what
+    _chunked_lockstep.last_state = se
     return bytes(got_o)
 
 
@@ -452,6 +453,37 @@ def case_chunked_resume(eng, n=90_000):
         assert _chunked_lockstep(eng, blob, fmt, steps, sizes, "%s both" % fmt) == plain
     # truncated stream fed in chunks: ends in input-underrun on both sides
     _chunked_lockstep(eng, blobs[0][1][: len(blobs[0][1]) // 2], "zlib", [5000], [n + 10], "truncated zlib in chunks")
+    # where the replays start (3bz_amd/api.py): flush-delimited streams resume at the last block boundary the engine
+    # proved — raw blocks from there, checksum continued, container trailer compared by the host — in all three
+    # containers; a Z_SYNC_FLUSH stream (blocks copy from before the boundary) must notice and replay from octet 0
+    def flushed(wbits, mode):
+        c = zlib.compressobj(6, zlib.DEFLATED, wbits)
+        return b"".join(c.compress(fp[i:i + 8192]) + c.flush(mode) for i in range(0, len(fp), 8192)) + c.flush()
+    for fmt, wbits in (("zlib", 15), ("gzip", 31), ("deflate", -15)):
+        blob = flushed(wbits, zlib.Z_FULL_FLUSH)
+        for steps, sizes in (([7000], [len(fp) + 10]), ([5000, 11000, 3000], [20000, 9000]), ([len(blob) - 3, 1], [len(fp) + 10])):
+            assert _chunked_lockstep(eng, blob, fmt, steps, sizes, "%s full-flush resume" % fmt) == fp
+            st = _chunked_lockstep.last_state
+            assert not st._no_base and (st._base_in > 0 or len(steps) == 2), (fmt, steps, st._base_in)  # (trailer-only chunks: nothing to adopt)
+        bad = blob[:-1] + bytes([blob[-1] ^ 1]) if fmt != "deflate" else None
+        if fmt == "zlib":   # a checksum mismatch: same error, same call as the reference
+            so, se = O.State(FMT[fmt], bytearray(len(fp) + 10)), A.make_zlib_state(bytearray(len(fp) + 10))
+            for lo in range(0, len(bad), 9000):
+                hi = min(len(bad), lo + 9000)
+                eo = ee = None
+                try:
+                    O.decompress(O.make_octet_vector_context(bad, start=lo, end=hi), so)
+                except O.OracleError as e:
+                    eo = e.code
+                try:
+                    A.decompress(A.make_octet_vector_context(bad, start=lo, end=hi), se, engine=eng)
+                except A.ThreeBzError as e:
+                    ee = e.code
+                assert eo == ee, (lo, eo, ee)
+            assert ee == -11 and se._no_base   # the tail's verdict sent it back to octet 0, and the whole stream confirmed
+    blob = flushed(15, zlib.Z_SYNC_FLUSH)
+    assert _chunked_lockstep(eng, blob, "zlib", [7000], [len(fp) + 10], "sync-flush resume") == fp
+    assert _chunked_lockstep.last_state._no_base and _chunked_lockstep.last_state._base_in == 0
 
 
 def case_fuzz(eng, seed=7, n=30):

@@ -92,7 +92,7 @@ def shard_cases(eng, n=200_000):
 
 
 def test_sharded_stream_all_ranks_in_turn(eng):
-    shard_cases(eng)
+    shard_cases(eng, n=120_000)
 
 
 def test_boundary_report(eng):

@@ -181,6 +181,71 @@ def make_octet_vector_context(vector, start=0, offset=None, end=None):
     return OctetVectorContext(vector, start, offset, end)
 
 
+class OctetPointer:
+    """octet-pointer (io-mmap.lisp:21-24): foreign memory [base, base+size) valid inside a scope.  `device=True`:
+    the memory is in HBM (a raw device pointer, e.g. torch.Tensor.data_ptr()) — the engine reads it in place."""
+
+    def __init__(self, base, size, device=False):
+        self.base, self.size, self.device = int(base or 0), int(size), bool(device)
+        self.scope = True
+
+
+def valid_octet_pointer(op):
+    """io-mmap.lisp:37-40"""
+    return bool(op.scope and op.base and op.size > 0)
+
+
+class with_octet_pointer:
+    """(with-octet-pointer (var pointer size) …) — io-mmap.lisp:26-35: the pointer object dies with the scope.
+    `pointer` may also be a Python buffer (bytes, bytearray, numpy uint8): its address is taken, as
+    cffi:with-pointer-to-vector-data does for the reference's callers (bench.lisp:61)."""
+
+    def __init__(self, pointer, size=None, device=False):
+        self._keep = None
+        if not isinstance(pointer, int):
+            self._keep = pointer
+            size = len(pointer) if size is None else size
+            pointer = _addr(pointer)
+        self.op = OctetPointer(pointer, size, device)
+
+    def __enter__(self):
+        return self.op
+
+    def __exit__(self, *exc):
+        self.op.scope = False
+        return False
+
+
+class OctetPointerContext:
+    """make-octet-pointer-context (io-mmap.lisp:47-54)"""
+
+    def __init__(self, octet_pointer, start=0, offset=0, end=None):
+        self.op = octet_pointer
+        self.pointer = octet_pointer.base
+        self.start = start
+        self.offset = offset
+        self.end = octet_pointer.size if end is None else end
+
+
+def make_octet_pointer_context(octet_pointer, start=0, offset=0, end=None):
+    return OctetPointerContext(octet_pointer, start, offset, end)
+
+
+def _context_octets(eng, context):
+    """the octets [offset, end) of a context as bytes (a copy: the states keep their input for resuming)"""
+    if isinstance(context, OctetPointerContext):
+        if not valid_octet_pointer(context.op):   # (assert (valid-octet-pointer (op context))) io-mmap.lisp:66
+            raise ThreeBzError(-22, "octet pointer used outside its scope (or null / empty)")
+        n = context.end - context.offset
+        if context.op.device:
+            out = bytearray(n)
+            if n:
+                eng.d2h(out, context.pointer + context.offset, n)
+            return bytes(out)
+        return C.string_at(context.pointer + context.offset, n)
+    return bytes(memoryview(context.octet_vector)[context.offset:context.end])
+
+
 class DeflateState:
     """deflate-state (deflate.lisp:4-62): only the slots a caller can observe"""
     format = FORMATS["deflate"]
@@ -353,10 +418,31 @@ def decompress(context, state, engine=None):
     state._calls += 1
     state.input_underrun = False
     state.output_overflow = False
-    new = bytes(memoryview(context.octet_vector)[context.offset:context.end])
+    if first and isinstance(context, OctetPointerContext) and valid_octet_pointer(context.op):
+        # foreign memory goes to the engine as it is: a host pointer through tbz_inflate, a device pointer through
+        # tbz_inflate_device (no staging copy of the input); the octets are only copied if the state must resume
+        out = state.output_buffer
+        n_in = context.end - context.offset
+        if context.op.device:
+            d_out = eng.malloc(len(out) + 64)
+            try:
+                res = eng.inflate_device(context.pointer + context.offset, n_in, d_out, len(out), state.format)
+                if res.status >= 0 and res.out_len:
+                    eng.d2h(out, d_out, int(res.out_len))
+            finally:
+                eng.free(d_out)
+        else:
+            res = _lib.Result()
+            eng._check(eng.lib.tbz_inflate(eng._ctx, state.format, context.pointer + context.offset, n_in,
+                                           _addr(out), len(out), C.byref(res)))
+        new = b"" if res.status in (_lib.FINISHED,) or res.status < 0 else _context_octets(eng, context)
+    else:
+        new = _context_octets(eng, context)
+        res = None
     if first:
         out = state.output_buffer
-        res = eng.inflate(new, state.format, out)
+        if res is None:
+            res = eng.inflate(new, state.format, out)
         state.result = res
         state._seen = bytearray(new)
         state._full = None

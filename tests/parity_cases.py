@@ -547,9 +547,59 @@ def case_gzip_members(eng, n_members=8, max_len=12_000, n_false=300):
                 assert w["flag"] == "underrun" and e.code == -20
 
 
+def case_pointer_contexts(eng, n=60_000):
+    """with-octet-pointer / make-octet-pointer-context (io-mmap.lisp:26-54): the same calls over foreign memory —
+    a host pointer (tbz_inflate reads it in place) and a device pointer (tbz_inflate_device, no staging) — must give
+    what the vector context gives, i.e. what the oracle gives; resumed calls included."""
+    mixed = _mixed_plain(n, 8)
+    fs, fp, _ = K.zlib_flush_stream(n, block=4096)
+    for fmt, blob, plain in (("zlib", zlib.compress(mixed, 6), mixed), ("gzip", pygzip.compress(mixed, 6, mtime=0), mixed),
+                             ("deflate", zlib.compress(mixed, 9)[2:-4], mixed), ("zlib", fs, fp)):
+        mk = {"deflate": A.make_deflate_state, "zlib": A.make_zlib_state, "gzip": A.make_gzip_state}[fmt]
+        d_in = eng.malloc(len(blob) + 64)
+        eng.h2d(d_in, blob)
+        try:
+            for cap in (n + 100, n // 3, 0):
+                want = oracle_oneshot(blob, fmt, cap)
+                for device in (False, True):
+                    with A.with_octet_pointer(d_in if device else blob, len(blob), device=device) as op:
+                        assert A.valid_octet_pointer(op)
+                        st = mk(bytearray(cap))
+                        ctx = A.make_octet_pointer_context(op)
+                        ret = A.decompress(ctx, st, engine=eng)
+                        flag = ("finished" if st.finished else "underrun" if st.input_underrun else "overflow")
+                        assert (flag, ret) == (want["flag"], want["ret"]), (fmt, cap, device, flag, ret)
+                        assert bytes(st.output_buffer[:st.output_offset]) == want["bytes"]
+                        # a second buffer after overflow: the state resumes from its own copy of the input
+                        if st.output_overflow:
+                            A.replace_output_buffer(st, bytearray(n + 100))
+                            A.decompress(ctx, st, engine=eng)
+                            assert st.finished and want["bytes"] + bytes(st.output_buffer[:st.output_offset]) == plain
+                    assert not A.valid_octet_pointer(op)
+                    try:   # (assert (valid-octet-pointer …)) io-mmap.lisp:66
+                        A.decompress(A.make_octet_pointer_context(op), mk(bytearray(8)), engine=eng)
+                        raise AssertionError("dead pointer accepted")
+                    except A.ThreeBzError:
+                        pass
+            # input in two pieces through pointer contexts (:end, then :offset)
+            for device in (False, True):
+                with A.with_octet_pointer(d_in if device else blob, len(blob), device=device) as op:
+                    st = mk(bytearray(n + 100))
+                    cut = len(blob) // 2
+                    A.decompress(A.make_octet_pointer_context(op, end=cut), st, engine=eng)
+                    assert st.input_underrun
+                    w = oracle_oneshot(blob, fmt, n + 100, end=cut)
+                    assert bytes(st.output_buffer[:st.output_offset]) == w["bytes"]
+                    A.decompress(A.make_octet_pointer_context(op, offset=cut), st, engine=eng)
+                    assert st.finished and bytes(st.output_buffer[:st.output_offset]) == plain
+        finally:
+            eng.free(d_in)
+
+
 ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,
              case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_device_buffers,
-             case_checksum_kernels, case_deep_codes, case_chunked_resume, case_gzip_members, case_fuzz]
+             case_checksum_kernels, case_deep_codes, case_chunked_resume, case_gzip_members,
+             case_pointer_contexts, case_fuzz]
 # the cases whose behaviour depends on the K1 flavour (forced-flavour runs skip the rest: checksums, device
 # buffers and the replay protocol go through the same engine calls whatever decodes the Huffman codes)
 K1_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,

@@ -128,7 +128,7 @@ def main():
     decode_ms = ms["huff"] + ms["lz"]
     roof = {
         "bound": "hbm",
-        "kernel": "tbz_k1g32_huff_decode+tbz_k2_lz77_small (the decode stage of SURVEY §8d: C read + U written)",
+        "kernel": "tbz_k1g32_huff_decode+tbz_k2_lz77_dual (the decode stage of SURVEY §8d: C read + U written)",
         "achieved": (C + U) / (decode_ms * 1e-3) / 1e9 if decode_ms > 0 else None,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",

@@ -75,8 +75,15 @@ def lib():
         L.tbzo_crc32.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32]
         L.tbzo_debug_build_trees.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int),
                                              C.c_void_p, C.POINTER(C.c_int)]
+        L.tbzo_set_fresh_tables.argtypes = [C.c_int]
         _LIB = L
     return _LIB
+
+
+def set_fresh_tables(on):
+    """test switch (not reference behaviour): an all-zero alphabet invalidates its table instead of leaving the
+    previous block's entries in it — what the device path documents it does"""
+    lib().tbzo_set_fresh_tables(1 if on else 0)
 
 
 def _addr(buf):

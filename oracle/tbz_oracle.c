@@ -128,6 +128,14 @@ static unsigned subtable(fill_ctx* f, int prefix_bits) {
   return ht_link_node((unsigned)b, (unsigned)start);
 }
 
+/* Test switch (NOT reference behaviour): with an all-zero alphabet the reference leaves whatever the previous
+ * block put in the table (:156-157) — state that crosses block and flush boundaries and that no encoder's
+ * stream depends on.  The device path documents that it behaves like a FRESH reference state there (every entry
+ * invalid); with this switch on the oracle does the same, so the fuzzers can tell that documented
+ * deviation from a real difference. */
+static int g_fresh_tables = 0;
+void tbzo_set_fresh_tables(int on) { g_fresh_tables = on; }
+
 /* huffman-tree.lisp:99-218 — build-tree-part.  Returns <0 on error, else 0 and
  * (*count,*bits,*max) = (values next-subtable min max-bits). */
 static int build_tree_part(hufftree* tree, int tree_offset, const uint8_t* table, int type, int start,
@@ -171,6 +179,8 @@ static int build_tree_part(hufftree* tree, int tree_offset, const uint8_t* table
     }
   int max_bits = last + (type == T_DIST ? 13 : type == T_LITLEN ? 5 : 7); /* :146-150 */
   if (min < 0) { /* :156-157: all-zero lengths — table left untouched */
+    if (g_fresh_tables) /* test switch, see tbzo_set_fresh_tables */
+      for (int i = tree_offset; i < MAX_TREE_SIZE; i++) tree->nodes[i] = 0xffff;
     *count = 0;
     *bits = 0;
     *max = 0;

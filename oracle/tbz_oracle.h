@@ -70,6 +70,8 @@ int tbzo_replace_output_buffer(tbzo_state* st, uint8_t* buf, size_t len);
 int tbzo_finished(const tbzo_state*);
 int tbzo_input_underrun(const tbzo_state*);
 int tbzo_output_overflow(const tbzo_state*);
+/* test switch, not reference behaviour: all-zero alphabets invalidate the table instead of leaving it stale */
+void tbzo_set_fresh_tables(int on);
 int64_t tbzo_output_offset(const tbzo_state*);
 const char* tbzo_errmsg(const tbzo_state*);
 /* checksum state of the wrapper (zs-s1 | zs-s2<<16, or gs-crc32) */

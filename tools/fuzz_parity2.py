@@ -18,18 +18,18 @@ def corrupt(b):
     for _ in range(rng.randrange(0, 3)):
         mode = rng.randrange(4)
         if mode == 0: b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
-        elif mode == 1: b = b[: rng.randrange(1, len(b))]
+        elif mode == 1: b = b[: rng.randrange(1, max(2, len(b)))]
         elif mode == 2:
             i = rng.randrange(len(b)); b[i:i] = bytes([0, 0, 255, 255])
         else: b[rng.randrange(len(b))] = rng.randrange(256)
     return bytes(b)
-t0 = time.time(); n = 0; nb = 0
+t0 = time.time(); n = 0; nb = 0; stale = 0
 while time.time() - t0 < float(sys.argv[2]):
     fmt = rng.choice(list(bases))
     if rng.random() < 0.5:
         b = corrupt(rng.choice(bases[fmt]))
         cap = rng.choice([50000, 50000, rng.randrange(0, 45000)])
-        P.assert_same(eng, b, fmt, cap, what="fuzz2 %d" % n)
+        stale += P.same_or_stale_tables(eng, b, fmt, cap, what="fuzz2 %d" % n)[1]
         n += 1
     else:
         k = rng.randrange(2, 7)
@@ -38,13 +38,19 @@ while time.time() - t0 < float(sys.argv[2]):
         outs = [bytearray(c) for c in caps]
         res = eng.inflate_batch(datas, P.FMT[fmt], outs)
         for i in range(k):
-            want = P.oracle_oneshot(datas[i], fmt, caps[i])
             r = res[i]
             flag = "error" if r.status < 0 else ("finished", "underrun", "overflow")[r.status]
-            assert flag == want["flag"], ("batch", nb, i, flag, want["flag"], r.status, want["code"])
-            if flag == "error":
-                assert r.status == want["code"], ("batch", nb, i, r.status, want["code"])
-            else:
-                assert r.out_len == want["offset"] and bytes(outs[i][: r.out_len]) == want["bytes"], ("batch", nb, i, "octets")
+            for fresh in (False, True):   # second try: the documented stale-table deviation (parity_cases.same_or_stale_tables)
+                P.O.set_fresh_tables(fresh)
+                try:
+                    want = P.oracle_oneshot(datas[i], fmt, caps[i])
+                finally:
+                    P.O.set_fresh_tables(False)
+                ok = flag == want["flag"] and (r.status == want["code"] if flag == "error" else
+                                               r.out_len == want["offset"] and bytes(outs[i][: r.out_len]) == want["bytes"])
+                if ok:
+                    stale += fresh
+                    break
+            assert ok, ("batch", nb, i, flag, want["flag"], r.status, want["code"])
         nb += 1
-print("fuzz2 single", n, "batches", nb, "clean")
+print("fuzz2 single", n, "batches", nb, "clean; stale-table deviations (documented):", stale)

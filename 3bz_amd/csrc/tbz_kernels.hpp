@@ -819,6 +819,12 @@ TBZ_DEV i32 k1_container_header(K1State& st, u32 fmt) {
     u32 crc = 0xffffffffu;
     u32 flg = 0;
     for (int i = 0; i < 10; i++) {
+      // the reference takes ID1+ID2 and CM+FLG as pairs: 16 bits or input-underrun, before it looks at either
+      // octet (gzip.lisp:113-131)
+      if ((i == 0 || i == 2) && st.br.pos + 16 > st.end_bit) {
+        st.fail_pos = p0;
+        return SEG_UNDERRUN;
+      }
       if ((e = k1_byte(st, &t, p0))) return e;
       crc = crc_bitwise(crc, t);
       if (i == 0 && t != 0x1f) return E_GZIP_MAGIC;

@@ -529,6 +529,39 @@ def case_fuzz(eng, seed=7, n=30):
         assert_same(eng, bytes(b), fmt, 70000, what="fuzz seed %d case %d" % (seed, k))
 
 
+def case_container_headers(eng):
+    """zlib / gzip framing octet by octet (zlib.lisp:14-37, gzip.lisp:113-266): every truncation of the header and of
+    the trailer, and damage at every header position (also cut right after the damaged octet: the reference reads
+    ID1+ID2 and CM+FLG as PAIRS, so one octet of a pair is input-underrun whatever it holds) — with and without the
+    optional gzip fields (FEXTRA, FNAME, FCOMMENT, FHCRC)."""
+    plain = b"hello world, hello gzip! " * 20
+    raw = zlib.compress(plain, 6)[2:-4]
+    blobs = []
+    for flg in (0x00, 0x1e, 0x04, 0x0a):
+        hdr = bytes([0x1f, 0x8b, 8, flg, 1, 2, 3, 4, 0, 3])
+        if flg & 4:
+            hdr += struct.pack("<H", 5) + b"extra"
+        if flg & 8:
+            hdr += b"name.txt\0"
+        if flg & 16:
+            hdr += b"a comment\0"
+        if flg & 2:
+            hdr += struct.pack("<H", zlib.crc32(hdr) & 0xffff)
+        blobs.append(("gzip", len(hdr), hdr + raw + struct.pack("<II", zlib.crc32(plain), len(plain))))
+    blobs.append(("zlib", 2, zlib.compress(plain, 6)))
+    for fmt, nh, g in blobs:
+        w = assert_same(eng, g, fmt, 1000)
+        assert w["flag"] == "finished" and w["bytes"] == plain
+        for cut in list(range(0, nh + 4)) + list(range(len(g) - 9, len(g))):
+            assert_same(eng, g[:cut], fmt, 1000, what="%s cut %d" % (fmt, cut))
+        for pos in range(nh):
+            for val in (0, 0xff, g[pos] ^ 1, g[pos] ^ 0x20):
+                b = bytearray(g)
+                b[pos] = val
+                assert_same(eng, bytes(b), fmt, 1000, what="%s octet %d = %d" % (fmt, pos, val))
+                assert_same(eng, bytes(b[:pos + 1]), fmt, 1000, what="%s octet %d = %d, cut after it" % (fmt, pos, val))
+
+
 def case_gzip_members(eng, n_members=8, max_len=12_000, n_false=300):
     """many-member gzip file (SURVEY §8d config 3 as a public call, §8f-4): member starts are found speculatively
     (every 1f 8b 08 is a candidate, a candidate range is a member iff it finishes having consumed exactly its
@@ -615,7 +648,7 @@ def case_pointer_contexts(eng, n=60_000):
 ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,
              case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_device_buffers,
              case_checksum_kernels, case_deep_codes, case_chunked_resume, case_gzip_members,
-             case_pointer_contexts, case_fuzz]
+             case_pointer_contexts, case_container_headers, case_fuzz]
 # the cases whose behaviour depends on the K1 flavour (forced-flavour runs skip the rest: checksums, device
 # buffers and the replay protocol go through the same engine calls whatever decodes the Huffman codes)
 K1_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,

@@ -38,7 +38,8 @@ def test_gpu_case(eng, case, request):
     forced = request.node.callspec.params["eng"] not in ("auto", "hostlayout", "k2single")
     if forced and case not in P.K1_CASES:
         pytest.skip("does not depend on the K1 flavour")
-    if request.node.callspec.params["eng"] == "k2single" and case in (P.case_chunked_resume, P.case_gzip_members, P.case_pointer_contexts):
+    if request.node.callspec.params["eng"] == "k2single" and case in (P.case_chunked_resume, P.case_gzip_members, P.case_pointer_contexts,
+                                                                      P.case_container_headers):
         pytest.skip("host-side protocol over the same engine calls (run with both layout paths)")
     case(eng)
 

@@ -346,7 +346,9 @@ def _replay(eng, state):
             d_in, d_out = eng.malloc(len(tail) + 64), eng.malloc(n + 64)
             try:
                 eng.h2d(d_in, tail)
-                res = eng.inflate_device(d_in, len(tail), d_out, n, fmt)
+                # (one octet of slack: a stored block cut off exactly at the end of a FULL buffer is output-overflow in
+                # the reference, deflate.lisp:538-573 — this scratch buffer must never be the reason for a status)
+                res = eng.inflate_device(d_in, len(tail), d_out, n + 1, fmt)
                 status, flags = res.status, res.flags
                 got = int(res.out_len) if status >= 0 else 0
                 if status == _lib.FINISHED and base_in and state.format != deflate:
@@ -481,7 +483,11 @@ def decompress(context, state, engine=None):
     state.output_offset = off + give
     state._delivered += give
     pending = avail - state._delivered
-    if pending > 0:
+    stored_cut = status == _lib.INPUT_UNDERRUN and (state._full_flags & 4) and \
+        state.output_offset == len(state.output_buffer)
+    if pending > 0 or stored_cut:
+        # (stored_cut: the input ran out inside a stored block just where this buffer is full — the reference
+        # asks for output space first there, deflate.lisp:538-573)
         state.output_overflow = True
         return state.output_offset
     state.finished = status == _lib.FINISHED

@@ -156,6 +156,7 @@ struct StreamPlan {
   uint64_t in_end_bit = 0;
   uint64_t boundary_bit = 0;  // last flush boundary the chain is known to have landed on (resume / shard seam)
   uint64_t boundary_out = 0;  // output octets produced before it
+  bool stored_cut = false;    // the input ran out inside a stored block's payload
   uint32_t trailer0 = 0, trailer1 = 0, trailer_have = 0;
   bool saw_final = false;
   uint32_t seg_first = 0, seg_count = 0;
@@ -536,7 +537,9 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     // 3bz decodes front to back: it reports overflow as soon as a token does not fit, before it
     // could meet a later error / underrun
     uint64_t cap = S.out_cap;
-    bool overflow = S.total_out > cap && !error_first;
+    // … and inside a stored block it asks for output space before it asks for input (copy-byte-or-fail,
+    // deflate.lisp:538-573): payload cut off exactly where the buffer is full is output-overflow
+    bool overflow = (S.total_out > cap || (S.stored_cut && status == TBZ_INPUT_UNDERRUN && S.total_out == cap)) && !error_first;
     if (overflow) status = TBZ_OUTPUT_OVERFLOW;
     R.status = status;
     R.segments = nseg;
@@ -550,6 +553,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     R.trailer_check = S.trailer0;
     R.trailer_isize = S.trailer1;
     if (S.saw_final) R.flags |= 2;
+    if (S.stored_cut) R.flags |= 4;
     if (status < 0) R.out_len = 0;  // reference signals an error: no partial-result contract
     return status;
   };
@@ -606,7 +610,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       S.in_end_bit = k.last.end_bit;
       S.boundary_bit = S.n_items > 1 ? k.last_start : 0;
       S.boundary_out = k.total_out - k.last.out_bytes;
-      if (k.last.status == SEG_UNDERRUN && k.last.pad && !(k.last.end_bit & 7)) {
+      S.stored_cut = k.last.status == SEG_UNDERRUN && k.last.pad == 2;
+      if (k.last.status == SEG_UNDERRUN && k.last.pad == 1 && !(k.last.end_bit & 7)) {
         S.boundary_bit = k.last.end_bit;
         S.boundary_out = k.total_out;
       }
@@ -675,7 +680,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if (q.status == SEG_UNDERRUN) {
       S.status = TBZ_INPUT_UNDERRUN;
       S.in_end_bit = q.end_bit;
-      if (q.pad && !(q.end_bit & 7)) {  // ran out exactly at an octet-aligned block start
+      S.stored_cut = q.pad == 2;
+      if (q.pad == 1 && !(q.end_bit & 7)) {  // ran out exactly at an octet-aligned block start
         S.boundary_bit = q.end_bit;
         S.boundary_out = S.total_out;
       }

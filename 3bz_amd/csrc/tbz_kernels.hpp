@@ -890,6 +890,7 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
   i32 status = 0;
   u32 land = 0xFFFFFFFFu, tr0 = 0, tr1 = 0, tr_have = 0;
   u64 blk_pos = it.start_bit, blk_prod = 0, blk_tok = 0;
+  u32 cut = 0;  // 2: ran out of input inside a stored block's payload
   int tables = 0;  // 0 none, 1 fixed, 2 dynamic
 
   if (it.flags & ITEM_HEAD) status = k1_container_header(st, fmt);
@@ -923,7 +924,7 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
         st.tok += 4;
         st.produced += ncopy;
       }
-      if (ncopy < LEN) { st.fail_pos = (byte0 + ncopy) * 8; status = SEG_UNDERRUN; break; }
+      if (ncopy < LEN) { st.fail_pos = (byte0 + ncopy) * 8; status = SEG_UNDERRUN; cut = 2; break; }
       br_seek(st.br, (byte0 + LEN) * 8);
     } else if (btype == 3) {
       status = E_BTYPE;  // deflate.lisp:521
@@ -1007,7 +1008,7 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
   }
   r.tok_words = T8 * 8;
   r.n_runs = T8 ? 1u : 0u;
-  r.pad = (status == SEG_UNDERRUN && st.fail_pos == blk_pos) ? 1u : 0u;  // ran out exactly where a block starts
+  r.pad = (status == SEG_UNDERRUN && st.fail_pos == blk_pos) ? 1u : status == SEG_UNDERRUN ? cut : 0u;
   r.status = status;
   r.max_deficit = st.deficit;
   r.trailer0 = tr0;
@@ -1143,7 +1144,8 @@ struct GangState {  // per gang, in LDS; owned by the leader
   u32 hlit, hdist, fixed;   // GM_BUILD: alphabet sizes; fixed: 1 the lanes write the fixed code lengths first,
                             //   2 they copy the lengths K1h left in the item's scratch
   u32 rounds, valid_lanes;  // diagnostics: rounds run and lanes committed (efficiency = valid_lanes / (G*rounds))
-  u32 pad[3];
+  u32 cut;                  // 2: ran out of input inside a stored block's payload (SegResult.pad)
+  u32 pad[2];
 };
 template <int G>
 struct KgLds {
@@ -1907,7 +1909,7 @@ TBZ_DEV void kg_leader_header(GangTables& gt, GangState& gs, K1State& st, const 
       gs.T += 8;
       gs.produced += ncopy;
     }
-    if (ncopy < LEN) { gs.fail_pos = (byte0 + ncopy) * 8; gs.status = SEG_UNDERRUN; gs.mode = GM_DONE; return; }
+    if (ncopy < LEN) { gs.fail_pos = (byte0 + ncopy) * 8; gs.status = SEG_UNDERRUN; gs.cut = 2; gs.mode = GM_DONE; return; }
     gs.P = (byte0 + LEN) * 8;
     kg_block_end(gs, st, it, P, fmt, fixup);
     return;
@@ -1988,6 +1990,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     gs.blk_tok = 0;
     gs.fail_pos = it.start_bit;
     gs.status = 0;
+    gs.cut = 0;
     gs.mode = have ? GM_HEADER : GM_DONE;
     gs.bfinal = 0;
     gs.deficit = 0;
@@ -2161,7 +2164,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
       r.tok_words = gs.T;
       r.n_runs = gs.nruns;
     }
-    r.pad = (gs.status == SEG_UNDERRUN && gs.fail_pos == gs.blk_pos) ? 1u : 0u;  // ran out exactly where a block starts
+    r.pad = (gs.status == SEG_UNDERRUN && gs.fail_pos == gs.blk_pos) ? 1u : gs.status == SEG_UNDERRUN ? gs.cut : 0u;
     r.status = gs.status;
     r.max_deficit = gs.deficit;
     r.trailer0 = gs.tr0;

@@ -58,7 +58,8 @@ struct SegResult {
   uint32_t trailer_have; // 0 none, 1 first word only (gzip crc without isize), 2 complete
   uint32_t land_marker;  // LANDED: index of the marker landed on
   uint32_t n_runs;       // entries of the item's run table that make up tok_words
-  uint32_t pad;          // UNDERRUN: 1 when the input ended exactly where a block starts (end_bit = that boundary)
+  uint32_t pad;          // UNDERRUN: 1 when the input ended exactly where a block starts (end_bit = that boundary);
+                         // 2 when it ended inside a stored block's payload (the reference checks output space first there)
   uint64_t reserved;     // K1g diagnostics: rounds << 32 | committed lanes
 };
 

@@ -152,7 +152,7 @@ def shard_decode(eng, data, fmt, cuts, r):
     d_out = eng.malloc(n + 64)
     try:
         eng.h2d(d_in, memoryview(data)[lo:hi] if not isinstance(data, bytes) else data[lo:hi])
-        res = eng.inflate_device(d_in, hi - lo, d_out, n, f)
+        res = eng.inflate_device(d_in, hi - lo, d_out, n + 1, f)   # (slack: the scratch buffer is never "full")
     finally:
         eng.free(d_in)
     got = int(res.out_len) if res.status >= 0 else 0
@@ -227,7 +227,7 @@ def inflate_sharded(eng, data, fmt, rank, world, dist, torch, device="cpu"):
         d_in, d_o = eng.malloc(len(data) + 64), eng.malloc(cap + 64)
         try:
             eng.h2d(d_in, data)
-            res = eng.inflate_device(d_in, len(data), d_o, cap, fmt)
+            res = eng.inflate_device(d_in, len(data), d_o, cap + 1, fmt)
         finally:
             eng.free(d_in)
         got = int(res.out_len) if res.status >= 0 else 0

@@ -84,7 +84,11 @@ typedef struct tbz_result {
   uint32_t crc32;        /* computed over the output (gzip.lisp:80-81) */
   uint32_t trailer_check;/* checksum stored in the stream trailer (0 if not reached) */
   uint32_t trailer_isize;/* gzip ISIZE (read, never compared: gzip.lisp:95-106,:278) */
-  uint32_t flags;        /* bit0: checksum verified against trailer; bit1: BFINAL block decoded */
+  uint32_t flags;        /* bit0: checksum verified against trailer; bit1: BFINAL block decoded; bit2: the
+                            input ran out inside a stored block's payload — there the reference asks for
+                            output space before input (deflate.lisp:538-573), so with the output exactly
+                            full the status is output-overflow, and a host that hands the output out in
+                            pieces must report the same when a piece ends there */
   uint32_t reserved;
   uint64_t boundary_out; /* not finished: output octets produced by the input before in_consumed (a decoder
                             restarted at that boundary continues the output there); finished: out_len */

@@ -217,6 +217,23 @@ def case_overflow_and_underrun(eng):
         for c in sorted(x for x in cuts if 0 <= x < len(blob)):
             w = assert_same(eng, blob, fmt, len(pl) + 10, end=c, what="%s cut %d" % (fmt, c))
             assert w["flag"] in ("underrun", "error"), (fmt, c, w["flag"])
+    # both at once: inside a stored block the reference asks for output space BEFORE it asks for input
+    # (copy-byte-or-fail, deflate.lisp:538-573), so a payload cut off exactly where the buffer is full is
+    # output-overflow; everywhere else a token needs its input first (input-underrun)
+    z0 = zlib.compress(plain[:9000], 0)          # header, stored block (5-octet block header), adler32
+    for cut in (7, 8, 100, 4000, len(z0) - 5):
+        have = cut - 7                            # payload octets present
+        for cap in (have - 1, have, have + 1):
+            if cap >= 0:
+                w = assert_same(eng, z0, "zlib", cap, end=cut, what="stored cut %d cap %d" % (cut, cap))
+                assert w["flag"] == ("underrun" if cap > have else "overflow"), (cut, cap, w["flag"])
+    zc = zlib.compress(plain[:9000], 6)
+    for cut in (400, 1000):
+        n_out = oracle_oneshot(zc, "zlib", 20000, end=cut)["offset"]
+        assert n_out > 0
+        for cap in (n_out - 1, n_out, n_out + 1):
+            w = assert_same(eng, zc, "zlib", cap, end=cut, what="huffman cut %d cap %d" % (cut, cap))
+            assert w["flag"] == ("overflow" if cap < n_out else "underrun"), (cut, cap, w["flag"])
     # decompress-vector's own errors (api.lisp:41-47,:55)
     z = zlib.compress(plain)
     for kw, code in (({"output": bytearray(10)}, -21), ({"end": len(z) - 3, "output": bytearray(len(plain))}, -20),
@@ -469,6 +486,10 @@ def case_chunked_resume(eng, n=90_000):
         assert _chunked_lockstep(eng, blob, fmt, steps, sizes, "%s both" % fmt) == plain
     # truncated stream fed in chunks: ends in input-underrun on both sides
     _chunked_lockstep(eng, blobs[0][1][: len(blobs[0][1]) // 2], "zlib", [5000], [n + 10], "truncated zlib in chunks")
+    # stored payload cut off exactly where an output buffer is full (4093 - 7 = 3 x 1362): the reference reports
+    # output-overflow there (it asks for space before input, deflate.lisp:538-573), then input-underrun
+    z0 = zlib.compress(fp[:9000], 0)
+    assert _chunked_lockstep(eng, z0, "zlib", [4093, 3000], [1362], "stored cut at a full buffer") == fp[:9000]
     # where the replays start (3bz_amd/api.py): flush-delimited streams resume at the last block boundary the engine
     # proved — raw blocks from there, checksum continued, container trailer compared by the host — in all three
     # containers; a Z_SYNC_FLUSH stream (blocks copy from before the boundary) must notice and replay from octet 0

@@ -21,6 +21,7 @@ while time.time() - t0 < float(sys.argv[2]):
     blob = flushed(wbits, mode, rng.choice([1000, 4096, 9000, 20000]), rng.choice([0, 1, 6]))
     if rng.random() < 0.2: blob = blob[:rng.randrange(1, len(blob))]
     steps = [rng.randrange(1, 15000) for _ in range(rng.randrange(1, 6))]
+    if sum(steps) * 1500 < len(blob) * len(steps): steps.append(15000)   # (the lockstep harness allows 2000 chunks)
     sizes = [rng.randrange(1, 40000) for _ in range(rng.randrange(1, 5))]
     P._chunked_lockstep(eng, blob, fmt, steps, sizes, "chunk fuzz %d %s %s %s" % (n, fmt, steps, sizes))
     st = P._chunked_lockstep.last_state; n += 1; based += st._base_in > 0; fell_back += st._no_base

@@ -819,6 +819,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     // groups: a segment that needs history (or continues a repaired block) joins its predecessor
     uint64_t o = 0;
     S.seg_first = (uint32_t)h_segs.size();
+    const size_t g0 = h_groups.size();  // this stream's first group
     for (size_t i = 0; i < v.size(); i++) {
       if (o >= R.out_len) break;
       bool join = i > 0 && (v[i].continues || v[i].deficit > 0);
@@ -829,6 +830,15 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         g.seg_first = (uint32_t)h_segs.size();
         g.seg_count = 0;
         h_groups.push_back(g);
+      } else {
+        // the history it needs may start before its predecessor's group (a repaired block in a damaged stream
+        // copying from segments that were independent until then): take in earlier groups until it is covered
+        const uint64_t need = S.out_off + (o > v[i].deficit ? o - v[i].deficit : 0);
+        while (h_groups.size() > g0 + 1 && h_groups.back().out_abs > need) {
+          const uint32_t cnt = h_groups.back().seg_count;
+          h_groups.pop_back();
+          h_groups.back().seg_count += cnt;
+        }
       }
       h_groups.back().seg_count++;
       h_segs.push_back(v[i].seg);

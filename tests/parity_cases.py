@@ -175,6 +175,24 @@ def case_flush_streams(eng, n=96 << 10):
     assert_same(eng, s, "zlib", len(p), what="1000-octet flush blocks")
 
 
+def case_history_across_groups(eng):
+    """Z_SYNC_FLUSH stream whose middle segment copies nothing from before itself (incompressible octets: it opens a
+    LZ77 group of its own) while the segment after it copies from the FIRST one, i.e. from before its predecessor's
+    group: the groups must be merged back until the history is covered.  (Found by the corruption fuzzer on the
+    device as a repaired block reaching across independent segments; this is the valid-stream form.)"""
+    rng = random.Random(77)
+    a = K.enwik_like(20_000, seed=31)
+    for mid_len in (1, 40, 300, 5000):
+        mid = bytes(rng.randrange(256) for _ in range(mid_len))
+        c = zlib.compressobj(9, zlib.DEFLATED, 15)
+        blob = c.compress(a) + c.flush(zlib.Z_SYNC_FLUSH) + c.compress(mid) + c.flush(zlib.Z_SYNC_FLUSH)
+        blob += c.compress(a[3000:15000]) + c.flush(zlib.Z_SYNC_FLUSH) + c.compress(mid + a[:4000]) + c.flush()
+        plain = a + mid + a[3000:15000] + mid + a[:4000]
+        w = assert_same(eng, blob, "zlib", len(plain) + 10, what="history across groups, middle %d" % mid_len)
+        assert w["flag"] == "finished" and w["bytes"] == plain
+        assert_same(eng, blob, "zlib", len(a) + mid_len + 5000, what="... with overflow")
+
+
 def case_configs_1_3_5(eng, adv_total=160 << 10):
     for two in (False, True):  # config 1: one / two stored blocks
         s, p = K.config1_stream(two)
@@ -667,10 +685,12 @@ def case_pointer_contexts(eng, n=60_000):
 
 
 ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,
+             case_history_across_groups,
              case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_device_buffers,
              case_checksum_kernels, case_deep_codes, case_chunked_resume, case_gzip_members,
              case_pointer_contexts, case_container_headers, case_fuzz]
 # the cases whose behaviour depends on the K1 flavour (forced-flavour runs skip the rest: checksums, device
 # buffers and the replay protocol go through the same engine calls whatever decodes the Huffman codes)
 K1_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,
+            case_history_across_groups,
             case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_deep_codes, case_fuzz]

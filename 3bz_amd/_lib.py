@@ -25,7 +25,10 @@ class Timings(C.Structure):
     """struct tbz_timings"""
     _fields_ = [("scan_ms", C.c_float), ("huff_ms", C.c_float), ("lz_ms", C.c_float), ("cksum_ms", C.c_float),
                 ("total_ms", C.c_float), ("huff_launches", C.c_uint32), ("fixup_rounds", C.c_uint32),
-                ("token_words", C.c_uint64), ("n_segments", C.c_uint64), ("n_groups", C.c_uint64)]
+                ("token_words", C.c_uint64), ("n_segments", C.c_uint64), ("n_groups", C.c_uint64),
+                ("find_ms", C.c_float), ("resolve_ms", C.c_float), ("k1_gang", C.c_uint32), ("k2_kinds", C.c_uint32),
+                ("n_candidates", C.c_uint64), ("n_hgroups", C.c_uint64), ("scratch_bytes", C.c_uint64),
+                ("h2d_copies", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 assert C.sizeof(Result) == 64

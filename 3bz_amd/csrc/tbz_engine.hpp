@@ -60,6 +60,23 @@ struct tbz_ctx {
 
 namespace tbz {
 
+// every device pool of a context (destroy, trim, accounting)
+static std::vector<DevBuf*> all_pools(tbz_ctx* ctx) {
+  return {&ctx->d_str_off, &ctx->d_str_len, &ctx->d_tile_first, &ctx->d_tile_counts, &ctx->d_tile_offsets,
+          &ctx->d_markers, &ctx->d_items, &ctx->d_res, &ctx->d_tok, &ctx->d_scratch, &ctx->d_runs, &ctx->d_order,
+          &ctx->d_segs, &ctx->d_groups, &ctx->d_ck_chunks, &ctx->d_ck_parts, &ctx->d_ck_streams, &ctx->d_ck_out,
+          &ctx->d_crc_tab, &ctx->d_in_stage, &ctx->d_out_stage, &ctx->d_k3_fi, &ctx->d_k3_ni, &ctx->d_k3_oo,
+          &ctx->d_k3_oc, &ctx->d_k3_sums, &ctx->d_k3_flags, &ctx->d_k3_gscan, &ctx->d_k3_gne, &ctx->d_k3_streams,
+          &ctx->d_k3_glob, &ctx->d_redo_items, &ctx->d_redo_res, &ctx->d_k0_slots, &ctx->d_k0_fm, &ctx->d_hdr,
+          &ctx->d_gck, &ctx->d_gchunks, &ctx->d_ck_l1, &ctx->d_tok2, &ctx->d_runs2};
+}
+static uint64_t scratch_total(tbz_ctx* ctx) {
+  uint64_t t = 0;
+  for (DevBuf* b : all_pools(ctx))
+    if (b != &ctx->d_in_stage && b != &ctx->d_out_stage) t += b->cap;
+  return t;
+}
+
 #define TBZ_HIP(call)                                                                       \
   do {                                                                                      \
     hipError_t e_ = (call);                                                                 \
@@ -461,6 +478,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   };
   auto launch_k1 = [&](const Item* d_items, SegResult* d_res, size_t n_it, bool fix) -> int {
     int G = k1_gang(n_it);
+    if (!fix) ctx->tim.k1_gang = (uint32_t)G;
     if (G == 1) return launch_lane(d_items, d_res, n_it, fix);
     size_t per = 64 / G, nwg = (n_it + per - 1) / per;
     // K1h: every lane parses the first block header of its own item, so that the gangs need not (their leaders
@@ -580,6 +598,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
           k2.gck = (CkPartial*)ctx->d_gck.p;
           k2.gchunks = (CkChunk*)ctx->d_gchunks.p;
         }
+        ctx->tim.k2_kinds |= ctx->k2_single ? 2u : 1u;
         if (ctx->k2_single)
           TBZ_LAUNCH_DYN(tbz_k2_lz77_small, n_it, k2.win_bytes + 2 * K2_TOKBUF + 512, ctx->stream, k2);
         else
@@ -589,6 +608,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       if (h_glob->n_big) {
         k2.win_bytes = 0;
         k2.cls = h_glob->n_big < n_it ? 2 : 0;
+        ctx->tim.k2_kinds |= 4u;
         TBZ_LAUNCH(tbz_k2_lz77, n_it, ctx->stream, k2);
       }
       TBZ_HIP(hipGetLastError());
@@ -877,6 +897,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if (!order_small.empty()) {
       k2.n_groups = (u32)order_small.size();
       k2.win_bytes = (u32)((max_small + K2_SLACK + 63) & ~63ull);
+      ctx->tim.k2_kinds |= ctx->k2_single ? 2u : 1u;
       if (ctx->k2_single)
         TBZ_LAUNCH_DYN(tbz_k2_lz77_small, order_small.size(), k2.win_bytes + 2 * K2_TOKBUF + 512, ctx->stream, k2);
       else
@@ -887,6 +908,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       k2.order = (const u32*)ctx->d_order.p + order_small.size();
       k2.n_groups = (u32)order_big.size();
       k2.win_bytes = 0;
+      ctx->tim.k2_kinds |= 4u;
       TBZ_LAUNCH(tbz_k2_lz77, order_big.size(), ctx->stream, k2);
     }
     TBZ_HIP(hipGetLastError());
@@ -946,6 +968,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   ctx->tim.lz_ms = elapsed(ctx, 4, 5);
   ctx->tim.cksum_ms = elapsed(ctx, 5, 6);
   ctx->tim.total_ms = elapsed(ctx, 0, 6);
+  ctx->tim.scratch_bytes = scratch_total(ctx);
   if (getenv("TBZ_DEBUG") && !ctx->tim.fixup_rounds)
     fprintf(stderr, "tbz: ms scan %.3f | items+upload %.3f | huff %.3f | results+walk+layout %.3f | lz %.3f | cksum %.3f\n",
             elapsed(ctx, 0, 1), elapsed(ctx, 1, 2), elapsed(ctx, 2, 3), elapsed(ctx, 3, 4), elapsed(ctx, 4, 5),
@@ -1043,13 +1066,7 @@ void tbz_ctx_destroy(tbz_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
-  tbz::DevBuf* bufs[] = {&ctx->d_str_off, &ctx->d_str_len, &ctx->d_tile_first, &ctx->d_tile_counts,
-                         &ctx->d_tile_offsets, &ctx->d_markers, &ctx->d_items, &ctx->d_res, &ctx->d_tok, &ctx->d_scratch, &ctx->d_runs, &ctx->d_order,
-                         &ctx->d_segs, &ctx->d_groups, &ctx->d_ck_chunks, &ctx->d_ck_parts, &ctx->d_ck_streams,
-                         &ctx->d_ck_out, &ctx->d_crc_tab, &ctx->d_in_stage, &ctx->d_out_stage, &ctx->d_k3_fi, &ctx->d_k3_ni,
-                         &ctx->d_k3_oo, &ctx->d_k3_oc, &ctx->d_k3_sums, &ctx->d_k3_flags, &ctx->d_k3_gscan, &ctx->d_k3_gne,
-                         &ctx->d_k3_streams, &ctx->d_k3_glob, &ctx->d_redo_items, &ctx->d_redo_res, &ctx->d_k0_slots, &ctx->d_k0_fm, &ctx->d_hdr, &ctx->d_gck, &ctx->d_gchunks, &ctx->d_ck_l1, &ctx->d_tok2, &ctx->d_runs2};
-  for (auto* b : bufs)
+  for (auto* b : tbz::all_pools(ctx))
     if (b->p) hipFree(b->p);
   if (ctx->h_pin) hipHostFree(ctx->h_pin);
   for (auto& ev : ctx->ev)
@@ -1105,8 +1122,11 @@ static int stage_batch(tbz_ctx* ctx, int format, size_t n, const uint8_t* const*
       TBZ_HIP(hipMemcpyAsync((uint8_t*)ctx->d_in_stage.p + io[i], ins[i], in_lens[i], hipMemcpyHostToDevice,
                              ctx->stream));
     }
+  uint32_t n_h2d = 0;
+  for (size_t i = 0; i < n; i++) n_h2d += in_lens[i] ? 1u : 0u;
   r = inflate_core(ctx, format, n, ctx->d_in_stage.p, io.data(), il.data(), size_only ? nullptr : ctx->d_out_stage.p,
                    oo.data(), oc.data(), results, size_only);
+  ctx->tim.h2d_copies = n_h2d;
   if (r) return r;
   if (!size_only) {
     for (size_t i = 0; i < n; i++)

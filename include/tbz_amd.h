@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TBZ_ABI_VERSION 1
+#define TBZ_ABI_VERSION 2
 
 /* decompress-vector's :format keyword (api.lisp:31-34) */
 enum { TBZ_FORMAT_DEFLATE = 0, TBZ_FORMAT_ZLIB = 1, TBZ_FORMAT_GZIP = 2 };
@@ -95,11 +95,12 @@ typedef struct tbz_result {
 } tbz_result;
 
 /* durations of the device stages of the LAST call, from HIP events recorded on the
- * context's stream (ms).  bench.py builds roofline.achieved from these. */
+ * context's stream (ms), and what the engine launched.  bench.py builds roofline.achieved and
+ * roofline.kernel from these. */
 typedef struct tbz_timings {
-  float scan_ms;     /* K0 scan_markers (count + scan + emit) */
+  float scan_ms;     /* K0 scan_markers (count + scan + emit) + K0b block-start finder */
   float huff_ms;     /* K1 huff_decode (all rounds) */
-  float lz_ms;       /* K2 lz77_resolve */
+  float lz_ms;       /* K2 lz77_resolve (both planes when segments need history they do not hold) */
   float cksum_ms;    /* K4/K5 checksum partials + combine */
   float total_ms;    /* first kernel start .. last kernel end (device time, includes host chain gaps) */
   uint32_t huff_launches;
@@ -107,6 +108,17 @@ typedef struct tbz_timings {
   uint64_t token_words; /* u16 token words written by K1 (traffic accounting) */
   uint64_t n_segments;
   uint64_t n_groups;
+  /* ---- ABI 2 */
+  float find_ms;     /* K0b: speculative block-start candidates (part of scan_ms) */
+  float resolve_ms;  /* K6: window propagation + marker resolution across LZ77 groups */
+  uint32_t k1_gang;  /* K1 flavour of the main launch: 1 = one lane per item, 8/16/32/64 = gang width */
+  uint32_t k2_kinds; /* K2 kernels launched: bit0 tbz_k2_lz77_dual, bit1 tbz_k2_lz77_small, bit2 tbz_k2_lz77 (ring),
+                        bit3 the ring kernel's second (pointer high octet) plane */
+  uint64_t n_candidates; /* block starts proposed by K0b */
+  uint64_t n_hgroups;    /* LZ77 groups decoded against a symbolic 32 KiB history (resolved by K6) */
+  uint64_t scratch_bytes;/* device scratch held by the context after the call (token pool, run tables, ...) */
+  uint32_t h2d_copies;   /* host->device input copies of the call (tbz_inflate / _size: 1 per staging) */
+  uint32_t reserved;
 } tbz_timings;
 
 typedef struct tbz_ctx tbz_ctx;

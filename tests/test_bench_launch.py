@@ -1,0 +1,48 @@
+"""bench.py's launch and sharding logic on the CPU: `--gpus 2` from a plain `python bench.py` has to start its
+own two ranks (a child `torch.distributed.run`; the parent never touches a GPU), shard config 4's FIXED batch
+with multi.assign_streams and print ONE JSON line from rank 0.  Engine = the lane-emulator build of the kernel
+sources, process group = gloo; sizes are tiny and the numbers mean nothing."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+EMU = os.path.join(EMU_DIR, "libtbz_emu.so")
+
+
+def _run(*extra, timeout=900):
+    subprocess.check_call(["make", "-C", EMU_DIR, "libtbz_emu.so"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--lib", EMU,
+                        "--steps", "1", "--warmup", "1", "--no-cpu-baseline", *extra],
+                       capture_output=True, text=True, env=env, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_self_launch_config4_two_ranks():
+    j = _run("--gpus", "2", "--config", "4", "--size-mib", "0.5")
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong"
+    assert j["config"]["streams_per_gpu"] == 4            # 8 streams over 2 ranks
+    assert j["config"]["decompressed_bytes"] == 4 * (64 << 10)
+    assert j["roofline"]["bound"] == "hbm" and j["roofline"]["frac"] > 0
+    assert "tbz_k1" in j["roofline"]["kernel"] and "tbz_k2" in j["roofline"]["kernel"]
+    assert j["cpu_baseline"] is None                        # N > 1: no CPU leg
+
+
+def test_bench_weak_default_two_ranks():
+    j = _run("--gpus", "2", "--size-mib", "0.25")
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["workload"].startswith("config 2:")
+
+
+def test_bench_single_process_configs():
+    for cfg, fmt in (("1", "deflate"), ("3", "gzip"), ("5", "zlib"), ("nf", "zlib")):
+        j = _run("--config", cfg, "--size-mib", "0.5")
+        assert j["n_gpus"] == 1 and j["value"] > 0, cfg
+        assert j["config"]["workload"].startswith("config %s:" % cfg)

@@ -71,6 +71,38 @@ def test_gpu_config2_128mib_properties(eng):
     assert bytes(got) == p
 
 
+def test_gpu_config4_batch_on_one_gpu(eng, request):
+    """BASELINE config 4 at full size on ONE GPU: the 8 x 128 MiB batch in one tbz_inflate_batch_device call —
+    status, length and adler32 of every stream (a checksum of everything, compared with zlib's over the
+    generated plaintext and with the stream's own trailer), and a full octet compare of two of them."""
+    import numpy as np
+    if request.node.callspec.params["eng"] != "auto":
+        pytest.skip("full-size batch: once, with the flavours the engine picks itself")
+    each, n = 128 << 20, 8
+    streams = [K.zlib_flush_stream(each, seed=0x3B2 + i, workers=min(16, os.cpu_count() or 1)) for i in range(n)]
+    in_offs, out_offs, ip, op = [], [], 0, 0
+    for s, p, a in streams:
+        in_offs.append(ip)
+        ip += (len(s) + 15) & ~15
+        out_offs.append(op)
+        op += each
+    d_in, d_out = eng.malloc(ip + 64), eng.malloc(op + 64)
+    try:
+        for (s, _, _), o in zip(streams, in_offs):
+            eng.h2d(d_in + o, s)
+        res = eng.inflate_batch_device(d_in, in_offs, [len(s[0]) for s in streams], d_out, out_offs, [each] * n, 1)
+        for i, r in enumerate(res):
+            assert r.status == 0 and r.out_len == each and (r.flags & 1), (i, r.status, r.out_len)
+            assert r.adler32 == streams[i][2] and r.segments == each // 16384, i
+        for i in (0, n - 1):
+            got = bytearray(each)
+            eng.d2h(got, d_out + out_offs[i])
+            assert np.array_equal(np.frombuffer(got, np.uint8), np.frombuffer(streams[i][1], np.uint8)), i
+    finally:
+        eng.free(d_in)
+        eng.free(d_out)
+
+
 def test_gpu_one_stream_across_ranks(eng):
     """SURVEY §8e row 2 on the card: the parts of ONE stream that 1/2/3/4/8 ranks would decode, decoded in turn
     by this GPU; verdict, offsets, combined checksum and octets (the two-process run is tests/test_multirank_gloo.py)"""

@@ -421,7 +421,7 @@ def _lz_apply(out, length, dist):
         out += (pat * reps)[:length]
 
 
-def adversarial_stream(total=256 << 20, seed=0x3B5A0005, full_flush_every=0):
+def adversarial_stream(total=256 << 20, seed=0x3B5A0005, full_flush_every=0, sync_flush_every=0):
     """Config 5: :zlib, fixed-Huffman blocks.
       phase A (first half): per block one literal then (len 258, dist 1) runs;
       phase B: a 32 KiB random page, then (len 3..258, dist 32768) references
@@ -430,7 +430,8 @@ def adversarial_stream(total=256 << 20, seed=0x3B5A0005, full_flush_every=0):
     Blocks hold <= 64 KiB of output.  full_flush_every=0 (default): no flush markers —
     the stream is ONE sequential segment (stated in DESIGN.md).  Otherwise an empty stored
     block + history restart is inserted every `full_flush_every` output bytes (phase B then
-    re-emits its page so distances stay legal).
+    re-emits its page so distances stay legal).  sync_flush_every: the empty stored block alone, history
+    kept (what Z_SYNC_FLUSH does): matches keep reaching back across the markers.
     Returns (stream, plain)."""
     rng = np.random.default_rng([seed, 5])
     w = FixedHuffmanWriter()
@@ -451,8 +452,15 @@ def adversarial_stream(total=256 << 20, seed=0x3B5A0005, full_flush_every=0):
         hist = 0
 
     def maybe_flush():
+        nonlocal since_flush
         if full_flush_every and since_flush >= full_flush_every:
             flush_marker()
+        elif sync_flush_every and since_flush >= sync_flush_every:
+            w.bits(0, 3)
+            w.align()
+            w.bits(0x0000, 16)
+            w.bits(0xFFFF, 16)
+            since_flush = 0
 
     # ---- phase A
     blk = 0

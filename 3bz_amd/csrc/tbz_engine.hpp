@@ -41,7 +41,7 @@ struct DevBuf {
 struct tbz_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[10] = {};
+  hipEvent_t ev[12] = {};
   std::string err;
   tbz_timings tim{};
   uint64_t gang_rounds = 0, gang_valid = 0;  // diagnostics of the last call (K1g)
@@ -51,11 +51,15 @@ struct tbz_ctx {
   void* h_pin = nullptr;     // pinned host scratch for small read-backs
   size_t h_pin_cap = 0;
   int k1_mode = 0;  // 0 auto, 1 lane-per-item, 4..64 gang of that many lanes (env TBZ_K1_MODE; tests force each)
+  bool sym_hist = true;  // groups that need history they do not hold run against symbolic history + K6 (env TBZ_HIST=off:
+                         // they join their predecessors' group instead, one workgroup per chain, as in round 1)
+  int find_mode = 1;  // K0b block-start finder: 0 never, 1 for streams whose items are large (default), 2 for every stream
+                      // of at least one finder tile (env TBZ_FIND=off|auto|always; tests force it at small sizes)
   // device pools (grow-only)
   tbz::DevBuf d_str_off, d_str_len, d_tile_first, d_tile_counts, d_tile_offsets, d_markers, d_items, d_res,
       d_tok, d_scratch, d_runs, d_segs, d_groups, d_order, d_k3_fi, d_k3_ni, d_k3_oo, d_k3_oc, d_k3_sums, d_k3_flags,
       d_k3_gscan, d_k3_gne, d_k3_streams, d_k3_glob, d_redo_items, d_redo_res, d_k0_slots, d_k0_fm, d_hdr, d_gck, d_gchunks, d_ck_l1, d_tok2, d_runs2, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
-      d_out_stage;
+      d_out_stage, d_kb_tf, d_kb_slots, d_kb_counts, d_kb_offsets, d_kb_cands, d_kb_fc, d_kb_head, d_markers2, d_kb_fm2, d_mark, d_hg, d_k6s;
 };
 
 namespace tbz {
@@ -68,7 +72,9 @@ static std::vector<DevBuf*> all_pools(tbz_ctx* ctx) {
           &ctx->d_crc_tab, &ctx->d_in_stage, &ctx->d_out_stage, &ctx->d_k3_fi, &ctx->d_k3_ni, &ctx->d_k3_oo,
           &ctx->d_k3_oc, &ctx->d_k3_sums, &ctx->d_k3_flags, &ctx->d_k3_gscan, &ctx->d_k3_gne, &ctx->d_k3_streams,
           &ctx->d_k3_glob, &ctx->d_redo_items, &ctx->d_redo_res, &ctx->d_k0_slots, &ctx->d_k0_fm, &ctx->d_hdr,
-          &ctx->d_gck, &ctx->d_gchunks, &ctx->d_ck_l1, &ctx->d_tok2, &ctx->d_runs2};
+          &ctx->d_gck, &ctx->d_gchunks, &ctx->d_ck_l1, &ctx->d_tok2, &ctx->d_runs2, &ctx->d_kb_tf, &ctx->d_kb_slots,
+          &ctx->d_kb_counts, &ctx->d_kb_offsets, &ctx->d_kb_cands, &ctx->d_kb_fc, &ctx->d_kb_head, &ctx->d_markers2,
+          &ctx->d_kb_fm2, &ctx->d_mark, &ctx->d_hg, &ctx->d_k6s};
 }
 static uint64_t scratch_total(tbz_ctx* ctx) {
   uint64_t t = 0;
@@ -332,9 +338,9 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   // One pass over the input finds the markers (kept per tile, then compacted in order) and a small kernel
   // builds the K1 items; the host reads 8 bytes + one index per stream.  Host copies of the marker and item
   // arrays are fetched only by the general (host) layout path.
-  std::vector<uint64_t> markers;
   std::vector<Item> items;
-  bool host_tables = false;
+  bool host_tables = false, have_find = false, have_resolve = false;
+  uint32_t last_h_stream = 0;
   uint32_t n_mark = 0;
   std::vector<uint32_t> first_marker(n + 1, 0);
   if (tiles) {
@@ -403,14 +409,85 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if ((r = upload(ctx, ctx->d_items, items))) return r;
     host_tables = true;
   }
-  const size_t n_items = (size_t)n_mark + n;
+  // ---------------------------------------------------------------- K0b: speculative block starts
+  // Streams whose items are large (few or no flush markers: ordinary zlib / gzip output) are searched for plausible
+  // dynamic-Huffman block headers; the candidates join the markers (one ascending list of bit positions per stream)
+  // and the items are built again from the merged list.  Nothing downstream tells a candidate from a marker.
+  const u64* d_markers_cur = (const u64*)ctx->d_markers.p;
   const u32* d_first_marker = (const u32*)ctx->d_k0_fm.p + 2;
-  auto fetch_host_tables = [&]() -> int {  // the general layout path walks items and markers on the host
+  if (tiles && ctx->find_mode) {
+    constexpr uint64_t FIND_MIN_ITEM_BITS = 8ull * (48u << 10);  // mean compressed octets per item below which it does not pay
+    std::vector<uint32_t> tfb(n + 1);
+    uint64_t tiles_b = 0;
+    for (size_t s = 0; s < n; s++) {
+      tfb[s] = (uint32_t)tiles_b;
+      const uint64_t items_s = 1 + (first_marker[s + 1] - first_marker[s]);
+      const bool search = ctx->find_mode == 2 ? sp[s].in_len >= 64 : (sp[s].in_len * 8 / items_s >= FIND_MIN_ITEM_BITS);
+      if (search) tiles_b += ((((uintptr_t)d_in + in_offs[s]) & 15) + in_lens[s] + K0B_TILE - 1) / K0B_TILE;
+      if (tiles_b > 0x7fffffffu) return TBZ_E_ARG;
+    }
+    tfb[n] = (uint32_t)tiles_b;
+    if (tiles_b) {
+      TBZ_HIP(hipEventRecord(ctx->ev[8], ctx->stream));
+      if ((r = upload(ctx, ctx->d_kb_tf, tfb))) return r;
+      if ((r = ensure(ctx, ctx->d_kb_slots, tiles_b * (size_t)K0B_SLOTS * 8))) return r;
+      if ((r = ensure(ctx, ctx->d_kb_counts, tiles_b * 4))) return r;
+      if ((r = ensure(ctx, ctx->d_kb_offsets, (tiles_b + 1) * 4))) return r;
+      if ((r = ensure(ctx, ctx->d_kb_cands, tiles_b * (size_t)K0B_SLOTS * 8 + 16))) return r;
+      if ((r = ensure(ctx, ctx->d_kb_fc, (n + 1) * 4))) return r;
+      if ((r = ensure(ctx, ctx->d_kb_head, 16))) return r;
+      if ((r = ensure(ctx, ctx->d_kb_fm2, (n + 1) * 4 + 8))) return r;
+      if ((r = ensure(ctx, ctx->d_markers2, ((size_t)n_mark + tiles_b * (size_t)K0B_SLOTS) * 8 + 16))) return r;
+      K0bParams kb{(const u8*)d_in, (const u64*)ctx->d_str_off.p, (const u64*)ctx->d_str_len.p,
+                   (const u32*)ctx->d_kb_tf.p, (u32)n, (u32)tiles_b, (u64*)ctx->d_kb_slots.p, (u32*)ctx->d_kb_counts.p,
+                   (u32*)ctx->d_kb_offsets.p, (u64*)ctx->d_kb_cands.p, (u32*)ctx->d_kb_fc.p, (u32*)ctx->d_kb_head.p,
+                   (const u64*)ctx->d_markers.p, (const u32*)ctx->d_k0_fm.p + 2, (u64*)ctx->d_markers2.p,
+                   (u32*)ctx->d_kb_fm2.p + 2, (u32*)ctx->d_kb_fm2.p};
+      TBZ_LAUNCH(tbz_k0b_scan, tiles_b, ctx->stream, kb);
+      TBZ_LAUNCH(tbz_k0b_validate, tiles_b, ctx->stream, kb);
+      TBZ_LAUNCH(tbz_k0b_offsets, 1, ctx->stream, kb);
+      TBZ_LAUNCH(tbz_k0b_compact, tiles_b, ctx->stream, kb);
+      const size_t max_merge = (size_t)n_mark + tiles_b * (size_t)K0B_SLOTS;
+      TBZ_LAUNCH(tbz_k0b_merge, (max_merge + 63) / 64, ctx->stream, kb);
+      uint32_t* h_head = (uint32_t*)ctx->h_pin;
+      TBZ_HIP(hipMemcpyAsync(h_head, ctx->d_kb_fm2.p, (n + 3) * 4, hipMemcpyDeviceToHost, ctx->stream));
+      TBZ_HIP(hipStreamSynchronize(ctx->stream));
+      const uint32_t n_merged = h_head[0];
+      ctx->tim.n_candidates = n_merged - n_mark;
+      if (n_merged != n_mark) {
+        n_mark = n_merged;
+        for (size_t s = 0; s <= n; s++) first_marker[s] = h_head[2 + s];
+        if ((r = ensure(ctx, ctx->d_items, ((size_t)n_mark + n) * sizeof(Item)))) return r;
+        K0Params k0m{};
+        k0m.str_off = (const u64*)ctx->d_str_off.p;
+        k0m.str_len = (const u64*)ctx->d_str_len.p;
+        k0m.n_streams = (u32)n;
+        k0m.markers = (u64*)ctx->d_markers2.p;
+        k0m.first_marker = (u32*)ctx->d_kb_fm2.p + 2;
+        k0m.head = (u32*)ctx->d_kb_fm2.p;
+        k0m.items = (Item*)ctx->d_items.p;
+        k0m.format = (u32)format;
+        k0m.second_pass = 1;
+        TBZ_LAUNCH(tbz_k0_items, ((size_t)n_mark + n + 63) / 64, ctx->stream, k0m);
+        d_markers_cur = (const u64*)ctx->d_markers2.p;
+        d_first_marker = (const u32*)ctx->d_kb_fm2.p + 2;
+        for (size_t s = 0; s < n; s++) {
+          StreamPlan& S = sp[s];
+          S.first_marker = first_marker[s];
+          S.first_item = first_marker[s] + (uint32_t)s;
+          S.n_items = 1 + (first_marker[s + 1] - first_marker[s]);
+          S.cur_item = S.first_item;
+        }
+      }
+      TBZ_HIP(hipGetLastError());
+      TBZ_HIP(hipEventRecord(ctx->ev[9], ctx->stream));
+      have_find = true;
+    }
+  }
+  const size_t n_items = (size_t)n_mark + n;
+  auto fetch_host_tables = [&]() -> int {  // the general layout path walks the items on the host
     if (host_tables) return 0;
-    markers.resize(n_mark);
     items.resize(n_items);
-    if (n_mark)
-      TBZ_HIP(hipMemcpyAsync(markers.data(), ctx->d_markers.p, (size_t)n_mark * 8, hipMemcpyDeviceToHost, ctx->stream));
     TBZ_HIP(hipMemcpyAsync(items.data(), ctx->d_items.p, n_items * sizeof(Item), hipMemcpyDeviceToHost, ctx->stream));
     TBZ_HIP(hipStreamSynchronize(ctx->stream));
     host_tables = true;
@@ -447,7 +524,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   auto launch_lane = [&](const Item* d_items, SegResult* d_res, size_t n_it, bool fix) -> int {
     int rr = ensure(ctx, ctx->d_scratch, n_it * (size_t)K1_SCRATCH);
     if (rr) return rr;
-    K1Params k1{(const u8*)d_in, pool_tok(fix), d_items, d_res, (const u64*)ctx->d_markers.p,
+    K1Params k1{(const u8*)d_in, pool_tok(fix), d_items, d_res, d_markers_cur,
                 (u8*)ctx->d_scratch.p, pool_runs(fix), d_first_marker, (u32)n_mark, (u32)n_it, items_per_wg(n_it)};
     TBZ_LAUNCH(tbz_k1_huff_decode, (n_it + k1.items_per_wg - 1) / k1.items_per_wg, ctx->stream, k1);
     return 0;
@@ -489,7 +566,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     K1hParams kh{(const u8*)d_in, d_items, (u8*)ctx->d_scratch.p, (HdrRec*)ctx->d_hdr.p, (u32)n_it};
     if (ctx->k1h) TBZ_LAUNCH(tbz_k1h_headers, (n_it + 63) / 64, ctx->stream, kh);
     K1gParams kg{(const u8*)d_in, pool_tok(fix), pool_runs(fix), d_items, d_res,
-                 (const u64*)ctx->d_markers.p, d_first_marker, ctx->k1h ? (const HdrRec*)ctx->d_hdr.p : nullptr,
+                 d_markers_cur, d_first_marker, ctx->k1h ? (const HdrRec*)ctx->d_hdr.p : nullptr,
                  (const u8*)ctx->d_scratch.p, (u32)n_mark, (u32)n_it};
     switch (G) {
       case 8: TBZ_LAUNCH(tbz_k1g8_huff_decode, nwg, ctx->stream, kg); break;
@@ -588,7 +665,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       const u32 n_it = (u32)n_items;
       fused_adler = format == TBZ_FORMAT_ZLIB && !ctx->k2_single && h_glob->n_big == 0 && !getenv("TBZ_NO_FUSED_ADLER");
       K2Params k2{(const u16*)ctx->d_tok.p, (const RunRec*)ctx->d_runs.p, nullptr, nullptr, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, nullptr,
-                  (const u8*)d_in, (u8*)d_out, n_it, 0, 0, nullptr, nullptr};
+                  (const u8*)d_in, (u8*)d_out, n_it, 0, 0, nullptr, nullptr, 0, 0, 0};
       if (h_glob->n_big < n_it) {
         k2.win_bytes = (u32)((h_glob->max_small + K2_SLACK + 63) & ~63ull);
         k2.cls = h_glob->n_big ? 1 : 0;
@@ -827,6 +904,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   // ---------------------------------------------------------------- per-stream layout, groups, status
   std::vector<Seg> h_segs;
   std::vector<Group> h_groups;
+  std::vector<uint8_t> h_hist;      // per group: 1 = H-group (symbolic history)
+  std::vector<uint32_t> h_gstream;  // per group: its stream
   for (size_t s = 0; s < n; s++) {
     StreamPlan& S = sp[s];
     tbz_result& R = results[s];
@@ -836,13 +915,20 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     status = fill_result(s, status, (uint32_t)v.size(), dist_first[s] == DIST_FIRST);
     if (status < 0) continue;  // reference signals an error: no partial-result contract
     if (size_only) continue;
-    // groups: a segment that needs history (or continues a repaired block) joins its predecessor
+    // groups: consecutive segments that share one LZ77 window in one K2 workgroup.  A segment that needs no history
+    // opens a group of its own.  One that does (its matches reach before its first octet, or it continues a
+    // repaired block) joins the group before it while that group is small; a group whose segments reach before
+    // ITS first octet becomes an H-group: decoded against symbolic history, resolved by K6 (so the groups of a
+    // stream without flush points run in parallel instead of collapsing into one workgroup).
     uint64_t o = 0;
     S.seg_first = (uint32_t)h_segs.size();
     const size_t g0 = h_groups.size();  // this stream's first group
+    constexpr uint64_t H_JOIN_BELOW = 48u << 10;  // a group keeps taking in history-needing segments below this size
     for (size_t i = 0; i < v.size(); i++) {
       if (o >= R.out_len) break;
-      bool join = i > 0 && (v[i].continues || v[i].deficit > 0);
+      const bool need = i > 0 && (v[i].continues || v[i].deficit > 0);
+      bool join = need;
+      if (ctx->sym_hist && need) join = (S.out_off + o) - h_groups.back().out_abs < H_JOIN_BELOW;
       if (!join) {
         Group g;
         g.out_abs = S.out_off + o;
@@ -850,14 +936,22 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         g.seg_first = (uint32_t)h_segs.size();
         g.seg_count = 0;
         h_groups.push_back(g);
-      } else {
-        // the history it needs may start before its predecessor's group (a repaired block in a damaged stream
-        // copying from segments that were independent until then): take in earlier groups until it is covered
-        const uint64_t need = S.out_off + (o > v[i].deficit ? o - v[i].deficit : 0);
-        while (h_groups.size() > g0 + 1 && h_groups.back().out_abs > need) {
-          const uint32_t cnt = h_groups.back().seg_count;
-          h_groups.pop_back();
-          h_groups.back().seg_count += cnt;
+        h_hist.push_back(0);
+      }
+      const uint64_t reach = S.out_off + (o > v[i].deficit ? o - v[i].deficit : 0);  // first octet its matches copy from
+      if (need && reach < h_groups.back().out_abs) {
+        if (ctx->sym_hist && h_groups.size() > g0 + 1) {
+          h_hist.back() = 1;
+        } else {
+          // (round-1 scheme, and always for a stream's first group) take in earlier groups until the history is covered
+          while (h_groups.size() > g0 + 1 && h_groups.back().out_abs > reach) {
+            const uint32_t cnt = h_groups.back().seg_count;
+            const uint8_t hh = h_hist.back();
+            h_groups.pop_back();
+            h_hist.pop_back();
+            h_groups.back().seg_count += cnt;
+            h_hist.back() |= hh;
+          }
         }
       }
       h_groups.back().seg_count++;
@@ -865,6 +959,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       o += v[i].seg.out_bytes;
     }
     S.seg_count = (uint32_t)h_segs.size() - S.seg_first;
+    for (size_t gi = g0; gi < h_groups.size(); gi++) h_gstream.push_back((uint32_t)s);
   }
   ctx->tim.n_segments = h_segs.size();
   ctx->tim.n_groups = h_groups.size();
@@ -876,13 +971,34 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if ((r = upload(ctx, ctx->d_segs, h_segs))) return r;
     if ((r = upload(ctx, ctx->d_groups, h_groups))) return r;
     // groups whose whole output fits a linear LDS window (the common case: flush-delimited segments)
-    // run with dynamic LDS sized to the largest of them; the rest take the 32 KiB-history ring kernel
-    std::vector<uint32_t> order_small, order_big;
-    uint64_t max_small = 0;
+    // run with dynamic LDS sized to the largest of them; the rest take the 32 KiB-history ring kernel;
+    // H-groups take the ring kernel twice (octet plane, pointer plane) and K6 afterwards
+    std::vector<uint32_t> order_small, order_big, order_h;
+    std::vector<HGroup> hgs;
+    std::vector<K6Stream> k6s;
+    uint64_t max_small = 0, mark_lo = ~0ull, mark_hi = 0, max_h = 0;
     for (size_t gi = 0; gi < h_groups.size(); gi++) {
       uint64_t tot = 0;
       for (uint32_t k = 0; k < h_groups[gi].seg_count; k++) tot += h_segs[h_groups[gi].seg_first + k].out_bytes;
-      if (tot + K2_SLACK <= K2_SMALL_MAX) {
+      if (h_hist[gi]) {
+        const StreamPlan& S = sp[h_gstream[gi]];
+        order_h.push_back((uint32_t)gi);
+        HGroup hg;
+        hg.start = h_groups[gi].out_abs;
+        hg.end = std::min(hg.start + tot, h_groups[gi].out_end);
+        hg.floor = S.out_off;
+        hg.pad = 0;
+        if (k6s.empty() || h_gstream[gi] != last_h_stream) {
+          k6s.push_back(K6Stream{(u32)hgs.size(), 0});
+          last_h_stream = h_gstream[gi];
+        }
+        hg.stream = (u32)k6s.size() - 1;
+        k6s.back().count++;
+        hgs.push_back(hg);
+        mark_lo = std::min(mark_lo, S.out_off);
+        mark_hi = std::max(mark_hi, h_groups[gi].out_end);
+        max_h = std::max(max_h, hg.end - hg.start);
+      } else if (tot + K2_SLACK <= K2_SMALL_MAX) {
         order_small.push_back((uint32_t)gi);
         max_small = std::max(max_small, tot);
       } else {
@@ -891,9 +1007,11 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     }
     std::vector<uint32_t> order(order_small);
     order.insert(order.end(), order_big.begin(), order_big.end());
+    order.insert(order.end(), order_h.begin(), order_h.end());
     if ((r = upload(ctx, ctx->d_order, order))) return r;
     K2Params k2{(const u16*)ctx->d_tok.p, (const RunRec*)ctx->d_runs.p, (const u16*)ctx->d_tok2.p, (const RunRec*)ctx->d_runs2.p,
-                (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, (const u32*)ctx->d_order.p, (const u8*)d_in, (u8*)d_out, 0, 0, 0, nullptr, nullptr};
+                (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, (const u32*)ctx->d_order.p, (const u8*)d_in, (u8*)d_out, 0, 0, 0, nullptr, nullptr,
+                0, 0, 0};
     if (!order_small.empty()) {
       k2.n_groups = (u32)order_small.size();
       k2.win_bytes = (u32)((max_small + K2_SLACK + 63) & ~63ull);
@@ -910,6 +1028,34 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       k2.win_bytes = 0;
       ctx->tim.k2_kinds |= 4u;
       TBZ_LAUNCH(tbz_k2_lz77, order_big.size(), ctx->stream, k2);
+    }
+    if (!order_h.empty()) {
+      // the mark plane covers [mark_lo, mark_hi) of the output, at the same alignment (mod 16) as the output itself
+      const uint32_t m0 = (uint32_t)(((uintptr_t)d_out + mark_lo) & 15);
+      if ((r = ensure(ctx, ctx->d_mark, (mark_hi - mark_lo) + 64))) return r;
+      if ((r = upload(ctx, ctx->d_hg, hgs))) return r;
+      if ((r = upload(ctx, ctx->d_k6s, k6s))) return r;
+      k2.order = (const u32*)ctx->d_order.p + order_small.size() + order_big.size();
+      k2.n_groups = (u32)order_h.size();
+      k2.win_bytes = 0;
+      k2.hist = 1;
+      ctx->tim.k2_kinds |= 4u | 8u;
+      ctx->tim.n_hgroups = order_h.size();
+      TBZ_LAUNCH(tbz_k2_lz77, order_h.size(), ctx->stream, k2);
+      k2.plane = 1;
+      k2.out_base = (u8*)ctx->d_mark.p + m0;
+      k2.out_bias = mark_lo;
+      TBZ_LAUNCH(tbz_k2_lz77, order_h.size(), ctx->stream, k2);
+      TBZ_HIP(hipEventRecord(ctx->ev[10], ctx->stream));
+      K6Params k6{(u8*)d_out, (u8*)ctx->d_mark.p + m0, mark_lo, (const HGroup*)ctx->d_hg.p, (const K6Stream*)ctx->d_k6s.p,
+                  (u32)hgs.size(), (u32)k6s.size(), 0};
+      TBZ_LAUNCH_WG(tbz_k6_window, k6s.size(), K6_THREADS, ctx->stream, k6);
+      if (max_h > K6_W) {
+        k6.pieces = (u32)((max_h - K6_W + 15 + K6_PIECE - 1) / K6_PIECE);
+        TBZ_LAUNCH(tbz_k6_resolve, (size_t)hgs.size() * k6.pieces, ctx->stream, k6);
+      }
+      TBZ_HIP(hipEventRecord(ctx->ev[11], ctx->stream));
+      have_resolve = true;
     }
     TBZ_HIP(hipGetLastError());
   }
@@ -965,7 +1111,9 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     }
   }
   ctx->tim.scan_ms = elapsed(ctx, 0, 1);
-  ctx->tim.lz_ms = elapsed(ctx, 4, 5);
+  ctx->tim.find_ms = have_find ? elapsed(ctx, 8, 9) : 0.f;
+  ctx->tim.resolve_ms = have_resolve ? elapsed(ctx, 10, 11) : 0.f;
+  ctx->tim.lz_ms = elapsed(ctx, 4, 5) - ctx->tim.resolve_ms;
   ctx->tim.cksum_ms = elapsed(ctx, 5, 6);
   ctx->tim.total_ms = elapsed(ctx, 0, 6);
   ctx->tim.scratch_bytes = scratch_total(ctx);
@@ -1051,6 +1199,8 @@ int tbz_ctx_create(int device_id, tbz_ctx** out_ctx) {
   if (const char* m = getenv("TBZ_HOST_LAYOUT")) ctx->host_layout = m[0] == '1';
   if (const char* m = getenv("TBZ_K2_MODE")) ctx->k2_single = !strcmp(m, "single");
   if (const char* m = getenv("TBZ_K1H")) ctx->k1h = m[0] != '0';
+  if (const char* m = getenv("TBZ_HIST")) ctx->sym_hist = strcmp(m, "off") != 0;
+  if (const char* m = getenv("TBZ_FIND")) ctx->find_mode = !strcmp(m, "off") ? 0 : !strcmp(m, "always") ? 2 : 1;
   if (const char* m = getenv("TBZ_K1_MODE")) {
     if (!strcmp(m, "lane")) ctx->k1_mode = 1;
     else if (!strncmp(m, "gang", 4)) {

@@ -62,6 +62,9 @@ TBZ_DEV u32 wave_xor_u32(u32 v) {
   return v;
 }
 
+// order in which a dynamic block header lists the code-length code's lengths (constants.lisp:63-68)
+TBZ_CONSTANT u8 c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
 // LDS accepts any octet address for 2/4/8/16-octet accesses on gfx950
 struct __attribute__((packed, aligned(1))) K2U128 { u64 lo, hi; };
 struct __attribute__((packed, aligned(1))) K2U64 { u64 v; };
@@ -85,7 +88,7 @@ TBZ_DEV u32 load_u32_unaligned(const u32* TBZ_RESTRICT w, u64 idx, u64 nwords) {
 }
 
 // ================================================================================================
-// K0 — marker scan.  A marker is the byte AFTER `00 00 FF FF` (the LEN/NLEN of an empty stored
+// K0 — marker scan.  A marker is the BIT position of the byte AFTER `00 00 FF FF` (the LEN/NLEN of an empty stored
 // block, which zlib emits for Z_SYNC_FLUSH / Z_FULL_FLUSH).  3bz has no counterpart: it is strictly
 // sequential (:block-end -> :start-of-block, deflate.lisp:719-722).
 // Work split: a tile is 64 KiB of MEMORY (16-octet aligned, so every load is an aligned dwordx4) =
@@ -199,7 +202,7 @@ TBZ_KERNEL void tbz_k0_scan_tiles(K0Params P) {
         while (m) {
           u32 k = __builtin_ctz(m);
           m &= m - 1;
-          if (o < K0_SLOTS) slots[o] = (u64)(c + k - T.base) + 4;
+          if (o < K0_SLOTS) slots[o] = ((u64)(c + k - T.base) + 4) * 8;
           o++;
         }
         base += tbz_shfl(inc, 63);
@@ -260,8 +263,8 @@ TBZ_KERNEL void tbz_k0_items(K0Params P) {
   const u32 s = lo, fm = P.first_marker[s], nm = P.first_marker[s + 1] - fm;
   const u32 k = i - (fm + s);
   Item it;
-  it.start_bit = (k == 0 ? P.str_off[s] : P.markers[fm + k - 1]) * 8;
-  it.limit_bit = k < nm ? P.markers[fm + k] * 8 : ~0ull;
+  it.start_bit = k == 0 ? P.str_off[s] * 8 : P.markers[fm + k - 1];
+  it.limit_bit = k < nm ? P.markers[fm + k] : ~0ull;
   it.end_byte = P.str_off[s] + P.str_len[s];
   it.stream = s;
   it.flags = (P.format << ITEM_FMT_SHIFT) | (k == 0 ? ITEM_HEAD : 0u);
@@ -283,10 +286,332 @@ TBZ_KERNEL void tbz_k0_scan_emit(K0Params P) {
     while (m) {
       u32 k = __builtin_ctz(m);
       m &= m - 1;
-      P.markers[o++] = (u64)(c + k - T.base) + 4;
+      P.markers[o++] = ((u64)(c + k - T.base) + 4) * 8;
     }
     base += tbz_shfl(inc, 63);
   }
+}
+
+// ================================================================================================
+// K0b — block-start finder for streams WITHOUT flush markers.  DEFLATE blocks are bit-aligned
+// and unmarked: 3bz finds the next block only by finishing the previous one (:block-end -> :start-of-block,
+// deflate.lisp:719-722).  But the header of a dynamic-Huffman block (deflate.lisp:577-669) is heavily
+// redundant, so plausible headers can be FOUND: every bit position is tested for
+//     BFINAL=0, BTYPE=2 | HLIT <= 29, HDIST <= 29 | the code-length code is complete (Kraft sum exactly 1)
+// by tbz_k0b_scan (bit-parallel masks over 32 positions at a time, then one LDS lookup per four code
+// lengths: ~1 position in 2300 survives on compressed data), and the survivors are parsed in full by
+// tbz_k0b_validate, one lane each: the HLIT+HDIST code lengths must decode without a repeat error, the
+// literal/length code must be complete and hold the end-of-block symbol, the distance code complete or a
+// single symbol (what is left is a true block start, or a false positive every few hundred MB).
+// A candidate is only ever USED if the block chain lands on it exactly (tbz_engine.hpp): a false candidate
+// costs a repair launch, never a wrong octet; a missed true start costs parallelism, nothing else.
+// Fixed-Huffman and stored blocks carry no such redundancy and are not looked for: the item before them
+// decodes through them.
+// ================================================================================================
+constexpr u32 K0B_TILE = 16u << 10;  // octets of memory per finder workgroup (16 rows of 1 KiB)
+constexpr u32 K0B_SLOTS = 128;       // survivors kept per tile (expected ~56 on compressed data; more are dropped)
+constexpr u32 K0B_TAIL_BITS = 80;    // a candidate must have this much stream left (3+14+up to 57 header bits)
+struct K0bParams {
+  const u8* in_base;
+  const u64* str_off;
+  const u64* str_len;
+  const u32* tile_first;   // [n_streams+1] prefix of FINDER tiles per stream (a stream that is not searched has none)
+  u32 n_streams;
+  u32 n_tiles;
+  u64* slots;              // [n_tiles][K0B_SLOTS] candidate bit positions (relative to in_base), ascending
+  u32* counts;             // [n_tiles]
+  u32* offsets;            // [n_tiles+1] exclusive scan of counts
+  u64* cands;              // compacted candidates (stream order, ascending)
+  u32* first_cand;         // [n_streams+1]
+  u32* head;               // [1]: total candidates
+  const u64* markers;      // merge: K0's flush markers (bit positions) ...
+  const u32* first_marker; //   [n_streams+1]
+  u64* merged;             // ... and the merged list
+  u32* first_merged;       //   [n_streams+1]
+  u32* head_merged;        //   [2]: total, 0  (laid out as K0Params::head for tbz_k0_items)
+};
+TBZ_DEV u32 k0b_find_stream(const K0bParams& P, u32 tile) {
+  u32 lo = 0, hi = P.n_streams;  // tile_first[lo] <= tile < tile_first[hi]; streams without tiles are skipped over
+  while (hi - lo > 1) {
+    u32 mid = (lo + hi) >> 1;
+    if (P.tile_first[mid] <= tile) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+TBZ_DEV u32 k0b_kraft3(u32 l) { return (128u >> l) & 0x7fu; }  // 2^(7-l), 0 for an unused symbol
+
+TBZ_KERNEL void tbz_k0b_scan(K0bParams P) {
+  TBZ_SHARED u16 T[4096];  // Kraft sum (units of 2^-7) of four 3-bit code lengths
+  const u32 lane = tbz_lane();
+  for (u32 i = lane; i < 4096; i += 64)
+    T[i] = (u16)(k0b_kraft3(i & 7) + k0b_kraft3((i >> 3) & 7) + k0b_kraft3((i >> 6) & 7) + k0b_kraft3((i >> 9) & 7));
+  tbz_sync();
+  const u32 tile = tbz_block();
+  const u32 s = k0b_find_stream(P, tile);
+  const uintptr_t base = (uintptr_t)P.in_base;
+  const uintptr_t s_lo = base + P.str_off[s], s_hi = s_lo + P.str_len[s];
+  const uintptr_t t0 = (s_lo & ~(uintptr_t)15) + (uintptr_t)(tile - P.tile_first[s]) * K0B_TILE;
+  // candidate bit positions p (relative to in_base) must satisfy p_min <= p <= p_max
+  const u64 p_min = (u64)(s_lo - base) * 8 + 1;  // (the stream's first bit belongs to the head item)
+  const u64 p_end = (u64)(s_hi - base) * 8;
+  u64* slots = P.slots + (u64)tile * K0B_SLOTS;
+  u32 nout = 0;
+  for (u32 r = 0; r < K0B_TILE / 1024; r++) {
+    const uintptr_t c = t0 + r * 1024 + lane * 16;
+    if (t0 + r * 1024 >= s_hi) break;  // wave-uniform: the rest of the tile lies past the stream
+    u32 w[7];
+    uint4 v{};
+    if (c < s_hi && c + 16 > s_lo) v = *(const uint4*)c;  // an aligned chunk holding a stream octet is mapped
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    w[4] = tbz_wave_shl1(v.x);
+    w[5] = tbz_wave_shl1(v.y);
+    w[6] = tbz_wave_shl1(v.z);
+    if (lane == 63) {
+      uint4 nx{};
+      const uintptr_t cn = c + 16;
+      if (cn < s_hi && cn + 16 > s_lo) nx = *(const uint4*)cn;
+      w[4] = nx.x; w[5] = nx.y; w[6] = nx.z;
+    }
+    const u64 bit0 = (u64)(c - base) * 8;  // may wrap below in_base for the first chunk: those positions fail p_min
+    u32 found = 0, nf = 0;                 // up to four survivors per lane: their offsets 0..127, one octet each
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {
+      const u64 x = ((u64)w[k + 1] << 32) | w[k];
+      const u64 m = ~x & ~(x >> 1) & (x >> 2);                               // BFINAL 0, BTYPE 2 (bits 0,0,1)
+      const u64 hl = (x >> 4) & (x >> 5) & (x >> 6) & (x >> 7);              // HLIT >= 30
+      const u64 hd = (x >> 9) & (x >> 10) & (x >> 11) & (x >> 12);           // HDIST >= 30
+      u32 m32 = (u32)(m & ~hl & ~hd);
+      while (m32) {
+        const u32 o = (u32)__builtin_ctz(m32);
+        m32 &= m32 - 1;
+        const u64 p = bit0 + 32 * k + o;
+        // HCLEN and the code-length code's lengths: 61 bits from o+13 on
+        const u64 f = (x >> (o + 13)) | ((u64)w[k + 2] << (51 - o));
+        const u32 n = (u32)(f & 15) + 4;
+        u64 L = f >> 4;
+        L &= (1ull << (3 * n)) - 1;  // 3n <= 57
+        const u32 sum = (u32)T[L & 4095] + T[(L >> 12) & 4095] + T[(L >> 24) & 4095] + T[(L >> 36) & 4095] +
+                        T[(L >> 48) & 4095];
+        const bool ok = sum == 128 && (i64)p >= (i64)p_min && p + K0B_TAIL_BITS <= p_end && (i64)p > 0;
+        if (ok && nf < 4) {
+          found |= (32 * k + o) << (8 * nf);
+          nf++;
+        }
+      }
+    }
+    if (tbz_ballot(nf != 0) == 0) continue;  // wave-uniform
+    const u32 inc = wave_incl_scan_u32(nf);
+    u32 at = nout + inc - nf;
+    for (u32 j = 0; j < nf; j++, at++)
+      if (at < K0B_SLOTS) slots[at] = bit0 + ((found >> (8 * j)) & 0xffu);
+    nout += tbz_shfl(inc, 63);
+  }
+  if (lane == 0) P.counts[tile] = nout < K0B_SLOTS ? nout : K0B_SLOTS;
+}
+
+// ---- full parse of one surviving candidate (one lane): a lean restatement of :dynamic-huffman-block …
+// :dht-len-table-data (deflate.lisp:577-669) that keeps no code lengths, only their Kraft sums
+struct K0bBits {
+  const u32* w;   // aligned word base
+  u64 wi;         // next word to load
+  u64 nwords;
+  u64 buf;        // LSB-first bit buffer
+  u32 n;          // valid bits in buf
+};
+TBZ_DEV void k0b_need(K0bBits& b, u32 k) {  // k <= 32
+  while (b.n < k) {
+    const u32 v = b.wi < b.nwords ? b.w[b.wi] : 0u;
+    b.buf |= (u64)v << b.n;
+    b.n += 32;
+    b.wi++;
+  }
+}
+TBZ_DEV u32 k0b_take(K0bBits& b, u32 k) {  // k <= 16
+  k0b_need(b, k);
+  const u32 v = (u32)b.buf & ((1u << k) - 1);
+  b.buf >>= k;
+  b.n -= k;
+  return v;
+}
+TBZ_DEV bool k0b_validate_one(const u8* in_base, u64 p, u64 s_lo_bit, u64 p_end, u8 (*tab)[64]) {
+  const u32 lane = tbz_lane();
+  // the block that follows a flush marker is K0's: no duplicates
+  if ((p & 7) == 0 && p >= s_lo_bit + 32) {
+    const u8* q = in_base + (p >> 3) - 4;
+    if (q[0] == 0 && q[1] == 0 && q[2] == 0xff && q[3] == 0xff) return false;
+  }
+  K0bBits b;
+  const uintptr_t a0 = (uintptr_t)in_base;
+  const u32 mis = (u32)(a0 & 3);
+  b.w = (const u32*)(a0 - mis);
+  const u64 a = p + mis * 8;
+  b.nwords = (mis * 8 + p_end + 31) >> 5;
+  b.wi = a >> 5;
+  b.buf = 0;
+  b.n = 0;
+  k0b_need(b, 32);
+  b.buf >>= (a & 31);
+  b.n -= (u32)(a & 31);
+  u64 used = 3 + 14;
+  k0b_take(b, 3);
+  const u32 hlit = k0b_take(b, 5) + 257, hdist = k0b_take(b, 5) + 1, hclen = k0b_take(b, 4) + 4;
+  // code-length code: lengths by symbol, 3 bits each
+  u64 pl = 0;
+  u32 cnt = 0;  // eight 4-bit counters: codes per length 0..7 (a length used 16+ times cannot be complete: 19 symbols)
+  for (u32 i = 0; i < hclen; i++) {
+    const u32 l = k0b_take(b, 3);
+    pl |= (u64)l << (3 * c_cl_order[i]);
+    if (l) cnt += 1u << (4 * l);
+  }
+  used += 3 * hclen;
+  u32 next[8];
+  {
+    u32 code = 0, prev = 0;
+    for (u32 l = 1; l < 8; l++) {
+      code = (code + prev) << 1;
+      prev = (cnt >> (4 * l)) & 15;
+      next[l] = code;
+    }
+  }
+  for (u32 j = 0; j < 128; j++) tab[j][lane] = 0;
+  for (u32 sym = 0; sym < 19; sym++) {
+    const u32 l = (u32)(pl >> (3 * sym)) & 7;
+    if (!l) continue;
+    u32 cd = 0;
+#pragma unroll
+    for (u32 q = 1; q < 8; q++)
+      if (q == l) cd = next[q]++;
+    const u32 rev = tbz_brev32(cd) >> (32 - l);
+    for (u32 j = rev; j < 128; j += 1u << l) tab[j][lane] = (u8)(l | (sym << 3));
+  }
+  const u32 n = hlit + hdist;
+  u32 i = 0, last = 0xff, kl = 0, kd = 0, nl_used = 0, nd_used = 0;
+  bool eob = false;
+  while (i < n) {
+    k0b_need(b, 16);
+    const u32 e = tab[(u32)b.buf & 127][lane];
+    const u32 l = e & 7, sym = e >> 3;
+    if (l == 0) return false;
+    const u32 xb = sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u;
+    const u32 x = ((u32)(b.buf >> l)) & ((1u << xb) - 1);
+    b.buf >>= l + xb;
+    b.n -= l + xb;
+    used += l + xb;
+    u32 rep = 1, val = sym;
+    if (sym == 16) {
+      if (last >= 16) return false;
+      rep = 3 + x;
+      val = last;
+    } else if (sym == 17) {
+      rep = 3 + x;
+      val = 0;
+    } else if (sym == 18) {
+      rep = 11 + x;
+      val = 0;
+    }
+    if (i + rep > n) return false;
+    last = val;
+    if (val) {
+      const u32 nlit = i < hlit ? (hlit - i < rep ? hlit - i : rep) : 0u;
+      const u32 kr = 32768u >> val;
+      kl += nlit * kr;
+      kd += (rep - nlit) * kr;
+      nl_used += nlit;
+      nd_used += rep - nlit;
+      if (i <= 256 && 256 < i + rep) eob = true;
+      if (kl > 32768u || kd > 32768u) return false;  // over-subscribed (huffman-tree.lisp:116-117)
+    }
+    i += rep;
+  }
+  if (p + used > p_end) return false;
+  if (!eob || kl != 32768u) return false;                 // literal/length code: complete, with end-of-block
+  if (kd != 32768u && nd_used > 1) return false;          // distance code: complete, or at most one symbol
+  return true;
+}
+
+TBZ_KERNEL void tbz_k0b_validate(K0bParams P) {
+  TBZ_SHARED u8 tab[128][64];  // per lane: the code-length code's 7-bit lookup table (length | symbol << 3)
+  const u32 lane = tbz_lane(), tile = tbz_block();
+  const u32 s = k0b_find_stream(P, tile);
+  const u64 s_lo_bit = P.str_off[s] * 8, p_end = (P.str_off[s] + P.str_len[s]) * 8;
+  u64* slots = P.slots + (u64)tile * K0B_SLOTS;
+  const u32 count = P.counts[tile];
+  u32 nout = 0;
+  for (u32 j0 = 0; j0 < count; j0 += 64) {  // wave-uniform trip count
+    const u32 j = j0 + lane;
+    u64 p = 0;
+    bool ok = false;
+    if (j < count) {
+      p = slots[j];
+      ok = k0b_validate_one(P.in_base, p, s_lo_bit, p_end, tab);
+    }
+    const u64 okm = tbz_ballot(ok);
+    tbz_sync();  // every lane has read its slot before the compacted ones are written (out index <= j)
+    if (ok) slots[nout + tbz_popc64(okm & ((1ull << lane) - 1))] = p;
+    nout += tbz_popc64(okm);
+    tbz_sync();
+  }
+  if (lane == 0) P.counts[tile] = nout;
+}
+
+// single wave: exclusive scan of the per-tile counts
+TBZ_KERNEL void tbz_k0b_offsets(K0bParams P) {
+  const u32 lane = tbz_lane();
+  u32 carry = 0;
+  for (u32 i = 0; i < P.n_tiles; i += 64) {
+    const u32 v = (i + lane) < P.n_tiles ? P.counts[i + lane] : 0;
+    const u32 inc = wave_incl_scan_u32(v);
+    if ((i + lane) < P.n_tiles) P.offsets[i + lane] = carry + inc - v;
+    carry += tbz_shfl(inc, 63);
+  }
+  if (lane == 0) {
+    P.offsets[P.n_tiles] = carry;
+    P.head[0] = carry;
+  }
+}
+
+// tile slots -> the compact candidate list; workgroup 0 writes the per-stream index
+TBZ_KERNEL void tbz_k0b_compact(K0bParams P) {
+  const u32 lane = tbz_lane(), t = tbz_block();
+  const u32 n = P.counts[t], o = P.offsets[t];
+  for (u32 j = lane; j < n; j += 64) P.cands[o + j] = P.slots[(u64)t * K0B_SLOTS + j];
+  if (t == 0)
+    for (u32 s = lane; s <= P.n_streams; s += 64) {
+      const u32 fc = P.offsets[s < P.n_streams ? P.tile_first[s] : P.n_tiles];
+      P.first_cand[s] = fc;
+      P.first_merged[s] = P.first_marker[s] + fc;
+      if (s == P.n_streams) {
+        P.head_merged[0] = P.first_marker[s] + fc;
+        P.head_merged[1] = 0;
+      }
+    }
+}
+
+// merge by rank: per stream both lists ascend and share no element (tbz_k0b_validate drops the block after a
+// flush marker), so an element's place is its own index plus the number of smaller elements of the other list
+TBZ_KERNEL void tbz_k0b_merge(K0bParams P) {
+  const u32 i = tbz_block() * 64 + tbz_lane();
+  const u32 n_m = P.first_marker[P.n_streams], n_c = P.first_cand[P.n_streams];
+  if (i >= n_m + n_c) return;
+  const bool is_m = i < n_m;
+  const u32 idx = is_m ? i : i - n_m;
+  const u32* first = is_m ? P.first_marker : P.first_cand;
+  u32 lo = 0, hi = P.n_streams;  // stream: first[lo] <= idx < first[hi]
+  while (hi - lo > 1) {
+    const u32 mid = (lo + hi) >> 1;
+    if (first[mid] <= idx) lo = mid; else hi = mid;
+  }
+  const u32 s = lo;
+  const u64 v = is_m ? P.markers[idx] : P.cands[idx];
+  const u64* other = is_m ? P.cands : P.markers;
+  const u32* ofirst = is_m ? P.first_cand : P.first_marker;
+  u32 a = ofirst[s], b = ofirst[s + 1];
+  const u32 a0 = a;
+  while (a < b) {
+    const u32 mid = (a + b) >> 1;
+    if (other[mid] < v) a = mid + 1; else b = mid;
+  }
+  P.merged[P.first_merged[s] + (idx - first[s]) + (a - a0)] = v;
 }
 
 // ================================================================================================
@@ -312,7 +637,6 @@ TBZ_KERNEL void tbz_k0_scan_emit(K0Params P) {
 // Replaces deflate.lisp:518-702 + huffman-tree.lisp:99-218 (same acceptance rules and errors).
 // ================================================================================================
 
-TBZ_CONSTANT u8 c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // token words (u16):
 //   0x00bb                      literal octet
@@ -893,7 +1217,11 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
   u32 cut = 0;  // 2: ran out of input inside a stored block's payload
   int tables = 0;  // 0 none, 1 fixed, 2 dynamic
 
-  if (it.flags & ITEM_HEAD) status = k1_container_header(st, fmt);
+  if (it.flags & ITEM_HEAD) {
+    status = k1_container_header(st, fmt);
+    // the first block may itself be a candidate (K0b): the head item is the container header alone
+    if (status == 0 && !fixup && st.br.pos == st.limit_bit) status = SEG_LANDED;
+  }
 
   while (status == 0) {
     blk_pos = st.br.pos;
@@ -972,8 +1300,8 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
     }
     if (!fixup) {
       if (st.br.pos == st.limit_bit) { status = SEG_LANDED; break; }
-    } else if ((st.br.pos & 7) == 0) {
-      u64 b = st.br.pos >> 3;
+    } else {
+      u64 b = st.br.pos;
       u32 lo = P.first_marker[it.stream];
       const u32 hi0 = P.first_marker[it.stream + 1];
       u32 hi = hi0;
@@ -1641,7 +1969,7 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, T
         // match: head | payload << 16
         tok_put2(to, isM ? (TOK_MATCH | lenx | (dm1 << 16)) : (lenx | (((e2 >> 4) & 0xffu) << 16)));
         const i32 d = (i32)dm1 + 1 - (i32)out;
-        mdef = isM & (d > mdef) ? d : mdef;
+        mdef = (isM & (d > mdef)) ? d : mdef;
         n += (isM | pair) ? 2u : 1u;
         out += isM ? lenx + 3 : (pair ? 2u : 1u);
       }
@@ -1844,8 +2172,8 @@ TBZ_DEV void kg_block_end(GangState& gs, K1State& st, const Item& it, const K1gP
       gs.mode = GM_DONE;
       return;
     }
-  } else if ((gs.P & 7) == 0) {
-    u64 b = gs.P >> 3;
+  } else {
+    u64 b = gs.P;
     u32 lo = P.first_marker[it.stream];
     const u32 hi0 = P.first_marker[it.stream + 1];
     u32 hi = hi0;
@@ -2009,6 +2337,10 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
         gs.mode = GM_DONE;
       }
       gs.P = st.br.pos;
+      if (!e && !fixup && gs.P == st.limit_bit) {  // the first block is itself a candidate (K0b): header only
+        gs.status = SEG_LANDED;
+        gs.mode = GM_DONE;
+      }
     }
   }
 
@@ -2225,6 +2557,11 @@ struct K2Params {
   u32 cls;            // with order == nullptr: 1 = only groups that fit the linear window, 2 = only the others
   CkPartial* gck;     // two-wave kernel: adler32 partial of every group's output, computed from the window while it
   CkChunk* gchunks;   //   is flushed (nullptr: not wanted); gchunks[g].len = octets the group stored
+  // ---- groups decoded against a SYMBOLIC history (ring kernel only; SURVEY §8f-1, see K6 below)
+  u32 hist;           // 1: the 32 KiB before the group's first octet are not in this window: fill them with pointers
+  u32 plane;          // 0: octets (a pointer's low octet where the source is symbolic) -> out_base
+                      // 1: 0 for a known octet, 0x80 | pointer >> 8 for a symbolic one    -> out_base = the mark plane
+  u64 out_bias;       // octet x of the output lives at out_base[x - out_bias] (the mark plane covers the streams' extent only)
 };
 
 // A group whose whole output fits the LDS window needs no ring: LINEAR = true keeps every octet of
@@ -2369,11 +2706,29 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
                      Emit&& emit, Finish&& finish) {
   const u32 lane = tbz_lane();
   const u64 lane_bit = 1ull << lane;
-  u8* outp = P.out_base + g.out_abs;
+  u8* outp = P.out_base + (g.out_abs - P.out_bias);
   const u32 a0 = (u32)((uintptr_t)outp & 15);
   const u64 clip = g.out_end > g.out_abs ? g.out_end - g.out_abs : 0;
   u64 pos = 0, flushed = 0;
   u32 rpos = a0;  // window index of `pos`
+  const u32 litmask = (!LINEAR && P.plane) ? 0u : 0xffu;  // plane 1: every octet this group produces itself is "known" = 0
+  if (!LINEAR && P.hist) {
+    // Symbolic history: octet j before the group's first one (j = 1..32768) is not known here — the group before
+    // is being decoded by another workgroup right now.  It is represented by a 15-bit POINTER i = 32768 - j into
+    // "the 32 KiB before this group", low octet in plane 0, 0x80 | high bits in plane 1; the copies below move
+    // pointers exactly as they move octets (LZ77 resolution does not look at the data), and K6 replaces them.
+    for (u32 i0 = lane * 4; i0 < 32768; i0 += 256) {
+      const u32 r = (a0 + (K2_WIN - 32768) + i0) % K2_WIN;
+      const u32 v = P.plane ? (0x80u | (i0 >> 8)) * 0x01010101u
+                            : ((i0 & 0xff) | (((i0 + 1) & 0xff) << 8) | (((i0 + 2) & 0xff) << 16) | (((i0 + 3) & 0xff) << 24));
+      if (r + 4 <= K2_WIN) {
+        k2_st32(win + r, v);
+      } else {
+        for (u32 q = 0; q < 4; q++) win[(r + q) % K2_WIN] = (u8)(v >> (8 * q));
+      }
+    }
+    tbz_sync();
+  }
 
   for (u32 s = 0; s < g.seg_count && pos < clip; s++) {
     const Seg sg = g.seg_first + s == gi ? sg_guess : P.segs[g.seg_first + s];
@@ -2495,8 +2850,8 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
         const u32 total = tbz_readlane(incl, last);
         const bool act = lane <= last;
         const u32 oa = incl - sum, ob = oa + len_a;
-        if (la && act) win[ring<LINEAR>(rpos + oa)] = (u8)a;
-        if (lb && act) win[ring<LINEAR>(rpos + ob)] = (u8)b;
+        if (la && act) win[ring<LINEAR>(rpos + oa)] = (u8)(a & litmask);
+        if (lb && act) win[ring<LINEAR>(rpos + ob)] = (u8)(b & litmask);
         const u32 na = tbz_wave_shl1(a);  // next lane's word a: the distance word of a head in b
         const bool hasm = (hav || hbv) && act;
         const u32 len = hav ? len_a : len_b;
@@ -2522,7 +2877,7 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
           while (cnt) {
             u32 c = cnt < 4096 ? (u32)cnt : 4096;
             tbz_sync();
-            for (u32 j = lane; j < c; j += 64) win[ring<LINEAR>(rpos + j)] = P.in_base[src + j];
+            for (u32 j = lane; j < c; j += 64) win[ring<LINEAR>(rpos + j)] = (u8)(P.in_base[src + j] & litmask);
             tbz_sync();
             pos += c;
             rpos = ring<LINEAR>(rpos + c);
@@ -2558,7 +2913,7 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
         const u64 act = m == 64 ? ~0ull : ((1ull << m) - 1);
         u32 dofs = incl - len;  // octet offset of this token inside the batch
         u32 dist = (tbz_wave_shl1(w) & 0x7fffu) + 1;
-        if (islit && (act & lane_bit)) win[ring<LINEAR>(rpos + dofs)] = (u8)w;
+        if (islit && (act & lane_bit)) win[ring<LINEAR>(rpos + dofs)] = (u8)(w & litmask);
         emit(mb & act, rpos, dofs, len, dist);
         pos += total;
         rpos = ring<LINEAR>(rpos + total);
@@ -2704,6 +3059,164 @@ TBZ_KERNEL_WG(128, 2) void tbz_k2_lz77_dual(K2Params P) {
         break;
       }
     }
+  }
+}
+
+// ================================================================================================
+// K6 — LZ77 references across groups (replaces the sequential dependency of copy-history on
+// everything before it, deflate.lisp:343-352, for groups decoded in parallel).
+//
+// A group that needs history it does not hold (an "H-group": its matches reach before its first octet, and the
+// groups before it are decoded by other workgroups at the same time) runs through the ring kernel twice — K2's
+// copies are the same whatever the octets are — against a window whose first 32 KiB hold POINTERS (see k2_body):
+//   plane 0 -> out:  the octet, or the low octet of a pointer
+//   plane 1 -> mark: 0, or 0x80 | the pointer's high bits
+// so after K2 every octet of an H-group is either final or "octet i of the 32 KiB before this group".
+//   tbz_k6_window  one workgroup per stream walks its H-groups IN ORDER and resolves each group's last 32 KiB
+//                  (its share of the window of whatever follows) out of a 32 KiB LDS ring of final octets; the
+//                  dependent chain of the whole scheme is this loop: one LDS gather round per group.
+//   tbz_k6_resolve every other symbolic octet of every H-group, all in parallel: its source is final by then.
+// ================================================================================================
+struct HGroup {
+  u64 start;   // absolute output offset (in out_base) of the group's first octet
+  u64 end;     // one past its last STORED octet (clipped at the caller's capacity)
+  u64 floor;   // absolute offset of the stream's first octet (no pointer reaches below it in a valid stream)
+  u32 stream;  // index into the per-stream table of tbz_k6_window
+  u32 pad;
+};
+struct K6Stream {
+  u32 first, count;  // H-groups [first, first+count) of this stream, ascending
+};
+struct K6Params {
+  u8* out_base;
+  u8* mark_base;     // mark plane: octet x of the output has its mark at mark_base[x - bias]
+  u64 bias;
+  const HGroup* hg;
+  const K6Stream* streams;
+  u32 n_hg, n_streams;
+  u32 pieces;        // tbz_k6_resolve: workgroups per H-group (K6_PIECE octets each)
+};
+constexpr u32 K6_THREADS = 1024;
+constexpr u32 K6_PIECE = 4096;
+constexpr u32 K6_W = 32768;
+
+// the 16 octets at absolute offsets [x, x+16) (x 16-aligned in ADDRESS space) with their marks replaced by what the
+// pointers refer to; `src(i)` returns source octet i of the group's window.  Only offsets in [lo, hi) are touched.
+template <class Src>
+TBZ_DEV bool k6_fix16(uint4& o, const uint4 m, u64 x, u64 lo, u64 hi, Src&& src) {
+  u32 ow[4] = {o.x, o.y, o.z, o.w};
+  const u32 mw[4] = {m.x, m.y, m.z, m.w};
+  bool any = false;
+#pragma unroll
+  for (u32 k = 0; k < 4; k++) {
+    if (mw[k] == 0) continue;
+    for (u32 q = 0; q < 4; q++) {
+      const u32 mb = (mw[k] >> (8 * q)) & 0xffu;
+      const u64 pos = x + 4 * k + q;
+      if (mb == 0 || (i64)pos < (i64)lo || (i64)pos >= (i64)hi) continue;
+      const u32 idx = ((mb & 0x7fu) << 8) | ((ow[k] >> (8 * q)) & 0xffu);
+      ow[k] = (ow[k] & ~(0xffu << (8 * q))) | ((u32)src(idx) << (8 * q));
+      any = true;
+    }
+  }
+  o = uint4{ow[0], ow[1], ow[2], ow[3]};
+  return any;
+}
+
+TBZ_KERNEL_WG(1024, 1) void tbz_k6_window(K6Params P) {
+  // final octets: the octet at absolute offset x sits at W[(address of x) & 32767], so that chunks which are 16-octet
+  // aligned in memory are aligned in the ring too
+  TBZ_SHARED __attribute__((aligned(16))) u8 W[K6_W];
+  const u32 tid = tbz_wave() * 64 + tbz_lane();
+  if (tbz_block() >= P.n_streams) return;
+  const K6Stream st = P.streams[tbz_block()];
+  u64 w_lo = 0, w_hi = 0;  // the ring holds the final octets of [w_lo, w_hi)
+  const uintptr_t ob = (uintptr_t)P.out_base;
+  auto R = [&](u64 x) { return (u32)((ob + x) & (K6_W - 1)); };
+  for (u32 gi = 0; gi < st.count; gi++) {
+    const HGroup g = P.hg[st.first + gi];
+    if (g.end <= g.start) continue;
+    // 1. the window [need_lo, g.start): whatever of it the ring does not hold comes from memory, where it is final
+    //    (octets of groups that needed no history, or last-32-KiB octets this loop stored in an earlier step)
+    const u64 need_lo = g.start - g.floor > K6_W ? g.start - K6_W : g.floor;
+    if (!(w_hi == g.start && w_lo <= need_lo)) {
+      const u64 upto = (w_hi == g.start && w_lo < g.start) ? w_lo : g.start;  // contiguous but short: the older part only
+      tbz_device_fence();  // (octets this workgroup stored in earlier steps must come back from L2, not a stale L1 line)
+      tbz_wg_barrier();
+      for (u64 x = need_lo + tid; x < upto; x += K6_THREADS) W[R(x)] = P.out_base[x];
+      w_lo = need_lo;
+      w_hi = g.start;
+    }
+    tbz_wg_barrier();
+    // 2. the group's last 32 KiB: gather first (a destination's ring slot is the slot of the source 32 KiB before it),
+    //    then store.  Threads own 16-octet chunks that are aligned in address space.
+    const u64 t_lo = g.end - g.start > K6_W ? g.end - K6_W : g.start;
+    const u64 c_lo = t_lo - ((ob + t_lo) & 15);  // absolute offset of the first chunk (may start before t_lo, even below 0)
+    uint4 ov[3], mv[3];
+    bool have[3], chg[3];
+#pragma unroll
+    for (u32 k = 0; k < 3; k++) {
+      const u64 x = c_lo + ((u64)tid + (u64)k * K6_THREADS) * 16;
+      have[k] = (i64)x < (i64)g.end;
+      chg[k] = false;
+      if (have[k]) {
+        ov[k] = *(const uint4*)(P.out_base + x);
+        mv[k] = *(const uint4*)(P.mark_base + (x - P.bias));
+        chg[k] = k6_fix16(ov[k], mv[k], x, t_lo, g.end, [&](u32 idx) { return W[R(g.start + idx)]; });
+      }
+    }
+    tbz_wg_barrier();
+#pragma unroll
+    for (u32 k = 0; k < 3; k++) {
+      if (!have[k]) continue;
+      const u64 x = c_lo + ((u64)tid + (u64)k * K6_THREADS) * 16;
+      if ((i64)x >= (i64)t_lo && x + 16 <= g.end) {
+        *(uint4*)(W + R(x)) = ov[k];
+      } else {  // the two ragged chunks at the ends
+        const u32 ow[4] = {ov[k].x, ov[k].y, ov[k].z, ov[k].w};
+        for (u32 q = 0; q < 16; q++) {
+          const u64 pos = x + q;
+          if ((i64)pos >= (i64)t_lo && (i64)pos < (i64)g.end) W[R(pos)] = (u8)(ow[q >> 2] >> (8 * (q & 3)));
+        }
+      }
+      if (chg[k]) {
+        // whole-chunk stores: the octets outside [t_lo, end) are written back unchanged (this kernel is the only
+        // writer while it runs); marks inside the range are cleared so that tbz_k6_resolve leaves them alone
+        *(uint4*)(P.out_base + x) = ov[k];
+        u32 mw[4] = {mv[k].x, mv[k].y, mv[k].z, mv[k].w};
+        for (u32 q = 0; q < 16; q++) {
+          const u64 pos = x + q;
+          if ((i64)pos >= (i64)t_lo && (i64)pos < (i64)g.end) mw[q >> 2] &= ~(0xffu << (8 * (q & 3)));
+        }
+        *(uint4*)(P.mark_base + (x - P.bias)) = uint4{mw[0], mw[1], mw[2], mw[3]};
+      }
+    }
+    w_lo = (g.end - w_lo > K6_W) ? g.end - K6_W : w_lo;
+    w_hi = g.end;
+    tbz_wg_barrier();
+  }
+}
+
+// everything but the last 32 KiB of every H-group: sources are final (tbz_k6_window has run)
+TBZ_KERNEL void tbz_k6_resolve(K6Params P) {
+  const u32 lane = tbz_lane();
+  const u32 hgi = tbz_block() / P.pieces, piece = tbz_block() % P.pieces;
+  if (hgi >= P.n_hg) return;
+  const HGroup g = P.hg[hgi];
+  if (g.end <= g.start || g.end - g.start <= K6_W) return;
+  const u64 r_hi = g.end - K6_W;  // [g.start, r_hi) is this kernel's
+  const uintptr_t ob = (uintptr_t)P.out_base;
+  const u64 c_lo = g.start - ((ob + g.start) & 15);
+  const u64 p_lo = c_lo + (u64)piece * K6_PIECE;
+  if ((i64)p_lo >= (i64)r_hi) return;
+  for (u32 k = lane; k < K6_PIECE / 16; k += 64) {
+    const u64 x = p_lo + (u64)k * 16;
+    if ((i64)x >= (i64)r_hi) break;
+    const uint4 m = *(const uint4*)(P.mark_base + (x - P.bias));
+    if ((m.x | m.y | m.z | m.w) == 0) continue;
+    uint4 o = *(const uint4*)(P.out_base + x);
+    if (k6_fix16(o, m, x, g.start, r_hi, [&](u32 idx) { return P.out_base[g.start - K6_W + idx]; }))
+      *(uint4*)(P.out_base + x) = o;
   }
 }
 

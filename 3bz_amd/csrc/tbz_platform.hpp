@@ -40,6 +40,9 @@ TBZ_DEV void tbz_wg_barrier() {
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// agent-scope release + acquire: this workgroup's stores reach L2 and its L1 lines are dropped, so that octets it
+// stored earlier are read back fresh (tbz_k6_window; cost per use: MI355X_MICROARCH.md, __threadfence row)
+TBZ_DEV void tbz_device_fence() { __threadfence(); }
 TBZ_DEV u32 tbz_block() { return blockIdx.x; }
 TBZ_DEV u32 tbz_nblocks() { return gridDim.x; }
 // Workgroup == one wavefront, and a wave's LDS (and vector-memory) instructions execute in issue order, so
@@ -122,4 +125,6 @@ TBZ_DEV u32 tbz_wave_incl_scan_u32(u32 x) {
 #define TBZ_LAUNCH_DYN_WG(kernel, grid, threads, lds_bytes, stream, ...) \
   hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3(threads), (lds_bytes), (stream), __VA_ARGS__)
 #define TBZ_KERNEL_WG(threads, w) extern "C" __global__ __launch_bounds__(threads, w)
+#define TBZ_LAUNCH_WG(kernel, grid, threads, stream, ...) \
+  hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3(threads), 0, (stream), __VA_ARGS__)
 #endif  // TBZ_PLATFORM_HPP_INCLUDED

@@ -2,8 +2,9 @@
 //
 // Vocabulary (follows the reference's domain, not ML's):
 //   stream   one deflate/zlib/gzip stream = one (decompress-vector …) call of 3bz
-//   marker   a byte position p+4 where input[p..p+4) = 00 00 FF FF, i.e. the byte after an empty
-//            stored block (Z_SYNC_FLUSH / Z_FULL_FLUSH).  Speculative: the pattern may also occur
+//   marker   a candidate block start, as a BIT position: the octet after input[p..p+4) = 00 00 FF FF (an empty
+//            stored block: Z_SYNC_FLUSH / Z_FULL_FLUSH), found by K0; or a bit position where a plausible
+//            dynamic-Huffman block header begins, found by K0b.  Speculative: the patterns also occur
 //            inside compressed data; only a decode that ENDS a block exactly there proves it.
 //   item     one unit of K1 work: "decode blocks starting at this bit until you land on the next
 //            marker / hit the final block / fail"

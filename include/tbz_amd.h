@@ -112,7 +112,7 @@ typedef struct tbz_timings {
   float find_ms;     /* K0b: speculative block-start candidates (part of scan_ms) */
   float resolve_ms;  /* K6: window propagation + marker resolution across LZ77 groups */
   uint32_t k1_gang;  /* K1 flavour of the main launch: 1 = one lane per item, 8/16/32/64 = gang width */
-  uint32_t k2_kinds; /* K2 kernels launched: bit0 tbz_k2_lz77_dual, bit1 tbz_k2_lz77_small, bit2 tbz_k2_lz77 (ring),
+  uint32_t k2_kinds; /* K2 kernels launched: bit0 tbz_k2_lz77_dual, bit1 tbz_k2_lz77_small, bit2 tbz_k2_lz77 [ring],
                         bit3 the ring kernel's second (pointer high octet) plane */
   uint64_t n_candidates; /* block starts proposed by K0b */
   uint64_t n_hgroups;    /* LZ77 groups decoded against a symbolic 32 KiB history (resolved by K6) */

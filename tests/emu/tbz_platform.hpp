@@ -44,14 +44,15 @@ struct uint4 {
 };
 
 namespace tbz_emu {
-// A workgroup = W wavefronts (W = 1 or 2) of 64 lanes = 64*W cooperative fibers on ONE OS thread.  Every
+// A workgroup = W wavefronts (W = 1 .. 16) of 64 lanes = 64*W cooperative fibers on ONE OS thread.  Every
 // wave-level collective (fence / ballot / shuffle) is "yield to the next lane of my wave"; because convergent
 // code makes every lane of a wave execute the same sequence of collectives, one trip round the wave's ring is
-// exactly one barrier.  A WORKGROUP barrier is a trip round the own wave followed by a switch to the other
-// wave until it has reached the same barrier.  Deterministic, and ~100x faster than OS threads on a
+// exactly one barrier.  A WORKGROUP barrier is a trip round the own wave followed by switches to the other
+// waves until each has reached the same barrier.  Deterministic, and ~100x faster than OS threads on a
 // std::barrier.
 constexpr size_t kStack = 512 << 10;
-constexpr int kMaxLanes = 128;
+constexpr int kMaxWaves = 16;
+constexpr int kMaxLanes = 64 * kMaxWaves;
 struct State {
   ucontext_t main_ctx;
   ucontext_t fib[kMaxLanes];
@@ -60,9 +61,9 @@ struct State {
   u64 nbar[kMaxLanes];
   u64 nwg[kMaxLanes];  // workgroup barriers passed, per lane
   int cur = 0;         // running fiber: wave = cur >> 6, lane = cur & 63
-  int wcur[2] = {0, 64};  // fiber to resume when a wave is switched back in
-  u64 wgcount[2] = {0, 0};  // workgroup barriers the wave has arrived at
-  int wdone[2] = {0, 0};
+  int wcur[kMaxWaves] = {};     // fiber to resume when a wave is switched back in
+  u64 wgcount[kMaxWaves] = {};  // workgroup barriers the wave has arrived at
+  int wdone[kMaxWaves] = {};
   int nwaves = 1;
   u32 block = 0, nblocks = 0;
   const std::function<void()>* fn = nullptr;
@@ -131,11 +132,22 @@ inline void barrier() {  // wave-level
 inline void wg_barrier() {
   State& s = st();
   barrier();  // every lane of my wave has arrived
-  const int me = s.cur, w = me >> 6, o = w ^ 1;
+  const int me = s.cur, w = me >> 6;
   s.nwg[me]++;
   if (s.wgcount[w] < s.nwg[me]) s.wgcount[w] = s.nwg[me];
   if (s.nwaves < 2) return;
-  while (s.wgcount[o] < s.nwg[me] && s.wdone[o] < 64) switch_to(me, s.wcur[o]);  // let the other wave catch up
+  for (;;) {  // let every other wave catch up
+    int o = -1;
+    for (int k = 1; k < s.nwaves; k++) {
+      const int c = (w + k) % s.nwaves;
+      if (s.wgcount[c] < s.nwg[me] && s.wdone[c] < 64) {
+        o = c;
+        break;
+      }
+    }
+    if (o < 0) break;
+    switch_to(me, s.wcur[o]);
+  }
 }
 inline void trampoline() {
   State& s = st();
@@ -153,9 +165,15 @@ inline void trampoline() {
       abort();
     }
   int nx = next_alive(me);
-  if (nx < 0) {  // my wave is finished: the other wave, if it still runs, else back to the launcher
-    const int o = (me >> 6) ^ 1;
-    nx = (s.nwaves == 2 && s.wdone[o] < 64) ? s.wcur[o] : kMain;
+  if (nx < 0) {  // my wave is finished: another wave that still runs, else back to the launcher
+    nx = kMain;
+    for (int k = 1; k < s.nwaves; k++) {
+      const int o = ((me >> 6) + k) % s.nwaves;
+      if (s.wdone[o] < 64) {
+        nx = s.wcur[o];
+        break;
+      }
+    }
   }
   if (nx != kMain) {
     s.cur = nx;
@@ -170,7 +188,7 @@ inline void trampoline() {
 #endif
   setcontext(nx == kMain ? &s.main_ctx : &s.fib[nx]);
 }
-// run kernel body `fn` for `grid` workgroups of `threads` (64 or 128) lanes, one workgroup after another
+// run kernel body `fn` for `grid` workgroups of `threads` (a multiple of 64, up to 1024) lanes, one workgroup after another
 inline void launch(u32 grid, const std::function<void()>& fn, int threads = 64) {
   if (grid == 0) return;
   State& s = st();
@@ -193,7 +211,7 @@ inline void launch(u32 grid, const std::function<void()>& fn, int threads = 64) 
   s.nwaves = threads / 64;
   for (u32 b = 0; b < grid; b++) {
     s.block = b;
-    for (int w = 0; w < 2; w++) {
+    for (int w = 0; w < kMaxWaves; w++) {
       s.wcur[w] = w * 64;
       s.wgcount[w] = 0;
       s.wdone[w] = w < s.nwaves ? 0 : 64;
@@ -226,6 +244,7 @@ inline u64 xchg(u64 v, u32 src) {  // value of lane `src` of MY wave
 TBZ_DEV u32 tbz_lane() { return (u32)tbz_emu::st().cur & 63; }
 TBZ_DEV u32 tbz_wave() { return (u32)tbz_emu::st().cur >> 6; }
 TBZ_DEV void tbz_wg_barrier() { tbz_emu::wg_barrier(); }
+TBZ_DEV void tbz_device_fence() {}
 TBZ_DEV u32 tbz_block() { return tbz_emu::st().block; }
 TBZ_DEV u32 tbz_nblocks() { return tbz_emu::st().nblocks; }
 TBZ_DEV void tbz_sync() { tbz_emu::barrier(); }
@@ -330,6 +349,8 @@ TBZ_DEV u32 tbz_wave_incl_scan_u32(u32 v) {
 #define TBZ_LAUNCH_DYN_WG(kernel, grid, threads, lds_bytes, stream, ...) \
   tbz_emu::launch((u32)(grid), [&] { kernel(__VA_ARGS__); }, (int)(threads))
 #define TBZ_KERNEL_WG(threads, w) static
+#define TBZ_LAUNCH_WG(kernel, grid, threads, stream, ...) \
+  tbz_emu::launch((u32)(grid), [&] { kernel(__VA_ARGS__); }, (int)(threads))
 
 // ---- the sliver of the HIP runtime the engine uses ----------------------------------------------
 typedef int hipError_t;

@@ -175,6 +175,39 @@ def case_flush_streams(eng, n=96 << 10):
     assert_same(eng, s, "zlib", len(p), what="1000-octet flush blocks")
 
 
+def case_noflush_streams(eng, n=200_000):
+    """ordinary zlib / gzip / deflate streams — no flush markers anywhere.  The block-start finder
+    (K0b) splits them at dynamic-block headers, the LZ77 groups run against symbolic history and K6 resolves the
+    references across them; results are the oracle's, for every capacity and cut."""
+    p = K.enwik_like(n, 0x3B7)
+    for level in (1, 6, 9):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        raw = c.compress(p) + c.flush()
+        assert_same(eng, raw, "deflate", n, what="no-flush deflate level %d" % level)
+        assert_same(eng, zlib.compress(p, level), "zlib", n, what="no-flush zlib level %d" % level)
+    s = zlib.compress(p, 6)
+    out = bytearray(n)
+    res = eng.inflate(s, 1, out)
+    t = eng.timings()
+    assert res.status == 0 and bytes(out) == p and res.adler32 == zlib.adler32(p)
+    assert t.n_candidates >= 2 and t.n_groups >= 3 and t.n_hgroups >= 2, (t.n_candidates, t.n_groups, t.n_hgroups)
+    assert_same(eng, pygzip.compress(p, 6, mtime=0), "gzip", n, what="no-flush gzip")
+    # capacities that end inside an H-group, inside its last 32 KiB, at a group seam ...
+    for cap in (n - 1, n // 2, 100_000, 70_001, 33_000, 1):
+        assert_same(eng, s, "zlib", cap, what="no-flush zlib, capacity %d" % cap)
+    for cut in (len(s) - 1, len(s) - 4, len(s) // 2, len(s) // 3, 3000):
+        assert_same(eng, s[:cut], "zlib", n, what="no-flush zlib cut at %d" % cut)
+    # Z_SYNC_FLUSH every 4 KiB: small segments that all reach back -> merged into H-groups
+    s2, p2, _ = K.zlib_flush_stream(n // 2, block=4096, flush=zlib.Z_SYNC_FLUSH)
+    assert_same(eng, s2, "zlib", len(p2), what="sync flush every 4 KiB")
+    assert_same(eng, s2, "zlib", len(p2) // 3, what="sync flush every 4 KiB, small buffer")
+    # long-lived references: a 20 KiB page repeated (every copy reaches back ~20 KiB, pointers of pointers)
+    page = K.xorshift64star_bytes(20_000, 77)
+    rep = page * (n // 20_000)
+    assert_same(eng, zlib.compress(rep, 6), "zlib", len(rep), what="repeated page")
+    assert_same(eng, zlib.compress(bytes(n), 6), "zlib", n, what="zeros (distance-1 runs across every group)")
+
+
 def case_history_across_groups(eng):
     """Z_SYNC_FLUSH stream whose middle segment copies nothing from before itself (incompressible octets: it opens a
     LZ77 group of its own) while the segment after it copies from the FIRST one, i.e. from before its predecessor's
@@ -685,12 +718,12 @@ def case_pointer_contexts(eng, n=60_000):
 
 
 ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,
-             case_history_across_groups,
+             case_noflush_streams, case_history_across_groups,
              case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_device_buffers,
              case_checksum_kernels, case_deep_codes, case_chunked_resume, case_gzip_members,
              case_pointer_contexts, case_container_headers, case_fuzz]
 # the cases whose behaviour depends on the K1 flavour (forced-flavour runs skip the rest: checksums, device
 # buffers and the replay protocol go through the same engine calls whatever decodes the Huffman codes)
 K1_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,
-            case_history_across_groups,
+            case_noflush_streams, case_history_across_groups,
             case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_deep_codes, case_fuzz]

@@ -15,13 +15,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 
 
-@pytest.fixture(scope="module", params=["auto", "hostlayout", "k2single", "gang8", "gang16", "lane"])
+@pytest.fixture(scope="module", params=["auto", "findalways", "hostlayout", "k2single", "gang8", "gang16", "lane"])
 def eng(request):
     """the three K1 flavours (TBZ_K1_MODE is read when a context is created)"""
     subprocess.check_call(["make", "-C", EMU_DIR, "libtbz_emu.so"], stdout=subprocess.DEVNULL)
     T = importlib.import_module("3bz_amd")
     if request.param == "hostlayout":  # chain walk + layout on the host even when the device could do it (K3)
         os.environ["TBZ_HOST_LAYOUT"] = "1"
+    elif request.param == "findalways":  # K0b block-start finder on every stream, however small (default: large items only)
+        os.environ["TBZ_FIND"] = "always"
     elif request.param == "k2single":  # one wave per group in K2 (default: front end and resolve on two waves)
         os.environ["TBZ_K2_MODE"] = "single"
     elif request.param != "auto":
@@ -30,13 +32,14 @@ def eng(request):
     os.environ.pop("TBZ_K1_MODE", None)
     os.environ.pop("TBZ_HOST_LAYOUT", None)
     os.environ.pop("TBZ_K2_MODE", None)
+    os.environ.pop("TBZ_FIND", None)
     yield e
     e.close()
 
 
 @pytest.mark.parametrize("case", P.ALL_CASES, ids=lambda c: c.__name__)
 def test_emu_case(eng, case, request):
-    forced = request.node.callspec.params["eng"] not in ("auto", "hostlayout", "k2single")
+    forced = request.node.callspec.params["eng"] not in ("auto", "findalways", "hostlayout", "k2single")
     if forced and case not in P.K1_CASES:
         pytest.skip("does not depend on the K1 flavour")
     if request.node.callspec.params["eng"] == "k2single" and case in (P.case_chunked_resume, P.case_gzip_members, P.case_pointer_contexts,

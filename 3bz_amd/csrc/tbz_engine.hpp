@@ -974,30 +974,19 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     // run with dynamic LDS sized to the largest of them; the rest take the 32 KiB-history ring kernel;
     // H-groups take the ring kernel twice (octet plane, pointer plane) and K6 afterwards
     std::vector<uint32_t> order_small, order_big, order_h;
-    std::vector<HGroup> hgs;
-    std::vector<K6Stream> k6s;
-    uint64_t max_small = 0, mark_lo = ~0ull, mark_hi = 0, max_h = 0;
+    struct HG { uint64_t start, end, floor; uint32_t stream; };
+    std::vector<HG> hgs;
+    uint64_t max_small = 0, mark_lo = ~0ull, mark_hi = 0;
     for (size_t gi = 0; gi < h_groups.size(); gi++) {
       uint64_t tot = 0;
       for (uint32_t k = 0; k < h_groups[gi].seg_count; k++) tot += h_segs[h_groups[gi].seg_first + k].out_bytes;
       if (h_hist[gi]) {
         const StreamPlan& S = sp[h_gstream[gi]];
         order_h.push_back((uint32_t)gi);
-        HGroup hg;
-        hg.start = h_groups[gi].out_abs;
-        hg.end = std::min(hg.start + tot, h_groups[gi].out_end);
-        hg.floor = S.out_off;
-        hg.pad = 0;
-        if (k6s.empty() || h_gstream[gi] != last_h_stream) {
-          k6s.push_back(K6Stream{(u32)hgs.size(), 0});
-          last_h_stream = h_gstream[gi];
-        }
-        hg.stream = (u32)k6s.size() - 1;
-        k6s.back().count++;
-        hgs.push_back(hg);
+        hgs.push_back(HG{h_groups[gi].out_abs, std::min(h_groups[gi].out_abs + tot, h_groups[gi].out_end), S.out_off,
+                         h_gstream[gi]});
         mark_lo = std::min(mark_lo, S.out_off);
         mark_hi = std::max(mark_hi, h_groups[gi].out_end);
-        max_h = std::max(max_h, hg.end - hg.start);
       } else if (tot + K2_SLACK <= K2_SMALL_MAX) {
         order_small.push_back((uint32_t)gi);
         max_small = std::max(max_small, tot);
@@ -1030,11 +1019,59 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       TBZ_LAUNCH(tbz_k2_lz77, order_big.size(), ctx->stream, k2);
     }
     if (!order_h.empty()) {
+      // ---- K6 work lists (see tbz_kernels.hpp): blocks = runs of consecutive H-groups of one stream, at most `bmax` long
+      size_t max_per_stream = 0;
+      for (size_t i = 0, j; i < hgs.size(); i = j) {
+        for (j = i; j < hgs.size() && hgs[j].stream == hgs[i].stream; j++) {}
+        max_per_stream = std::max(max_per_stream, j - i);
+      }
+      size_t bmax = 1;
+      while (bmax * bmax < max_per_stream) bmax++;
+      if (const char* m = getenv("TBZ_K6_BLOCK")) bmax = std::max(1, atoi(m));
+      std::vector<K6Range> ranges;
+      std::vector<K6List> lists;
+      // section 1: tails of the groups of multi-group blocks (tbz_k6_chain_sym); section 2: one range per block, one
+      // list per stream (tbz_k6_chain); sections 3a / 3b: tbz_k6_resolve
+      std::vector<K6Range> r1, r2, r3a, r3b;
+      std::vector<K6List> l1, l2;
+      for (size_t i = 0, j; i < hgs.size(); i = j) {
+        K6List ls{(u32)r2.size(), 0};
+        for (j = i; j < hgs.size() && hgs[j].stream == hgs[i].stream;) {
+          size_t e = j + 1;  // block [j, e)
+          while (e < hgs.size() && e - j < bmax && hgs[e].stream == hgs[j].stream && hgs[e].start == hgs[e - 1].end) e++;
+          const uint64_t B0 = hgs[j].start, E = hgs[e - 1].end, fl = hgs[j].floor;
+          const uint64_t last_lo = E - B0 > K6_W ? E - K6_W : B0;
+          if (e - j > 1) {
+            l1.push_back(K6List{(u32)r1.size(), (u32)(e - j)});
+            for (size_t k = j; k < e; k++) {
+              const uint64_t t_lo = hgs[k].end - hgs[k].start > K6_W ? hgs[k].end - K6_W : hgs[k].start;
+              r1.push_back(K6Range{hgs[k].start, t_lo, hgs[k].end, fl});
+              if (t_lo < std::min(hgs[k].end, last_lo)) r3a.push_back(K6Range{B0, t_lo, std::min(hgs[k].end, last_lo), fl});
+            }
+          }
+          r2.push_back(K6Range{B0, last_lo, E, fl});
+          ls.count++;
+          for (size_t k = j; k < e; k++)  // a group's octets before its tail, in sub-ranges of at most 64 KiB
+            if (hgs[k].end - hgs[k].start > K6_W)
+              for (uint64_t x = hgs[k].start; x < hgs[k].end - K6_W; x += 65536)
+                r3b.push_back(K6Range{hgs[k].start, x, std::min(x + 65536, hgs[k].end - K6_W), fl});
+          j = e;
+        }
+        l2.push_back(ls);
+      }
+      for (auto& l : l2) l.first += (u32)r1.size();
+      const size_t o2 = r1.size(), o3a = o2 + r2.size(), o3b = o3a + r3a.size();
+      ranges = r1;
+      ranges.insert(ranges.end(), r2.begin(), r2.end());
+      ranges.insert(ranges.end(), r3a.begin(), r3a.end());
+      ranges.insert(ranges.end(), r3b.begin(), r3b.end());
+      lists = l1;
+      lists.insert(lists.end(), l2.begin(), l2.end());
       // the mark plane covers [mark_lo, mark_hi) of the output, at the same alignment (mod 16) as the output itself
       const uint32_t m0 = (uint32_t)(((uintptr_t)d_out + mark_lo) & 15);
       if ((r = ensure(ctx, ctx->d_mark, (mark_hi - mark_lo) + 64))) return r;
-      if ((r = upload(ctx, ctx->d_hg, hgs))) return r;
-      if ((r = upload(ctx, ctx->d_k6s, k6s))) return r;
+      if ((r = upload(ctx, ctx->d_hg, ranges))) return r;
+      if ((r = upload(ctx, ctx->d_k6s, lists))) return r;
       k2.order = (const u32*)ctx->d_order.p + order_small.size() + order_big.size();
       k2.n_groups = (u32)order_h.size();
       k2.win_bytes = 0;
@@ -1047,13 +1084,26 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       k2.out_bias = mark_lo;
       TBZ_LAUNCH(tbz_k2_lz77, order_h.size(), ctx->stream, k2);
       TBZ_HIP(hipEventRecord(ctx->ev[10], ctx->stream));
-      K6Params k6{(u8*)d_out, (u8*)ctx->d_mark.p + m0, mark_lo, (const HGroup*)ctx->d_hg.p, (const K6Stream*)ctx->d_k6s.p,
-                  (u32)hgs.size(), (u32)k6s.size(), 0};
-      TBZ_LAUNCH_WG(tbz_k6_window, k6s.size(), K6_THREADS, ctx->stream, k6);
-      if (max_h > K6_W) {
-        k6.pieces = (u32)((max_h - K6_W + 15 + K6_PIECE - 1) / K6_PIECE);
-        TBZ_LAUNCH(tbz_k6_resolve, (size_t)hgs.size() * k6.pieces, ctx->stream, k6);
+      const K6Range* dr = (const K6Range*)ctx->d_hg.p;
+      const K6List* dl = (const K6List*)ctx->d_k6s.p;
+      K6Params k6{(u8*)d_out, (u8*)ctx->d_mark.p + m0, mark_lo, dr, dl, (u32)ranges.size(), 0, 0};
+      if (!l1.empty()) {
+        k6.n_lists = (u32)l1.size();
+        TBZ_LAUNCH_WG(tbz_k6_chain_sym, l1.size(), K6_THREADS, ctx->stream, k6);
       }
+      k6.lists = dl + l1.size();
+      k6.n_lists = (u32)l2.size();
+      TBZ_LAUNCH_WG(tbz_k6_chain, l2.size(), K6_THREADS, ctx->stream, k6);
+      auto resolve = [&](size_t first, size_t count, uint64_t maxlen) {
+        if (!count) return;
+        K6Params q = k6;
+        q.ranges = dr + first;
+        q.n_ranges = (u32)count;
+        q.pieces = (u32)((maxlen + 15 + K6_PIECE - 1) / K6_PIECE);
+        TBZ_LAUNCH(tbz_k6_resolve, count * (size_t)q.pieces, ctx->stream, q);
+      };
+      resolve(o3a, r3a.size(), K6_W);
+      resolve(o3b, r3b.size(), 65536);
       TBZ_HIP(hipEventRecord(ctx->ev[11], ctx->stream));
       have_resolve = true;
     }

@@ -412,18 +412,28 @@ TBZ_KERNEL void tbz_k0b_scan(K0bParams P) {
 // ---- full parse of one surviving candidate (one lane): a lean restatement of :dynamic-huffman-block …
 // :dht-len-table-data (deflate.lisp:577-669) that keeps no code lengths, only their Kraft sums
 struct K0bBits {
-  const u32* w;   // aligned word base
-  u64 wi;         // next word to load
+  const u32* w;   // word base, 16-octet aligned
+  u64 wi;         // next word to hand out
   u64 nwords;
   u64 buf;        // LSB-first bit buffer
   u32 n;          // valid bits in buf
+  uint4 q;        // the aligned four words that hold word wi (fetched 16 octets at a time: a header is a serial
+  u64 qi;         //   read of 60-150 octets, and every fetch is a memory round trip for the whole wave)
 };
+TBZ_DEV u32 k0b_word(K0bBits& b) {
+  const u64 i = b.wi++;
+  if ((i & ~3ull) != b.qi) {
+    b.qi = i & ~3ull;
+    b.q = b.qi < b.nwords ? *(const uint4*)(b.w + b.qi) : uint4{};  // (an aligned 16-octet chunk that holds a stream octet is mapped)
+  }
+  const u32 k = (u32)(i & 3);
+  const u32 v = k == 0 ? b.q.x : k == 1 ? b.q.y : k == 2 ? b.q.z : b.q.w;
+  return i < b.nwords ? v : 0u;
+}
 TBZ_DEV void k0b_need(K0bBits& b, u32 k) {  // k <= 32
   while (b.n < k) {
-    const u32 v = b.wi < b.nwords ? b.w[b.wi] : 0u;
-    b.buf |= (u64)v << b.n;
+    b.buf |= (u64)k0b_word(b) << b.n;
     b.n += 32;
-    b.wi++;
   }
 }
 TBZ_DEV u32 k0b_take(K0bBits& b, u32 k) {  // k <= 16
@@ -442,11 +452,13 @@ TBZ_DEV bool k0b_validate_one(const u8* in_base, u64 p, u64 s_lo_bit, u64 p_end,
   }
   K0bBits b;
   const uintptr_t a0 = (uintptr_t)in_base;
-  const u32 mis = (u32)(a0 & 3);
+  const u32 mis = (u32)(a0 & 15);
   b.w = (const u32*)(a0 - mis);
   const u64 a = p + mis * 8;
   b.nwords = (mis * 8 + p_end + 31) >> 5;
   b.wi = a >> 5;
+  b.qi = ~0ull;
+  b.q = uint4{};
   b.buf = 0;
   b.n = 0;
   k0b_need(b, 32);
@@ -2532,7 +2544,8 @@ TBZ_K1G_KERNEL(64)
 // (deflate.lisp:233-359, :538-573).
 // ================================================================================================
 constexpr u32 ADLER_P = 65521;
-constexpr u32 K2_WIN = 36864;   // 32 KiB history + one batch span + slack; multiple of 16
+constexpr u32 K2_WIN = 36096;   // 32 KiB history + one batch span + 256 of slack; multiple of 16 (38.7 KB of LDS with the
+                                // token ring: four workgroups per CU)
 constexpr u32 K2_SPAN = 3072;   // max octets one batch may produce (cut otherwise)
 constexpr u32 K2_FLUSH = 8192;  // flush the ring to HBM every this many octets
 constexpr u32 K2_SHORT = 32;    // matches up to this length are copied by their own lane
@@ -2875,7 +2888,7 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
           u64 cnt = (w0 & 0x3fff) | ((u64)(w1 & 3) << 14);
           u64 src = ((u64)(w1 >> 2) & 0x1fff) | ((u64)w2 << 13) | ((u64)w3 << 28);
           while (cnt) {
-            u32 c = cnt < 4096 ? (u32)cnt : 4096;
+            u32 c = cnt < K2_SPAN ? (u32)cnt : K2_SPAN;  // (the ring holds 32 KiB of history + one span)
             tbz_sync();
             for (u32 j = lane; j < c; j += 64) win[ring<LINEAR>(rpos + j)] = (u8)(P.in_base[src + j] & litmask);
             tbz_sync();
@@ -3071,152 +3084,266 @@ TBZ_KERNEL_WG(128, 2) void tbz_k2_lz77_dual(K2Params P) {
 // copies are the same whatever the octets are — against a window whose first 32 KiB hold POINTERS (see k2_body):
 //   plane 0 -> out:  the octet, or the low octet of a pointer
 //   plane 1 -> mark: 0, or 0x80 | the pointer's high bits
-// so after K2 every octet of an H-group is either final or "octet i of the 32 KiB before this group".
-//   tbz_k6_window  one workgroup per stream walks its H-groups IN ORDER and resolves each group's last 32 KiB
-//                  (its share of the window of whatever follows) out of a 32 KiB LDS ring of final octets; the
-//                  dependent chain of the whole scheme is this loop: one LDS gather round per group.
-//   tbz_k6_resolve every other symbolic octet of every H-group, all in parallel: its source is final by then.
+// so after K2 every octet of an H-group is either final or "octet i of the 32 KiB before this group".  What later
+// groups can see of a group is its last 32 KiB (its TAIL), so the dependent chain runs over tails only:
+//   1. tbz_k6_chain_sym   blocks of consecutive H-groups, all blocks in parallel: one workgroup walks its block's
+//                         tails in order through a 32 KiB ring of SYMBOLS and rewrites them relative to the 32 KiB
+//                         before the BLOCK (pointers of pointers collapse);
+//   2. tbz_k6_chain       one workgroup per stream walks the blocks in order and makes each block's last 32 KiB
+//                         final out of a ring of final octets;
+//   3. tbz_k6_resolve     everything else in parallel, its sources being final by then: first the other tail octets
+//                         (relative to their block), then every H-group's octets before its tail (relative to itself).
+// The chain is (groups per block) + (blocks per stream) steps instead of one step per group; a step is one LDS gather
+// round, two workgroup barriers and the stores.
 // ================================================================================================
-struct HGroup {
-  u64 start;   // absolute output offset (in out_base) of the group's first octet
-  u64 end;     // one past its last STORED octet (clipped at the caller's capacity)
-  u64 floor;   // absolute offset of the stream's first octet (no pointer reaches below it in a valid stream)
-  u32 stream;  // index into the per-stream table of tbz_k6_window
-  u32 pad;
+struct K6Range {   // the symbolic octets of [lo, hi): pointer i stands for the octet at absolute offset base - 32768 + i
+  u64 base, lo, hi;
+  u64 floor;       // the stream's first octet (no pointer reaches below it in a valid stream)
 };
-struct K6Stream {
-  u32 first, count;  // H-groups [first, first+count) of this stream, ascending
+struct K6List {
+  u32 first, count;  // ranges [first, first+count), walked in order by one workgroup
 };
 struct K6Params {
   u8* out_base;
   u8* mark_base;     // mark plane: octet x of the output has its mark at mark_base[x - bias]
   u64 bias;
-  const HGroup* hg;
-  const K6Stream* streams;
-  u32 n_hg, n_streams;
-  u32 pieces;        // tbz_k6_resolve: workgroups per H-group (K6_PIECE octets each)
+  const K6Range* ranges;
+  const K6List* lists;
+  u32 n_ranges, n_lists;
+  u32 pieces;        // tbz_k6_resolve: workgroups per range (K6_PIECE octets each)
 };
 constexpr u32 K6_THREADS = 1024;
 constexpr u32 K6_PIECE = 4096;
 constexpr u32 K6_W = 32768;
 
-// the 16 octets at absolute offsets [x, x+16) (x 16-aligned in ADDRESS space) with their marks replaced by what the
-// pointers refer to; `src(i)` returns source octet i of the group's window.  Only offsets in [lo, hi) are touched.
-template <class Src>
-TBZ_DEV bool k6_fix16(uint4& o, const uint4 m, u64 x, u64 lo, u64 hi, Src&& src) {
-  u32 ow[4] = {o.x, o.y, o.z, o.w};
-  const u32 mw[4] = {m.x, m.y, m.z, m.w};
-  bool any = false;
+// per-octet masks over a dword: 0xff where the mark octet says "symbolic" (bit 7), and where the octet's absolute
+// offset x + k lies inside [lo, hi)
+TBZ_DEV u32 k6_marked(u32 mw) { return ((mw >> 7) & 0x01010101u) * 0xffu; }
+TBZ_DEV u32 k6_inrange(u64 x, u64 lo, u64 hi) {
+  u32 r = 0;
+#pragma unroll
+  for (u32 k = 0; k < 4; k++) r |= ((i64)(x + k) >= (i64)lo && (i64)(x + k) < (i64)hi) ? 0xffu << (8 * k) : 0u;
+  return r;
+}
+// One thread's chunk: the 16 octets at absolute offsets [x, x+16) (x 16-aligned in ADDRESS space), planes o / m.
+// Every symbolic octet (inside [lo, hi) unless WHOLE says the chunk lies inside anyway) is replaced by what its
+// pointer refers to: src(i, a, b) yields the source's two planes.  All sixteen lookups go out together, symbolic or
+// not, and the result is merged in with masks: straight-line code.  Returns whether anything was replaced.
+template <bool WHOLE, class Src>
+TBZ_DEV bool k6_fix16(uint4& o, uint4& m, u64 x, u64 lo, u64 hi, Src&& src) {
+  if ((m.x | m.y | m.z | m.w) == 0) return false;
+  u32 ow[4] = {o.x, o.y, o.z, o.w}, mw[4] = {m.x, m.y, m.z, m.w};
+  u32 n0[4] = {0, 0, 0, 0}, n1[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (u32 q = 0; q < 16; q++) {
+    const u32 sh = 8 * (q & 3);
+    const u32 mb = tbz_bfe(mw[q >> 2], sh, 7), ob = tbz_bfe(ow[q >> 2], sh, 8);
+    u32 a, b;
+    src((mb << 8) | ob, a, b);
+    n0[q >> 2] |= a << sh;
+    n1[q >> 2] |= b << sh;
+  }
+  u32 any = 0;
 #pragma unroll
   for (u32 k = 0; k < 4; k++) {
-    if (mw[k] == 0) continue;
-    for (u32 q = 0; q < 4; q++) {
-      const u32 mb = (mw[k] >> (8 * q)) & 0xffu;
-      const u64 pos = x + 4 * k + q;
-      if (mb == 0 || (i64)pos < (i64)lo || (i64)pos >= (i64)hi) continue;
-      const u32 idx = ((mb & 0x7fu) << 8) | ((ow[k] >> (8 * q)) & 0xffu);
-      ow[k] = (ow[k] & ~(0xffu << (8 * q))) | ((u32)src(idx) << (8 * q));
-      any = true;
-    }
+    u32 bm = k6_marked(mw[k]);
+    if (!WHOLE) bm &= k6_inrange(x + 4 * k, lo, hi);
+    ow[k] = (ow[k] & ~bm) | (n0[k] & bm);
+    mw[k] = (mw[k] & ~bm) | (n1[k] & bm);
+    any |= bm;
   }
   o = uint4{ow[0], ow[1], ow[2], ow[3]};
-  return any;
+  m = uint4{mw[0], mw[1], mw[2], mw[3]};
+  return any != 0;
 }
 
-TBZ_KERNEL_WG(1024, 1) void tbz_k6_window(K6Params P) {
-  // final octets: the octet at absolute offset x sits at W[(address of x) & 32767], so that chunks which are 16-octet
-  // aligned in memory are aligned in the ring too
-  TBZ_SHARED __attribute__((aligned(16))) u8 W[K6_W];
+struct K6R {  // a K6Range in wave-uniform registers
+  u64 base, lo, hi, floor;
+};
+TBZ_DEV K6R k6_range(const K6Params& P, u32 i) {
+  const u64* q = (const u64*)(P.ranges + i);
+  K6R r;
+  r.base = tbz_uniform64(q[0]);
+  r.lo = tbz_uniform64(q[1]);
+  r.hi = tbz_uniform64(q[2]);
+  r.floor = tbz_uniform64(q[3]);
+  return r;
+}
+
+// SYM = false: the ring holds FINAL octets; every range comes out final (marks cleared).
+// SYM = true:  the ring holds SYMBOLS relative to the list's first base B0 (ring octets of [B0-32768, B0) start out as
+//              the identity pointers); ranges come out relative to B0.  The ranges of a list are then the tails of
+//              CONSECUTIVE groups (range r+1's base is range r's hi), which the host guarantees.
+// A range is at most 32 KiB (+ alignment): two 16-octet chunks per thread, and a third for thread 0.
+template <bool SYM>
+TBZ_DEV void k6_chain(const K6Params& P, u8* W0, u8* W1) {
   const u32 tid = tbz_wave() * 64 + tbz_lane();
-  if (tbz_block() >= P.n_streams) return;
-  const K6Stream st = P.streams[tbz_block()];
-  u64 w_lo = 0, w_hi = 0;  // the ring holds the final octets of [w_lo, w_hi)
+  if (tbz_block() >= P.n_lists) return;
+  const u32 first = tbz_uniform(P.lists[tbz_block()].first), count = tbz_uniform(P.lists[tbz_block()].count);
+  if (count == 0) return;
   const uintptr_t ob = (uintptr_t)P.out_base;
-  auto R = [&](u64 x) { return (u32)((ob + x) & (K6_W - 1)); };
-  for (u32 gi = 0; gi < st.count; gi++) {
-    const HGroup g = P.hg[st.first + gi];
-    if (g.end <= g.start) continue;
-    // 1. the window [need_lo, g.start): whatever of it the ring does not hold comes from memory, where it is final
-    //    (octets of groups that needed no history, or last-32-KiB octets this loop stored in an earlier step)
-    const u64 need_lo = g.start - g.floor > K6_W ? g.start - K6_W : g.floor;
-    if (!(w_hi == g.start && w_lo <= need_lo)) {
-      const u64 upto = (w_hi == g.start && w_lo < g.start) ? w_lo : g.start;  // contiguous but short: the older part only
-      tbz_device_fence();  // (octets this workgroup stored in earlier steps must come back from L2, not a stale L1 line)
+  // the octet at absolute offset x sits at ring index (address of x) & 32767: chunks that are 16-octet aligned in
+  // memory are aligned in the ring too
+  u64 w_lo = 0, w_hi = 0;  // the ring holds [w_lo, w_hi)
+  K6R g = k6_range(P, first);
+  if (SYM) {
+    const u64 B0 = g.base;
+    for (u32 i = tid * 4; i < K6_W; i += K6_THREADS * 4) {
+      const u64 x = B0 - K6_W + i;
+#pragma unroll
+      for (u32 q = 0; q < 4; q++) {
+        const u32 r = (u32)((ob + x + q) & (K6_W - 1));
+        W0[r] = (u8)(i + q);
+        W1[r] = (u8)(0x80u | ((i + q) >> 8));
+      }
+    }
+    w_lo = B0 - K6_W;
+    w_hi = B0;
+  }
+  // a range's planes do not depend on the chain (K2 wrote them): they are fetched one step ahead — and its record two
+  // steps ahead — so that a step is LDS gathers, two barriers and the stores
+  uint4 o0{}, o1{}, o2{}, m0{}, m1{}, m2{};
+  auto chunk_x = [&](const K6R& r, u32 k) { return (r.lo - ((ob + r.lo) & 15)) + ((u64)tid + (u64)k * K6_THREADS) * 16; };
+  auto fetch = [&](const K6R& r, u32 k, uint4& o, uint4& m) {
+    const u64 x = chunk_x(r, k);
+    if (r.hi > r.lo && (i64)x < (i64)r.hi) {
+      o = *(const uint4*)(P.out_base + x);
+      m = *(const uint4*)(P.mark_base + (x - P.bias));
+    }
+  };
+  fetch(g, 0, o0, m0);
+  fetch(g, 1, o1, m1);
+  if (tid == 0) fetch(g, 2, o2, m2);
+  K6R gn = count > 1 ? k6_range(P, first + 1) : g;
+  for (u32 gi = 0; gi < count; gi++) {
+    const K6R gnn = gi + 2 < count ? k6_range(P, first + gi + 2) : gn;
+    uint4 p0{}, p1{}, p2{}, q0{}, q1{}, q2{};
+    if (gi + 1 < count) {
+      fetch(gn, 0, p0, q0);
+      fetch(gn, 1, p1, q1);
+      if (tid == 0) fetch(gn, 2, p2, q2);
+    }
+    if (g.hi > g.lo) {
+      // 1. the window [need_lo, base): whatever of it the ring does not hold comes from memory, where it is final
+      //    (octets of groups that needed no history, or octets this loop stored in an earlier step)
+      if (!SYM) {
+        const u64 need_lo = g.base - g.floor > K6_W ? g.base - K6_W : g.floor;
+        if (!(w_hi == g.base && w_lo <= need_lo)) {
+          const bool older = w_hi == g.base && w_lo < g.base;  // contiguous but short: the older part only
+          const u64 upto = older ? w_lo : g.base;
+          tbz_device_fence();  // (octets this workgroup stored in earlier steps must come back from L2, not a stale L1 line)
+          tbz_wg_barrier();
+          for (u64 x = need_lo + tid; x < upto; x += K6_THREADS) W0[(u32)((ob + x) & (K6_W - 1))] = P.out_base[x];
+          w_lo = need_lo;
+          if (!older) w_hi = g.base;
+        }
+      }
       tbz_wg_barrier();
-      for (u64 x = need_lo + tid; x < upto; x += K6_THREADS) W[R(x)] = P.out_base[x];
-      w_lo = need_lo;
-      w_hi = g.start;
-    }
-    tbz_wg_barrier();
-    // 2. the group's last 32 KiB: gather first (a destination's ring slot is the slot of the source 32 KiB before it),
-    //    then store.  Threads own 16-octet chunks that are aligned in address space.
-    const u64 t_lo = g.end - g.start > K6_W ? g.end - K6_W : g.start;
-    const u64 c_lo = t_lo - ((ob + t_lo) & 15);  // absolute offset of the first chunk (may start before t_lo, even below 0)
-    uint4 ov[3], mv[3];
-    bool have[3], chg[3];
-#pragma unroll
-    for (u32 k = 0; k < 3; k++) {
-      const u64 x = c_lo + ((u64)tid + (u64)k * K6_THREADS) * 16;
-      have[k] = (i64)x < (i64)g.end;
-      chg[k] = false;
-      if (have[k]) {
-        ov[k] = *(const uint4*)(P.out_base + x);
-        mv[k] = *(const uint4*)(P.mark_base + (x - P.bias));
-        chg[k] = k6_fix16(ov[k], mv[k], x, t_lo, g.end, [&](u32 idx) { return W[R(g.start + idx)]; });
-      }
-    }
-    tbz_wg_barrier();
-#pragma unroll
-    for (u32 k = 0; k < 3; k++) {
-      if (!have[k]) continue;
-      const u64 x = c_lo + ((u64)tid + (u64)k * K6_THREADS) * 16;
-      if ((i64)x >= (i64)t_lo && x + 16 <= g.end) {
-        *(uint4*)(W + R(x)) = ov[k];
-      } else {  // the two ragged chunks at the ends
-        const u32 ow[4] = {ov[k].x, ov[k].y, ov[k].z, ov[k].w};
-        for (u32 q = 0; q < 16; q++) {
-          const u64 pos = x + q;
-          if ((i64)pos >= (i64)t_lo && (i64)pos < (i64)g.end) W[R(pos)] = (u8)(ow[q >> 2] >> (8 * (q & 3)));
+      // 2. gather first (a destination's ring slot is the slot of the source 32 KiB before it), then store.  Threads own
+      //    16-octet chunks that are aligned in address space.
+      const u32 rbase = (u32)(ob + g.base);
+      auto src = [&](u32 idx, u32& a, u32& b) {
+        const u32 r = (rbase + idx) & (K6_W - 1);
+        a = W0[r];
+        b = SYM ? (u32)W1[r] : 0u;
+      };
+      auto step_fix = [&](u32 k, uint4& o, uint4& m) -> bool {
+        const u64 x = chunk_x(g, k);
+        if ((i64)x >= (i64)g.hi) return false;
+        if ((i64)x >= (i64)g.lo && x + 16 <= g.hi) return k6_fix16<true>(o, m, x, g.lo, g.hi, src);
+        return k6_fix16<false>(o, m, x, g.lo, g.hi, src);
+      };
+      const bool c0 = step_fix(0, o0, m0), c1 = step_fix(1, o1, m1);
+      bool c2 = false;
+      if (tid == 0) c2 = step_fix(2, o2, m2);
+      tbz_wg_barrier();
+      auto step_store = [&](u32 k, const uint4& o, const uint4& m, bool chg) {
+        const u64 x = chunk_x(g, k);
+        if ((i64)x >= (i64)g.hi) return;
+        if ((i64)x >= (i64)g.lo && x + 16 <= g.hi) {
+          const u32 r = (u32)((ob + x) & (K6_W - 1));
+          *(uint4*)(W0 + r) = o;
+          if (SYM) *(uint4*)(W1 + r) = m;
+          if (chg) {  // (final mode: the marks are now 0, so that tbz_k6_resolve leaves these octets alone)
+            *(uint4*)(P.out_base + x) = o;
+            *(uint4*)(P.mark_base + (x - P.bias)) = m;
+          }
+        } else {
+          // the two ragged chunks at the ends: octet by octet — what lies outside [lo, hi) belongs to a neighbour
+          // whose octets this copy (fetched a step early) may hold in an older state
+          const u32 ow[4] = {o.x, o.y, o.z, o.w}, mw[4] = {m.x, m.y, m.z, m.w};
+          for (u32 q = 0; q < 16; q++) {
+            const u64 pos = x + q;
+            if ((i64)pos < (i64)g.lo || (i64)pos >= (i64)g.hi) continue;
+            const u8 b0 = (u8)(ow[q >> 2] >> (8 * (q & 3))), b1 = (u8)(mw[q >> 2] >> (8 * (q & 3)));
+            const u32 r = (u32)((ob + pos) & (K6_W - 1));
+            W0[r] = b0;
+            if (SYM) W1[r] = b1;
+            if (chg) {
+              P.out_base[pos] = b0;
+              P.mark_base[pos - P.bias] = b1;
+            }
+          }
         }
-      }
-      if (chg[k]) {
-        // whole-chunk stores: the octets outside [t_lo, end) are written back unchanged (this kernel is the only
-        // writer while it runs); marks inside the range are cleared so that tbz_k6_resolve leaves them alone
-        *(uint4*)(P.out_base + x) = ov[k];
-        u32 mw[4] = {mv[k].x, mv[k].y, mv[k].z, mv[k].w};
-        for (u32 q = 0; q < 16; q++) {
-          const u64 pos = x + q;
-          if ((i64)pos >= (i64)t_lo && (i64)pos < (i64)g.end) mw[q >> 2] &= ~(0xffu << (8 * (q & 3)));
-        }
-        *(uint4*)(P.mark_base + (x - P.bias)) = uint4{mw[0], mw[1], mw[2], mw[3]};
-      }
+      };
+      step_store(0, o0, m0, c0);
+      step_store(1, o1, m1, c1);
+      if (tid == 0) step_store(2, o2, m2, c2);
+      if (w_hi < g.lo) w_lo = g.lo;                      // (final mode only: a gap — the ring restarts at this range)
+      w_hi = g.hi;
+      if (w_hi - w_lo > K6_W) w_lo = w_hi - K6_W;
+      tbz_wg_barrier();
     }
-    w_lo = (g.end - w_lo > K6_W) ? g.end - K6_W : w_lo;
-    w_hi = g.end;
-    tbz_wg_barrier();
+    g = gn;
+    gn = gnn;
+    o0 = p0; o1 = p1; o2 = p2;
+    m0 = q0; m1 = q1; m2 = q2;
   }
 }
 
-// everything but the last 32 KiB of every H-group: sources are final (tbz_k6_window has run)
+TBZ_KERNEL_WG(1024, 1) void tbz_k6_chain(K6Params P) {
+  TBZ_SHARED __attribute__((aligned(16))) u8 W0[K6_W];
+  k6_chain<false>(P, W0, W0);
+}
+TBZ_KERNEL_WG(1024, 1) void tbz_k6_chain_sym(K6Params P) {
+  TBZ_SHARED __attribute__((aligned(16))) u8 W0[K6_W];
+  TBZ_SHARED __attribute__((aligned(16))) u8 W1[K6_W];
+  k6_chain<true>(P, W0, W1);
+}
+
+// ranges whose sources are final in memory, all in parallel (K6_PIECE octets per workgroup)
 TBZ_KERNEL void tbz_k6_resolve(K6Params P) {
   const u32 lane = tbz_lane();
-  const u32 hgi = tbz_block() / P.pieces, piece = tbz_block() % P.pieces;
-  if (hgi >= P.n_hg) return;
-  const HGroup g = P.hg[hgi];
-  if (g.end <= g.start || g.end - g.start <= K6_W) return;
-  const u64 r_hi = g.end - K6_W;  // [g.start, r_hi) is this kernel's
+  const u32 ri = tbz_block() / P.pieces, piece = tbz_block() % P.pieces;
+  if (ri >= P.n_ranges) return;
+  const K6Range g = P.ranges[ri];
+  if (g.hi <= g.lo) return;
   const uintptr_t ob = (uintptr_t)P.out_base;
-  const u64 c_lo = g.start - ((ob + g.start) & 15);
+  const u64 c_lo = g.lo - ((ob + g.lo) & 15);
   const u64 p_lo = c_lo + (u64)piece * K6_PIECE;
-  if ((i64)p_lo >= (i64)r_hi) return;
+  if ((i64)p_lo >= (i64)g.hi) return;
   for (u32 k = lane; k < K6_PIECE / 16; k += 64) {
     const u64 x = p_lo + (u64)k * 16;
-    if ((i64)x >= (i64)r_hi) break;
-    const uint4 m = *(const uint4*)(P.mark_base + (x - P.bias));
+    if ((i64)x >= (i64)g.hi) break;
+    uint4 m = *(const uint4*)(P.mark_base + (x - P.bias));
     if ((m.x | m.y | m.z | m.w) == 0) continue;
     uint4 o = *(const uint4*)(P.out_base + x);
-    if (k6_fix16(o, m, x, g.start, r_hi, [&](u32 idx) { return P.out_base[g.start - K6_W + idx]; }))
+    auto src = [&](u32 idx, u32& a, u32& b) {
+      // (all sixteen lookups are made, symbolic or not: an address below the stream's first octet is one that no
+      // pointer of a valid stream means — read the first octet instead of unmapped memory)
+      const i64 y = (i64)(g.base - K6_W + idx);
+      a = P.out_base[y < (i64)g.floor ? g.floor : (u64)y];
+      b = 0;
+    };
+    const bool whole = (i64)x >= (i64)g.lo && x + 16 <= g.hi;
+    if (!(whole ? k6_fix16<true>(o, m, x, g.lo, g.hi, src) : k6_fix16<false>(o, m, x, g.lo, g.hi, src))) continue;
+    if ((i64)x >= (i64)g.lo && x + 16 <= g.hi) {
       *(uint4*)(P.out_base + x) = o;
+    } else {  // ragged ends: the octets outside the range are another workgroup's
+      const u32 ow[4] = {o.x, o.y, o.z, o.w};
+      for (u32 q = 0; q < 16; q++)
+        if ((i64)(x + q) >= (i64)g.lo && (i64)(x + q) < (i64)g.hi) P.out_base[x + q] = (u8)(ow[q >> 2] >> (8 * (q & 3)));
+    }
   }
 }
 

@@ -59,7 +59,7 @@ struct tbz_ctx {
   tbz::DevBuf d_str_off, d_str_len, d_tile_first, d_tile_counts, d_tile_offsets, d_markers, d_items, d_res,
       d_tok, d_scratch, d_runs, d_segs, d_groups, d_order, d_k3_fi, d_k3_ni, d_k3_oo, d_k3_oc, d_k3_sums, d_k3_flags,
       d_k3_gscan, d_k3_gne, d_k3_streams, d_k3_glob, d_redo_items, d_redo_res, d_k0_slots, d_k0_fm, d_hdr, d_gck, d_gchunks, d_ck_l1, d_tok2, d_runs2, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
-      d_out_stage, d_kb_tf, d_kb_slots, d_kb_counts, d_kb_offsets, d_kb_cands, d_kb_fc, d_kb_head, d_markers2, d_kb_fm2, d_mark, d_hg, d_k6s;
+      d_out_stage, d_kb_tf, d_kb_slots, d_kb_counts, d_kb_offsets, d_kb_cands, d_kb_fc, d_kb_head, d_markers2, d_kb_fm2, d_mark, d_hg, d_k6s, d_bigs, d_recs;
 };
 
 namespace tbz {
@@ -74,7 +74,7 @@ static std::vector<DevBuf*> all_pools(tbz_ctx* ctx) {
           &ctx->d_k3_glob, &ctx->d_redo_items, &ctx->d_redo_res, &ctx->d_k0_slots, &ctx->d_k0_fm, &ctx->d_hdr,
           &ctx->d_gck, &ctx->d_gchunks, &ctx->d_ck_l1, &ctx->d_tok2, &ctx->d_runs2, &ctx->d_kb_tf, &ctx->d_kb_slots,
           &ctx->d_kb_counts, &ctx->d_kb_offsets, &ctx->d_kb_cands, &ctx->d_kb_fc, &ctx->d_kb_head, &ctx->d_markers2,
-          &ctx->d_kb_fm2, &ctx->d_mark, &ctx->d_hg, &ctx->d_k6s};
+          &ctx->d_kb_fm2, &ctx->d_mark, &ctx->d_hg, &ctx->d_k6s, &ctx->d_bigs, &ctx->d_recs};
 }
 static uint64_t scratch_total(tbz_ctx* ctx) {
   uint64_t t = 0;
@@ -417,12 +417,15 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   const u32* d_first_marker = (const u32*)ctx->d_k0_fm.p + 2;
   if (tiles && ctx->find_mode) {
     constexpr uint64_t FIND_MIN_ITEM_BITS = 8ull * (48u << 10);  // mean compressed octets per item below which it does not pay
+    // ... nor when the call already has enough items to fill the chip (a batch of thousands of streams: measured on
+    // config 3, 4096 gzip members, splitting them cost more in K2's second plane than it gained in K1)
+    const bool enough = (size_t)n_mark + n >= 2048;
     std::vector<uint32_t> tfb(n + 1);
     uint64_t tiles_b = 0;
     for (size_t s = 0; s < n; s++) {
       tfb[s] = (uint32_t)tiles_b;
       const uint64_t items_s = 1 + (first_marker[s + 1] - first_marker[s]);
-      const bool search = ctx->find_mode == 2 ? sp[s].in_len >= 64 : (sp[s].in_len * 8 / items_s >= FIND_MIN_ITEM_BITS);
+      const bool search = ctx->find_mode == 2 ? sp[s].in_len >= 64 : (!enough && sp[s].in_len * 8 / items_s >= FIND_MIN_ITEM_BITS);
       if (search) tiles_b += ((((uintptr_t)d_in + in_offs[s]) & 15) + in_lens[s] + K0B_TILE - 1) / K0B_TILE;
       if (tiles_b > 0x7fffffffu) return TBZ_E_ARG;
     }
@@ -595,7 +598,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if ((r = upload(ctx, ctx->d_k3_oo, oo))) return r;
     if ((r = upload(ctx, ctx->d_k3_oc, oc))) return r;
     if ((r = ensure(ctx, ctx->d_k3_sums, 3 * (size_t)(k3_tiles + 1) * 8))) return r;
-    if ((r = ensure(ctx, ctx->d_k3_flags, 3 * (size_t)k3_tiles * 8))) return r;
+    if ((r = ensure(ctx, ctx->d_k3_flags, 4 * (size_t)k3_tiles * 8))) return r;
     if ((r = ensure(ctx, ctx->d_k3_gscan, n_items * 8))) return r;
     if ((r = ensure(ctx, ctx->d_k3_gne, n_items * 4))) return r;
     if ((r = ensure(ctx, ctx->d_segs, n_items * sizeof(Seg)))) return r;
@@ -624,6 +627,12 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     TBZ_HIP(hipMemcpyAsync(h_glob, ctx->d_k3_glob.p, sizeof(K3Global), hipMemcpyDeviceToHost, ctx->stream));
     TBZ_HIP(hipStreamSynchronize(ctx->stream));
     simple = h_glob->not_simple == 0;
+    // an item far larger than a fair share of the output is sliced (tbz_k3_slice): the general path lays that out
+    if (simple && ctx->sym_hist && !size_only) {
+      uint64_t target = std::max<uint64_t>(64u << 10, h_glob->total_out / 4096);
+      if (const char* m = getenv("TBZ_SLICE")) target = std::max(1024, atoi(m));
+      if (h_glob->max_out >= 2 * target) simple = false;
+    }
   }
   // what a stream reports once its status is known (both layout paths)
   auto fill_result = [&](size_t s, int32_t status, uint32_t nseg, bool error_first = false) {
@@ -737,6 +746,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     h.seg.out_bytes = q.out_bytes;
     h.seg.n_runs = q.n_runs;
     h.seg.pool = is_fixup ? 1u : 0u;
+    h.seg.run_first = 0;
+    h.seg.pad = 0;
     h.stream = (uint32_t)s;
     h.deficit = q.max_deficit;
     h.continues = S.next_continues;
@@ -906,6 +917,18 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   std::vector<Group> h_groups;
   std::vector<uint8_t> h_hist;      // per group: 1 = H-group (symbolic history)
   std::vector<uint32_t> h_gstream;  // per group: its stream
+  std::vector<int32_t> h_grec;      // per group: index of the slice record that describes it (tbz_k3_slice), or -1
+  std::vector<BigSeg> bigs;
+  uint32_t n_recs = 0;
+  // K2's parallelism is its number of groups: segments much larger than a fair share of the call's output are cut
+  // into slices at run boundaries on the device (tbz_k3_slice); every slice becomes a group
+  uint64_t slice_target = 64u << 10;
+  {
+    uint64_t tot = 0;
+    for (size_t s = 0; s < n; s++) tot += std::min(sp[s].total_out, sp[s].out_cap);
+    slice_target = std::max<uint64_t>(slice_target, tot / 4096);
+    if (const char* m = getenv("TBZ_SLICE")) slice_target = std::max(1024, atoi(m));  // (tests force small slices)
+  }
   for (size_t s = 0; s < n; s++) {
     StreamPlan& S = sp[s];
     tbz_result& R = results[s];
@@ -924,11 +947,42 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     S.seg_first = (uint32_t)h_segs.size();
     const size_t g0 = h_groups.size();  // this stream's first group
     constexpr uint64_t H_JOIN_BELOW = 48u << 10;  // a group keeps taking in history-needing segments below this size
+    bool after_big = false;
     for (size_t i = 0; i < v.size(); i++) {
       if (o >= R.out_len) break;
       const bool need = i > 0 && (v[i].continues || v[i].deficit > 0);
-      bool join = need;
-      if (ctx->sym_hist && need) join = (S.out_off + o) - h_groups.back().out_abs < H_JOIN_BELOW;
+      const uint64_t reach = S.out_off + (o > v[i].deficit ? o - v[i].deficit : 0);  // first octet its matches copy from
+      if (ctx->sym_hist && v[i].seg.out_bytes >= 2 * slice_target && v[i].seg.n_runs >= 2) {
+        // a large segment: its slices are laid out by the device, one group each
+        BigSeg b{};
+        b.seg = v[i].seg;
+        b.out_abs = S.out_off + o;
+        b.out_end = S.out_off + R.out_len;
+        b.target = slice_target;
+        b.seg_slot = (uint32_t)h_segs.size();
+        b.group_slot = (uint32_t)h_groups.size();
+        b.rec_slot = n_recs;
+        b.n_slots = (uint32_t)(v[i].seg.out_bytes / slice_target + 1);
+        b.first_hist = (need && reach < b.out_abs && h_groups.size() > g0) ? 1u : 0u;
+        bigs.push_back(b);
+        for (uint32_t k = 0; k < b.n_slots; k++) {
+          Group g{};
+          g.out_abs = b.out_abs;
+          g.out_end = b.out_end;
+          g.seg_first = b.seg_slot + k;
+          h_groups.push_back(g);
+          h_hist.push_back(0);
+          h_grec.push_back((int32_t)(n_recs + k));
+          h_segs.push_back(Seg{});
+        }
+        n_recs += b.n_slots;
+        o += v[i].seg.out_bytes;
+        after_big = true;
+        continue;
+      }
+      bool join = need && !after_big;
+      if (ctx->sym_hist && join) join = (S.out_off + o) - h_groups.back().out_abs < H_JOIN_BELOW;
+      after_big = false;
       if (!join) {
         Group g;
         g.out_abs = S.out_off + o;
@@ -937,8 +991,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         g.seg_count = 0;
         h_groups.push_back(g);
         h_hist.push_back(0);
+        h_grec.push_back(-1);
       }
-      const uint64_t reach = S.out_off + (o > v[i].deficit ? o - v[i].deficit : 0);  // first octet its matches copy from
       if (need && reach < h_groups.back().out_abs) {
         if (ctx->sym_hist && h_groups.size() > g0 + 1) {
           h_hist.back() = 1;
@@ -949,6 +1003,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
             const uint8_t hh = h_hist.back();
             h_groups.pop_back();
             h_hist.pop_back();
+            h_grec.pop_back();
             h_groups.back().seg_count += cnt;
             h_hist.back() |= hh;
           }
@@ -970,6 +1025,23 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if (!d_out) return TBZ_E_ARG;
     if ((r = upload(ctx, ctx->d_segs, h_segs))) return r;
     if ((r = upload(ctx, ctx->d_groups, h_groups))) return r;
+    std::vector<SliceRec> recs(n_recs);
+    if (!bigs.empty()) {
+      if ((r = upload(ctx, ctx->d_bigs, bigs))) return r;
+      if ((r = ensure(ctx, ctx->d_recs, (size_t)n_recs * sizeof(SliceRec)))) return r;
+      K3sParams ks{(const BigSeg*)ctx->d_bigs.p, (const RunRec*)ctx->d_runs.p, (const RunRec*)ctx->d_runs2.p,
+                   (Seg*)ctx->d_segs.p, (Group*)ctx->d_groups.p, (SliceRec*)ctx->d_recs.p, (u32)bigs.size()};
+      TBZ_LAUNCH(tbz_k3_slice, bigs.size(), ctx->stream, ks);
+      TBZ_HIP(hipMemcpyAsync(recs.data(), ctx->d_recs.p, (size_t)n_recs * sizeof(SliceRec), hipMemcpyDeviceToHost, ctx->stream));
+      TBZ_HIP(hipStreamSynchronize(ctx->stream));
+      for (size_t gi = 0; gi < h_groups.size(); gi++)
+        if (h_grec[gi] >= 0) {
+          const SliceRec& q = recs[h_grec[gi]];
+          h_groups[gi].out_abs = q.out_abs;
+          h_groups[gi].seg_count = q.used ? 1u : 0u;
+          h_hist[gi] = (uint8_t)(q.used && q.hist);
+        }
+    }
     // groups whose whole output fits a linear LDS window (the common case: flush-delimited segments)
     // run with dynamic LDS sized to the largest of them; the rest take the 32 KiB-history ring kernel;
     // H-groups take the ring kernel twice (octet plane, pointer plane) and K6 afterwards
@@ -979,12 +1051,17 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     uint64_t max_small = 0, mark_lo = ~0ull, mark_hi = 0;
     for (size_t gi = 0; gi < h_groups.size(); gi++) {
       uint64_t tot = 0;
-      for (uint32_t k = 0; k < h_groups[gi].seg_count; k++) tot += h_segs[h_groups[gi].seg_first + k].out_bytes;
+      if (h_grec[gi] >= 0) {
+        if (!recs[h_grec[gi]].used) continue;  // an empty slot: no workgroup at all
+        tot = recs[h_grec[gi]].out_bytes;
+      } else {
+        for (uint32_t k = 0; k < h_groups[gi].seg_count; k++) tot += h_segs[h_groups[gi].seg_first + k].out_bytes;
+      }
       if (h_hist[gi]) {
         const StreamPlan& S = sp[h_gstream[gi]];
         order_h.push_back((uint32_t)gi);
-        hgs.push_back(HG{h_groups[gi].out_abs, std::min(h_groups[gi].out_abs + tot, h_groups[gi].out_end), S.out_off,
-                         h_gstream[gi]});
+        hgs.push_back(HG{h_groups[gi].out_abs, std::max(h_groups[gi].out_abs, std::min(h_groups[gi].out_abs + tot, h_groups[gi].out_end)),
+                         S.out_off, h_gstream[gi]});
         mark_lo = std::min(mark_lo, S.out_off);
         mark_hi = std::max(mark_hi, h_groups[gi].out_end);
       } else if (tot + K2_SLACK <= K2_SMALL_MAX) {
@@ -997,6 +1074,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     std::vector<uint32_t> order(order_small);
     order.insert(order.end(), order_big.begin(), order_big.end());
     order.insert(order.end(), order_h.begin(), order_h.end());
+    ctx->tim.n_groups = order.size();
     if ((r = upload(ctx, ctx->d_order, order))) return r;
     K2Params k2{(const u16*)ctx->d_tok.p, (const RunRec*)ctx->d_runs.p, (const u16*)ctx->d_tok2.p, (const RunRec*)ctx->d_runs2.p,
                 (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, (const u32*)ctx->d_order.p, (const u8*)d_in, (u8*)d_out, 0, 0, 0, nullptr, nullptr,

@@ -1344,6 +1344,8 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
     RunRec rr;
     rr.off8 = 0;
     rr.n8 = (u32)T8;
+    rr.out = r.out_bytes > 0xfffffffeull ? 0xffffffffu : (u32)r.out_bytes;
+    rr.mdef = st.deficit;
     P.runs[it.start_bit >> RUN_SHIFT] = rr;
   }
   r.tok_words = T8 * 8;
@@ -2244,6 +2246,8 @@ TBZ_DEV void kg_leader_header(GangTables& gt, GangState& gs, K1State& st, const 
       RunRec rr;
       rr.off8 = (u32)(x >> 3);
       rr.n8 = 1;
+      rr.out = ncopy;
+      rr.mdef = 0;
       (P.runs + (it.start_bit >> RUN_SHIFT))[gs.nruns] = rr;
       gs.nruns += 1;
       gs.T += 8;
@@ -2448,6 +2452,8 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
       RunRec rr;
       rr.off8 = (u32)((s_lo - (it.start_bit & ~7ull)) >> 3);
       rr.n8 = n8;
+      rr.out = ro.out;
+      rr.mdef = ro.mdef > 0 ? (u32)ro.mdef : 0u;
       (P.runs + (it.start_bit >> RUN_SHIFT))[gs.nruns + rank] = rr;
     }
     // history check material: largest (distance - octets produced before the match) over the round
@@ -2754,16 +2760,14 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
     const u64 npieces = sg.tok_words >> 3;
     // (a repaired segment's tokens live in the repair launches' own pool: a gang that repairs runs past the
     // marker it will land on, and must not scribble over the tokens of the items that start there)
-    const RunRec* rt = (sg.pool ? P.runs2 : P.runs) + (sg.tok_index >> RUN_SHIFT);
+    const RunRec* rt = (sg.pool ? P.runs2 : P.runs) + (sg.tok_index >> RUN_SHIFT) + sg.run_first;
     const u16* tbase = (sg.pool ? P.tok2 : P.tok) + (sg.tok_index & ~7ull);  // run offsets count 8-word granules from here
     u32* rE = rcache;
     u32* rO = rcache + 64;
     u32 rbase = 0, ctot = 0;
     u64 cbase = 0;
     auto load_cache = [&]() {
-      RunRec rr;
-      rr.off8 = 0;
-      rr.n8 = 0;
+      RunRec rr{};
       if (rbase + lane < sg.n_runs) rr = rt[rbase + lane];
       const u32 inc = tbz_wave_incl_scan_u32(rr.n8);
       tbz_sync();
@@ -3366,6 +3370,7 @@ struct K3Stream {              // per stream, written by the device
 struct K3Global {
   u32 not_simple, n_big;
   u64 max_small;               // largest group that fits the linear K2 window
+  u64 max_out, total_out;      // largest item / all items (octets): the host slices segments that are far too large
 };
 struct K3Params {
   const Item* items;
@@ -3375,7 +3380,7 @@ struct K3Params {
   const u64* out_off;
   const u64* out_cap;
   u64* tile_sums;              // [3][n_tiles + 1]: out_bytes, tok_words, nonempty; scanned in place
-  u64* tile_flags;             // [3][n_tiles]: not_simple, n_big, max_small
+  u64* tile_flags;             // [4][n_tiles]: not_simple, n_big, max_small, max_out
   u64* gscan;                  // [n_items]: exclusive scan of out_bytes over ALL items
   u32* gne;                    // [n_items]: exclusive scan of the non-empty flags
   Seg* segs;
@@ -3387,7 +3392,7 @@ struct K3Params {
 
 TBZ_KERNEL void tbz_k3_tile_sums(K3Params P) {
   const u32 lane = tbz_lane(), t = tbz_block();
-  u64 so = 0, sw = 0, sn = 0, bad = 0, nbig = 0, mx = 0;
+  u64 so = 0, sw = 0, sn = 0, bad = 0, nbig = 0, mx = 0, mxo = 0;
   for (u32 it = 0; it < K3_TILE / 64; it++) {
     const u32 i = t * K3_TILE + it * 64 + lane;
     if (i >= P.n_items) continue;
@@ -3403,6 +3408,7 @@ TBZ_KERNEL void tbz_k3_tile_sums(K3Params P) {
     const bool big = q.out_bytes + K2_SLACK > K2_SMALL_MAX;
     nbig += big ? 1u : 0u;
     mx = !big && q.out_bytes > mx ? q.out_bytes : mx;
+    mxo = q.out_bytes > mxo ? q.out_bytes : mxo;
   }
   so = wave_sum_u64(so);
   sw = wave_sum_u64(sw);
@@ -3413,6 +3419,8 @@ TBZ_KERNEL void tbz_k3_tile_sums(K3Params P) {
   for (int m = 32; m >= 1; m >>= 1) {
     const u64 o = tbz_shfl_xor64(mx, m);
     mx = o > mx ? o : mx;
+    const u64 o2 = tbz_shfl_xor64(mxo, m);
+    mxo = o2 > mxo ? o2 : mxo;
   }
   if (lane == 0) {
     const u32 T1 = P.n_tiles + 1;
@@ -3422,6 +3430,7 @@ TBZ_KERNEL void tbz_k3_tile_sums(K3Params P) {
     P.tile_flags[t] = bad;
     P.tile_flags[P.n_tiles + t] = nbig;
     P.tile_flags[2 * P.n_tiles + t] = mx;
+    P.tile_flags[3 * P.n_tiles + t] = mxo;
   }
 }
 
@@ -3439,12 +3448,14 @@ TBZ_KERNEL void tbz_k3_scan_tiles(K3Params P) {
     }
     if (lane == 0) P.tile_sums[c * T1 + P.n_tiles] = carry;
   }
-  u64 bad = 0, nbig = 0, mx = 0;
+  u64 bad = 0, nbig = 0, mx = 0, mxo = 0;
   for (u32 i = lane; i < P.n_tiles; i += 64) {
     bad += P.tile_flags[i];
     nbig += P.tile_flags[P.n_tiles + i];
     const u64 m = P.tile_flags[2 * P.n_tiles + i];
     mx = m > mx ? m : mx;
+    const u64 m2 = P.tile_flags[3 * P.n_tiles + i];
+    mxo = m2 > mxo ? m2 : mxo;
   }
   bad = wave_sum_u64(bad);
   nbig = wave_sum_u64(nbig);
@@ -3452,12 +3463,16 @@ TBZ_KERNEL void tbz_k3_scan_tiles(K3Params P) {
   for (int m = 32; m >= 1; m >>= 1) {
     const u64 o = tbz_shfl_xor64(mx, m);
     mx = o > mx ? o : mx;
+    const u64 o2 = tbz_shfl_xor64(mxo, m);
+    mxo = o2 > mxo ? o2 : mxo;
   }
   if (lane == 0) {
     K3Global gl;
     gl.not_simple = bad ? 1u : 0u;
     gl.n_big = (u32)nbig;
     gl.max_small = mx;
+    gl.max_out = mxo;
+    gl.total_out = P.tile_sums[P.n_tiles];
     *P.glob = gl;
   }
 }
@@ -3504,6 +3519,8 @@ TBZ_KERNEL void tbz_k3_emit(K3Params P) {
     sg.out_bytes = q.out_bytes;
     sg.n_runs = q.n_runs;
     sg.pool = 0;
+    sg.run_first = 0;
+    sg.pad = 0;
     P.segs[i] = sg;
     Group g;
     g.out_abs = P.out_off[s] + rel;
@@ -3530,6 +3547,126 @@ TBZ_KERNEL void tbz_k3_emit(K3Params P) {
     tot.last_start = 0;
     P.streams[P.n_streams] = tot;
   }
+}
+
+// ================================================================================================
+// K3s — slices.  K2's parallelism is its number of groups, and a segment is as large as the encoder's blocks (or the
+// whole stream, when nothing in it can be found: fixed-Huffman or stored blocks without flush points).  A large
+// segment is therefore cut at RUN boundaries (K1 left the octets each run produces and how far its matches reach
+// back in the run table) into units of about `target` octets: run i, which starts P_i octets into the segment,
+// belongs to slice floor(P_i / target).  Each slice becomes a group of its own; one that reaches before its first
+// octet is an H-group (symbolic history + K6), exactly like a segment that reaches into the segment before it.
+// One wavefront per segment; the host reads the small per-slice records back and schedules K2 / K6 from them.
+// ================================================================================================
+struct BigSeg {
+  Seg seg;          // the whole segment
+  u64 out_abs;      // absolute output offset of its first octet
+  u64 out_end;      // clip (the stream's capacity)
+  u64 target;       // octets per slice
+  u32 seg_slot;     // slices go to segs[seg_slot + k], groups[group_slot + k], recs[rec_slot + k], k < n_slots
+  u32 group_slot;
+  u32 rec_slot;
+  u32 n_slots;
+  u32 first_hist;   // 1: the segment itself reaches before its first octet (slice 0 is an H-group)
+  u32 pad;
+};
+struct SliceRec {
+  u64 out_abs;
+  u64 out_bytes;
+  u32 hist;
+  u32 used;
+};
+struct K3sParams {
+  const BigSeg* big;
+  const RunRec* runs;
+  const RunRec* runs2;
+  Seg* segs;
+  Group* groups;
+  SliceRec* recs;
+  u32 n_big;
+};
+TBZ_KERNEL void tbz_k3_slice(K3sParams P) {
+  const u32 lane = tbz_lane();
+  if (tbz_block() >= P.n_big) return;
+  const BigSeg bs = P.big[tbz_block()];
+  const RunRec* rt = (bs.seg.pool ? P.runs2 : P.runs) + (bs.seg.tok_index >> RUN_SHIFT);
+  for (u32 k = lane; k < bs.n_slots; k += 64) {  // slots no run starts in stay empty
+    Group g{};
+    g.out_abs = bs.out_abs;
+    g.out_end = bs.out_abs;
+    g.seg_first = bs.seg_slot + k;
+    g.seg_count = 0;
+    P.groups[bs.group_slot + k] = g;
+    P.recs[bs.rec_slot + k] = SliceRec{};
+  }
+  tbz_sync();
+  // the slice being accumulated (wave-uniform)
+  u64 cur_k = ~0ull, cur_start = 0, acc_words = 0, acc_out = 0, carry = 0;
+  u32 cur_first = 0, cur_runs = 0, cur_hist = 0;
+  auto flush = [&]() {
+    if (cur_k == ~0ull || cur_runs == 0 || cur_k >= bs.n_slots) return;
+    if (lane == 0) {
+      Seg sg = bs.seg;
+      sg.tok_words = acc_words;
+      sg.out_bytes = acc_out;
+      sg.n_runs = cur_runs;
+      sg.run_first = cur_first;
+      P.segs[bs.seg_slot + cur_k] = sg;
+      Group g;
+      g.out_abs = bs.out_abs + cur_start;
+      g.out_end = bs.out_end;
+      g.seg_first = bs.seg_slot + (u32)cur_k;
+      g.seg_count = 1;
+      P.groups[bs.group_slot + cur_k] = g;
+      SliceRec r;
+      r.out_abs = bs.out_abs + cur_start;
+      r.out_bytes = acc_out;
+      r.hist = cur_k == 0 ? bs.first_hist : cur_hist;
+      r.used = 1;
+      P.recs[bs.rec_slot + cur_k] = r;
+    }
+  };
+  for (u32 base = 0; base < bs.seg.n_runs; base += 64) {  // wave-uniform trip count
+    RunRec rr{};
+    const bool have = base + lane < bs.seg.n_runs;
+    if (have) rr = rt[base + lane];
+    const u64 incl_o = wave_incl_scan_u64(rr.out), incl_w = wave_incl_scan_u64((u64)rr.n8 * 8);
+    const u64 Pi = carry + incl_o - rr.out;  // octets of the segment before this run
+    const u64 ki = Pi / bs.target;
+    const u32 kprev_lo = tbz_wave_shr1((u32)ki), kprev_hi = tbz_wave_shr1((u32)(ki >> 32));
+    const u64 kprev = lane == 0 ? cur_k : (((u64)kprev_hi << 32) | kprev_lo);
+    u64 heads = tbz_ballot(have && ki != kprev);
+    const u64 valid = tbz_ballot(have);
+    u32 from = 0;
+    // the chunk's runs go to the current slice up to the first head, then slice by slice
+    for (;;) {
+      const u32 to = heads ? (u32)tbz_ffs64(heads) - 1 : (u32)tbz_popc64(valid);  // lanes [from, to) continue the slice
+      if (to > from) {
+        const u64 o_hi = tbz_shfl64(incl_o, (int)(to - 1)), w_hi = tbz_shfl64(incl_w, (int)(to - 1));
+        const u64 o_lo = from ? tbz_shfl64(incl_o, (int)(from - 1)) : 0, w_lo = from ? tbz_shfl64(incl_w, (int)(from - 1)) : 0;
+        const bool in = lane >= from && lane < to;
+        // a run reaches before the slice's first octet when its matches reach further back than it is into the slice
+        const u64 reach = tbz_ballot(in && (u64)rr.mdef > Pi - cur_start);
+        acc_out += o_hi - o_lo;
+        acc_words += w_hi - w_lo;
+        cur_runs += to - from;
+        cur_hist |= reach ? 1u : 0u;
+      }
+      if (!heads) break;
+      flush();
+      const u32 h = (u32)tbz_ffs64(heads) - 1;
+      heads &= heads - 1;
+      cur_k = tbz_shfl64(ki, (int)h);
+      cur_start = tbz_shfl64(Pi, (int)h);
+      cur_first = base + h;
+      cur_runs = 0;
+      cur_hist = 0;
+      acc_words = acc_out = 0;
+      from = h;
+    }
+    carry += tbz_shfl64(incl_o, 63);
+  }
+  flush();
 }
 
 // ================================================================================================

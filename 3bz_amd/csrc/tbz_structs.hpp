@@ -67,12 +67,16 @@ struct SegResult {
 // One contiguous piece of an item's token stream: n8 * 8 words at tok[(item.start_bit & ~7) + off8 * 8 ...].
 // An item's table starts at runs[item.start_bit >> RUN_SHIFT] (position-addressed like the token pool:
 // a token-bearing item spans more than 2^RUN_SHIFT bits, and K1 declines items that would need more runs
-// than their span holds slots).
+// than their span holds slots).  `out` and `mdef` let K3 cut a large segment into K2 work units at run
+// boundaries without looking at a token (tbz_k3_slice).
 struct RunRec {
   uint32_t off8;
   uint32_t n8;
+  uint32_t out;   // octets the run's tokens produce (0xffffffff: more than fits — such a segment is not sliced)
+  uint32_t mdef;  // max over its matches of (distance - octets the RUN produced before the match), 0 if none reaches
+                  // before the run's first octet
 };
-constexpr uint32_t RUN_SHIFT = 5;
+constexpr uint32_t RUN_SHIFT = 6;
 
 struct Seg {
   uint64_t tok_index;  // the item's start_bit: base of its token region and (>> RUN_SHIFT) of its run table
@@ -80,6 +84,8 @@ struct Seg {
   uint64_t out_bytes;
   uint32_t n_runs;
   uint32_t pool;       // 0: the call's token pool / run tables; 1: those of the repair (fix-up) launches
+  uint32_t run_first;  // first entry of the item's run table that belongs to this unit (a slice of a large segment)
+  uint32_t pad;
 };
 
 struct Group {

@@ -169,7 +169,8 @@ def case_flush_streams(eng, n=96 << 10):
     out = bytearray(len(p))
     res = eng.inflate(s, 1, out)
     assert res.status == 0 and bytes(out) == p
-    assert eng.timings().n_groups < eng.timings().n_segments
+    t = eng.timings()   # the segments reach into each other: shared windows, or symbolic history + K6
+    assert t.n_hgroups >= 1 or t.n_groups < t.n_segments
     # small blocks: a flush every 1000 octets
     s, p, a = K.zlib_flush_stream(40_000, block=1000)
     assert_same(eng, s, "zlib", len(p), what="1000-octet flush blocks")

@@ -1487,7 +1487,9 @@ struct GangState {  // per gang, in LDS; owned by the leader
                             //   2 they copy the lengths K1h left in the item's scratch
   u32 rounds, valid_lanes;  // diagnostics: rounds run and lanes committed (efficiency = valid_lanes / (G*rounds))
   u32 cut;                  // 2: ran out of input inside a stored block's payload (SegResult.pad)
-  u32 pad[2];
+  u32 inl;                  // 1: a committed lane passed a block header inside its run (see Inl): the current block does
+                            //   not start on a run boundary, so an overshoot cannot be rolled back to it (-> SEG_REDO)
+  u32 noinline;             // 1: the next round decodes block by block (the round before was cut at a wrong assumption)
 };
 template <int G>
 struct KgLds {
@@ -1882,6 +1884,20 @@ struct RoundOut {
   u32 out;   // octets they produce
   i32 mdef;  // max over recorded matches of (distance - octets this lane produced before the match)
   u32 flag;
+  // fixed-Huffman blocks that follow each other are decoded THROUGH (see Inl): while recording, the lane passed
+  u64 hdr;      //   … its last block header at this bit position (valid when nhdr != 0)
+  u32 nhdr;     //   … this many block headers
+  u32 assumed;  //   … an end-of-block code without knowing whether that block was the final one (it took it not to be)
+  i32 bf_end;   // BFINAL of the block the lane was in when it stopped, -1 = the block it started in (no header passed)
+};
+// Decoding through block boundaries inside a lane's sub-range.  With the fixed code loaded (deflate.lisp:518-528 ->
+// ht-constants.lisp:9-32) the tables do not change from block to block, so "end-of-block, BFINAL, BTYPE=1" is consumed
+// like a token and the lane goes on; anything else after an end-of-block code stops the lane as before.  A lane that
+// began inside a block does not know that block's BFINAL: it assumes 0 and says so; the commit step, which knows
+// BFINAL lane by lane along the chain, cuts the round where the assumption was wrong.
+struct Inl {
+  bool on;
+  i32 cur_bf;  // BFINAL of the block the reader is in: -1 unknown
 };
 // A lane's token output.  Storing every token straight to memory is a 2- or 4-octet store per lane into 64
 // different cache lines per instruction, and the lines leave L2 partly written (measured: 4.7 GB of write
@@ -1999,6 +2015,8 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, T
     B.hi = hi;
     B.nx = nx;
     B.o = o;
+    // (a span of ONE token never reaches the flush above: blocks of a single literal, decoded through)
+    if (REC && to.n - to.nf >= 8) tok_flush_piece(to);
     if (bad) { ret = 1; break; }
     if (rel >= tgt) { ret = 0; break; }
   }
@@ -2021,7 +2039,7 @@ TBZ_DEV u32 kg_canon_lds(u32 pk, const u32* lim, const u16* dlt, u32 cap, u32& s
 // reference's failure rules.  Returns 0 if it was a literal or match inside the limit (consumed, and
 // recorded when `rec`); otherwise fills ro.flag / ro.e / ro.aux and returns 1.
 TBZ_DEV u32 kg_exact_step(const GangTables& gt, BitReader& B, u64 lim64, bool rec, TokOut& to, u32& out, i32& mdef,
-                          RoundOut& ro) {
+                          RoundOut& ro, Inl& il) {
   const u64 p0 = B.pos;
   br_seek_fill(B, p0);
   const u32 pk = br_peek(B);
@@ -2042,6 +2060,20 @@ TBZ_DEV u32 kg_exact_step(const GangTables& gt, BitReader& B, u64 lim64, bool re
       return 1;
     }
     if (sym == 256) {
+      if (il.on && il.cur_bf != 1 && B.pos + 3 <= lim64) {
+        const u32 h = br_peek(B);
+        if (((h >> 1) & 3) == 1) {  // another fixed-Huffman block: through it
+          if (rec) {
+            if (il.cur_bf < 0) ro.assumed = 1;
+            ro.hdr = B.pos;
+            ro.nhdr += 1;
+            ro.bf_end = (i32)(h & 1);
+          }
+          il.cur_bf = (i32)(h & 1);
+          br_skip(B, 3);
+          return 0;
+        }
+      }
       ro.flag = RF_EOB;
       ro.e = B.pos;
       return 1;
@@ -2099,7 +2131,7 @@ TBZ_DEV u32 kg_exact_step(const GangTables& gt, BitReader& B, u64 lim64, bool re
 // One lane's share of a round: decode from `start`; tokens that start before rec_from are the run-up
 // (not recorded), the ones from there to the first token start >= stop are staged.
 TBZ_DEV void kg_lane_round(const GangTables& gt, BitReader& B, u64 start, u64 rec_from, u64 stop, u64 lim64,
-                           u16* stage, u8* ring, u32 cap, RoundOut& ro) {
+                           u16* stage, u8* ring, u32 cap, RoundOut& ro, Inl il) {
   TokOut to;
   to.ring = ring;
   to.stage = stage;
@@ -2110,7 +2142,7 @@ TBZ_DEV void kg_lane_round(const GangTables& gt, BitReader& B, u64 start, u64 re
   bool junk = false;
   while (B.pos < rec_from) {  // run-up
     if (kg_span<false>(gt, B, rec_from, lim64, to, cap, out, mdef) == 0) break;
-    if (kg_exact_step(gt, B, lim64, false, to, out, mdef, ro)) {
+    if (kg_exact_step(gt, B, lim64, false, to, out, mdef, ro, il)) {
       junk = true;  // ended (end-of-block / failure) during the run-up: nothing of this lane can be valid
       break;
     }
@@ -2131,7 +2163,7 @@ TBZ_DEV void kg_lane_round(const GangTables& gt, BitReader& B, u64 start, u64 re
       ro.aux = B.pos;
       break;
     }
-    if (kg_exact_step(gt, B, lim64, true, to, out, mdef, ro)) break;
+    if (kg_exact_step(gt, B, lim64, true, to, out, mdef, ro, il)) break;
   }
   // the run is stored in whole 8-word granules: pad with no-ops and let the last pieces out
   ro.n = to.n;
@@ -2214,6 +2246,7 @@ TBZ_DEV void kg_leader_header(GangTables& gt, GangState& gs, K1State& st, const 
   gs.blk_prod = gs.produced;
   gs.blk_tok = gs.T;
   gs.blk_runs = gs.nruns;
+  gs.inl = 0;
   u32 pk = br_peek(st.br);
   br_skip(st.br, 3);
   if (st.br.pos > st.end_bit) { gs.fail_pos = gs.blk_pos; gs.status = SEG_UNDERRUN; gs.mode = GM_DONE; return; }
@@ -2344,6 +2377,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     gs.hlit = gs.hdist = gs.fixed = 0;
     gs.nruns = gs.blk_runs = 0;
     gs.rounds = gs.valid_lanes = 0;
+    gs.inl = gs.noinline = 0;
     if (have && (it.flags & ITEM_HEAD)) {
       br_seek_fill(st.br, it.start_bit);
       i32 e = k1_container_header(st, fmt);
@@ -2403,6 +2437,12 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     ro.out = 0;
     ro.mdef = -(1 << 30);
     ro.flag = RF_JUNK;
+    ro.hdr = 0;
+    ro.nhdr = 0;
+    ro.assumed = 0;
+    ro.bf_end = -1;
+    // consecutive fixed-Huffman blocks are decoded through (not by repair items: they land on a marker after EVERY block)
+    const bool inl_on = inblk && gs.tables == 1 && !fixup && !gs.noinline;
     u16* stage = P.tok;
     u64 s_lo = 0;  // token-pool index of this lane's region
     if (inblk) {
@@ -2416,7 +2456,10 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
       const u64 start = g == 0 ? Pb : s_g - KG_OVL;
       s_lo = s_g & ~7ull;
       stage = P.tok + s_lo;  // private region of the token pool: [s_g & ~7, (s_g + sub) & ~7), 16-octet aligned
-      kg_lane_round(gt, st.br, start, s_g, s_g + sub, lim64, stage, S.tokring + lane * KG_RING_STRIDE, sub - 16, ro);
+      Inl il;
+      il.on = inl_on;
+      il.cur_bf = g == 0 ? (i32)gs.bfinal : -1;
+      kg_lane_round(gt, st.br, start, s_g, s_g + sub, lim64, stage, S.tokring + lane * KG_RING_STRIDE, sub - 16, ro, il);
     }
     // ---- chain validation: lane g counts iff it began recording exactly where lane g-1 stopped
     const u32 pe_lo = tbz_wave_shr1((u32)ro.e), pe_hi = tbz_wave_shr1((u32)(ro.e >> 32));
@@ -2426,7 +2469,45 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     const u64 okm = tbz_ballot(link);
     constexpr u64 GMASK = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1);
     const u64 gm = (okm >> base) & GMASK;
-    const u32 v = gm == GMASK ? (u32)G : (u32)__builtin_ctzll(~gm);  // valid lanes of my gang
+    u32 v = gm == GMASK ? (u32)G : (u32)__builtin_ctzll(~gm);  // valid lanes of my gang
+    // lanes that decoded through block headers: BFINAL of the block each lane STARTED in is the last one reported
+    // before it along the chain (the leader's for lane 0); a lane that took an unknown block for non-final and went
+    // through its end-of-block code was wrong if that block was the final one: the round ends before that lane
+    i32 bf_last = -1;       // BFINAL reported by the last lane of the committed chain that passed a header
+    u64 hdr_last = 0;
+    bool any_hdr = false;
+    if (tbz_ballot(ro.nhdr != 0) != 0) {  // wave-uniform
+      i32 bf_in = ro.bf_end;  // inclusive scan "last defined" over the gang's lanes, then shifted by one
+#pragma unroll
+      for (u32 d = 1; d < (u32)G; d <<= 1) {
+        const i32 t = (i32)tbz_shfl_up((u32)bf_in, d);
+        if (g >= d && bf_in < 0) bf_in = t;
+      }
+      const i32 incl = bf_in;
+      i32 before = (i32)tbz_wave_shr1((u32)incl);
+      if (g == 0) before = -1;
+      const i32 start_bf = before < 0 ? (i32)gs.bfinal : before;
+      const u64 bad = (tbz_ballot(inblk && ro.assumed && start_bf == 1) >> base) & GMASK;
+      if (bad) {
+        const u32 fb = (u32)__builtin_ctzll(bad);
+        v = v < fb ? v : fb;
+      }
+      const u32 lvv = base + (v ? v - 1 : 0);
+      const i32 bf_lv = (i32)tbz_shfl((u32)incl, (int)lvv);
+      bf_last = v ? bf_lv : -1;
+      // the last header passed by a committed lane
+      u64 hp = (g < v && ro.nhdr) ? ro.hdr : 0;
+#pragma unroll
+      for (int m = 1; m < G; m <<= 1) {
+        const u64 t = tbz_shfl_xor64(hp, m);
+        hp = t > hp ? t : hp;
+      }
+      hdr_last = hp;
+      any_hdr = hp != 0;
+      if (leader && inblk) gs.noinline = bad ? 1u : 0u;
+    } else if (leader && inblk) {
+      gs.noinline = 0;
+    }
     const bool valid = g < v;
     // ---- commit: nothing is copied.  A valid lane's tokens stay where it staged them; it pads them to
     // the 8-word granule and enters them in the item's run table, which is what K2 follows.
@@ -2472,6 +2553,11 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     } else if (leader && inblk) {
       gs.rounds += 1;
       gs.valid_lanes += v;
+      if (any_hdr) {  // the chain went through block headers: the current block is the last of them
+        if (bf_last >= 0) gs.bfinal = (u32)bf_last;
+        gs.blk_pos = hdr_last;
+        gs.inl = 1;
+      }
       gs.T += tot_n;
       gs.nruns += tot_r;
       gs.produced += tot_o;
@@ -2503,6 +2589,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
 
   if (leader && have) {
     SegResult r;
+    if (gs.status == SEG_OVERSHOOT && gs.inl) gs.status = SEG_REDO;  // the block's start lies inside a run: one lane redoes the item
     if (gs.status == SEG_OVERSHOOT) {
       r.end_bit = gs.blk_pos;
       r.out_bytes = gs.blk_prod;

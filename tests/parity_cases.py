@@ -209,6 +209,81 @@ def case_noflush_streams(eng, n=200_000):
     assert_same(eng, zlib.compress(bytes(n), 6), "zlib", n, what="zeros (distance-1 runs across every group)")
 
 
+def _fixed_chain(seed, nblk, maxtok, final_at=None):
+    """raw deflate of `nblk` fixed-Huffman blocks of 1..maxtok random tokens each; BFINAL on block `final_at`
+    (default: an empty final block at the end).  Returns (stream, plain up to and including the final block)."""
+    rng = random.Random(seed)
+    w = K.FixedHuffmanWriter()
+    out = bytearray()
+    fin = None
+    for b in range(nblk):
+        w.begin_block(final_at == b)
+        for _ in range(rng.randrange(1, maxtok + 1)):
+            if len(out) > 300 and rng.random() < 0.3:
+                ln, d = rng.randrange(3, 259), rng.randrange(1, min(len(out), 32768) + 1)
+                w.match(ln, d)
+                K._lz_apply(out, ln, d)
+            else:
+                c = rng.randrange(256)
+                w.literal(c)
+                out.append(c)
+        w.end_block()
+        if final_at == b:
+            fin = len(out)
+    if final_at is None:
+        w.begin_block(True)
+        w.end_block()
+        fin = len(out)
+    w.align()
+    return w.getvalue(), bytes(out[:fin])
+
+
+def case_fixed_block_chains(eng):
+    """Consecutive fixed-Huffman blocks are decoded THROUGH by the gang kernel (end-of-block + header consumed like a
+    token; a lane that starts inside a block assumes it is not the final one): blocks of one to three tokens, blocks
+    of hundreds, a final block in the middle with more 'blocks' behind it, cuts and small buffers everywhere."""
+    for seed, nblk, maxtok in ((1, 400, 3), (2, 1500, 1), (3, 900, 40), (4, 60, 700)):
+        s, p = _fixed_chain(seed, nblk, maxtok)
+        want = assert_same(eng, s, "deflate", len(p) + 10, what="fixed chain %d" % seed)
+        assert want["flag"] == "finished" and want["bytes"] == p
+        for cut in (len(s) - 1, len(s) - 2, len(s) // 2, len(s) // 3 + 1, 40, 7):
+            assert_same(eng, s[:cut], "deflate", len(p) + 10, what="fixed chain %d cut %d" % (seed, cut))
+        for cap in (len(p) - 1, len(p) // 2, 33, 1, 0):
+            assert_same(eng, s, "deflate", cap, what="fixed chain %d cap %d" % (seed, cap))
+    # BFINAL in the middle: what follows looks like more fixed blocks, but the stream ended
+    for seed, nblk, fin in ((5, 600, 300), (6, 600, 17), (7, 2000, 1999), (8, 300, 0)):
+        s, p = _fixed_chain(seed, nblk, 4, final_at=fin)
+        want = assert_same(eng, s, "deflate", 200_000, what="final block %d of %d" % (fin, nblk))
+        assert want["flag"] == "finished" and want["bytes"] == p
+        assert_same(eng, zlib_wrap(s, p), "zlib", 200_000, what="final block %d of %d, zlib" % (fin, nblk))
+    # a dynamic block between runs of fixed ones, and a stored one
+    s1, p1 = _fixed_chain(9, 200, 5)
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    mid = _mixed_plain(30_000, 3)
+    dyn = c.compress(mid) + c.flush(zlib.Z_SYNC_FLUSH)  # ends on a stored block, not final
+    # (s1 ends with an empty FINAL fixed block: rebuild without it)
+    w = K.FixedHuffmanWriter()
+    for b in (b"abc", b"de", b"f" * 5):
+        w.begin_block(False)
+        for ch in b:
+            w.literal(ch)
+        w.end_block()
+    w.bits(0, 3)  # an empty stored block aligns the stream to an octet
+    w.align()
+    w.bits(0, 16)
+    w.bits(0xFFFF, 16)
+    head = w.getvalue()
+    tail, ptail = _fixed_chain(10, 300, 3)
+    s = head + dyn + tail
+    p = b"abcdefffff" + mid + ptail
+    want = assert_same(eng, s, "deflate", len(p) + 5, what="fixed / dynamic / stored / fixed")
+    assert want["flag"] == "finished" and want["bytes"] == p
+
+
+def zlib_wrap(raw, plain):
+    return b"\x78\x9c" + raw + struct.pack(">I", zlib.adler32(plain))
+
+
 def case_history_across_groups(eng):
     """Z_SYNC_FLUSH stream whose middle segment copies nothing from before itself (incompressible octets: it opens a
     LZ77 group of its own) while the segment after it copies from the FIRST one, i.e. from before its predecessor's
@@ -719,12 +794,12 @@ def case_pointer_contexts(eng, n=60_000):
 
 
 ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,
-             case_noflush_streams, case_history_across_groups,
+             case_noflush_streams, case_fixed_block_chains, case_history_across_groups,
              case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_device_buffers,
              case_checksum_kernels, case_deep_codes, case_chunked_resume, case_gzip_members,
              case_pointer_contexts, case_container_headers, case_fuzz]
 # the cases whose behaviour depends on the K1 flavour (forced-flavour runs skip the rest: checksums, device
 # buffers and the replay protocol go through the same engine calls whatever decodes the Huffman codes)
 K1_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,
-            case_noflush_streams, case_history_across_groups,
+            case_noflush_streams, case_fixed_block_chains, case_history_across_groups,
             case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_deep_codes, case_fuzz]

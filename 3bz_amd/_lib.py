@@ -28,14 +28,14 @@ class Timings(C.Structure):
                 ("token_words", C.c_uint64), ("n_segments", C.c_uint64), ("n_groups", C.c_uint64),
                 ("find_ms", C.c_float), ("resolve_ms", C.c_float), ("k1_gang", C.c_uint32), ("k2_kinds", C.c_uint32),
                 ("n_candidates", C.c_uint64), ("n_hgroups", C.c_uint64), ("scratch_bytes", C.c_uint64),
-                ("h2d_copies", C.c_uint32), ("reserved", C.c_uint32)]
+                ("h2d_copies", C.c_uint32), ("passes", C.c_uint32)]
 
 
 assert C.sizeof(Result) == 64
 
 # every symbol include/tbz_amd.h declares
 SYMBOLS = [
-    "tbz_ctx_create", "tbz_ctx_destroy", "tbz_abi_version", "tbz_strerror", "tbz_last_error",
+    "tbz_ctx_create", "tbz_ctx_destroy", "tbz_ctx_trim", "tbz_abi_version", "tbz_strerror", "tbz_last_error",
     "tbz_device_count", "tbz_inflate", "tbz_inflate_size", "tbz_inflate_batch", "tbz_inflate_device",
     "tbz_inflate_batch_device", "tbz_adler32_device", "tbz_crc32_device", "tbz_device_malloc",
     "tbz_device_free", "tbz_memcpy_h2d", "tbz_memcpy_d2h", "tbz_last_timings",
@@ -63,6 +63,7 @@ def load(path=None):
     L.tbz_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.tbz_ctx_destroy.argtypes = [vp]
     L.tbz_ctx_destroy.restype = None
+    L.tbz_ctx_trim.argtypes = [vp]
     L.tbz_strerror.restype = C.c_char_p
     L.tbz_strerror.argtypes = [C.c_int]
     L.tbz_last_error.restype = C.c_char_p

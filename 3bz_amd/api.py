@@ -140,6 +140,10 @@ class Engine:
     def d2h(self, out, d_src, n=None):
         self._check(self.lib.tbz_memcpy_d2h(self._ctx, _addr(out), d_src, len(out) if n is None else n))
 
+    def trim(self):
+        """release the context's device scratch (it only grows otherwise)"""
+        self._check(self.lib.tbz_ctx_trim(self._ctx))
+
     def timings(self):
         t = _lib.Timings()
         self._check(self.lib.tbz_last_timings(self._ctx, C.byref(t)))

@@ -53,6 +53,8 @@ struct tbz_ctx {
   int k1_mode = 0;  // 0 auto, 1 lane-per-item, 4..64 gang of that many lanes (env TBZ_K1_MODE; tests force each)
   bool sym_hist = true;  // groups that need history they do not hold run against symbolic history + K6 (env TBZ_HIST=off:
                          // they join their predecessors' group instead, one workgroup per chain, as in round 1)
+  uint64_t pool_cap = 96ull << 30;  // octets of token pool + run tables one pass may hold (env TBZ_POOL_CAP_MIB): a batch
+                                    // whose streams need more is decoded in several passes over consecutive streams
   int find_mode = 1;  // K0b block-start finder: 0 never, 1 for streams whose items are large (default), 2 for every stream
                       // of at least one finder tile (env TBZ_FIND=off|auto|always; tests force it at small sizes)
   // device pools (grow-only)
@@ -315,7 +317,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   std::vector<StreamPlan> sp(n);
   std::vector<uint64_t> h_off(n), h_len(n);
   std::vector<uint32_t> tile_first(n + 1);
-  uint64_t in_extent = 0, tiles = 0, in_total_bits = 0;
+  uint64_t in_extent = 0, in_lo = ~0ull, tiles = 0, in_total_bits = 0;
   for (size_t s = 0; s < n; s++) {
     sp[s].in_off = in_offs[s];
     sp[s].in_len = in_lens[s];
@@ -324,6 +326,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     h_off[s] = in_offs[s];
     h_len[s] = in_lens[s];
     in_extent = std::max(in_extent, in_offs[s] + in_lens[s]);
+    if (in_lens[s]) in_lo = std::min(in_lo, in_offs[s]);
     in_total_bits += in_lens[s] * 8;
     tile_first[s] = (uint32_t)tiles;
     // tiles are 64 KiB of memory starting at the stream's first octet rounded down to 16 (see K0)
@@ -498,10 +501,16 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   };
   if ((r = record(ctx, 1))) return r;
 
-  // token pool: one u16 per input bit (K1 never writes more words than bits consumed)
-  if ((r = ensure(ctx, ctx->d_tok, (size_t)in_extent * 16 + 64))) return r;
-  // run tables: one 8-byte slot per 2^RUN_SHIFT input bits, position-addressed like the token pool
-  if ((r = ensure(ctx, ctx->d_runs, (((size_t)in_extent * 8) >> RUN_SHIFT) * sizeof(RunRec) + 1024))) return r;
+  // token pool: one u16 per input bit (K1 never writes more words than bits consumed); run tables: one 16-octet slot
+  // per 2^RUN_SHIFT input bits.  Both are addressed by bit position RELATIVE to the first stream octet of the call
+  // (pool_base: a batch that is a window into a large buffer pays for its own extent only); the repair launches'
+  // pools cover the repaired streams' tails only (pool2_base).
+  if (in_lo > in_extent) in_lo = in_extent;
+  const uint64_t pool_base = (in_lo * 8) & ~(uint64_t)((1u << RUN_SHIFT) - 1);  // bits
+  const uint64_t pool_bits = in_extent * 8 - pool_base;
+  uint64_t pool2_base = pool_base, pool2_hi = 0;
+  if ((r = ensure(ctx, ctx->d_tok, (size_t)pool_bits * 2 + 256))) return r;
+  if ((r = ensure(ctx, ctx->d_runs, ((size_t)pool_bits >> RUN_SHIFT) * sizeof(RunRec) + 1024))) return r;
   if ((r = ensure(ctx, ctx->d_res, n_items * sizeof(SegResult)))) return r;
   // K1 flavour.  One lane per item is bound by ONE item's serial chain (~1.1 us per token) and decodes
   // without lookup tables; a gang of G lanes shares one item and one set of LDS tables.  G follows the
@@ -522,8 +531,11 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   };
   // Repair (fix-up) launches decode into pools of their own: a gang that repairs an item runs past the marker
   // it will land on, into the bit range of items whose tokens (position-addressed!) are already in place.
-  auto pool_tok = [&](bool fix) { return (u16*)(fix ? ctx->d_tok2.p : ctx->d_tok.p); };
-  auto pool_runs = [&](bool fix) { return (RunRec*)(fix ? ctx->d_runs2.p : ctx->d_runs.p); };
+  // (kernels index the pools by absolute bit position: the pointers handed to them are shifted down by the pool's base)
+  auto pool_tok = [&](bool fix) { return fix ? (u16*)ctx->d_tok2.p - pool2_base : (u16*)ctx->d_tok.p - pool_base; };
+  auto pool_runs = [&](bool fix) {
+    return fix ? (RunRec*)ctx->d_runs2.p - (pool2_base >> RUN_SHIFT) : (RunRec*)ctx->d_runs.p - (pool_base >> RUN_SHIFT);
+  };
   auto launch_lane = [&](const Item* d_items, SegResult* d_res, size_t n_it, bool fix) -> int {
     int rr = ensure(ctx, ctx->d_scratch, n_it * (size_t)K1_SCRATCH);
     if (rr) return rr;
@@ -673,7 +685,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       if (!d_out) return TBZ_E_ARG;
       const u32 n_it = (u32)n_items;
       fused_adler = format == TBZ_FORMAT_ZLIB && !ctx->k2_single && h_glob->n_big == 0 && !getenv("TBZ_NO_FUSED_ADLER");
-      K2Params k2{(const u16*)ctx->d_tok.p, (const RunRec*)ctx->d_runs.p, nullptr, nullptr, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, nullptr,
+      K2Params k2{pool_tok(false), pool_runs(false), nullptr, nullptr, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, nullptr,
                   (const u8*)d_in, (u8*)d_out, n_it, 0, 0, nullptr, nullptr, 0, 0, 0};
       if (h_glob->n_big < n_it) {
         k2.win_bytes = (u32)((h_glob->max_small + K2_SLACK + 63) & ~63ull);
@@ -829,8 +841,28 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if ((r = upload(ctx, ctx->d_items, fix))) return r;
     if ((r = ensure(ctx, ctx->d_res, fix.size() * sizeof(SegResult)))) return r;
     if ((r = record(ctx, 2))) return r;
-    if ((r = ensure(ctx, ctx->d_tok2, (size_t)in_extent * 16 + 64))) return r;
-    if ((r = ensure(ctx, ctx->d_runs2, (((size_t)in_extent * 8) >> RUN_SHIFT) * sizeof(RunRec) + 1024))) return r;
+    {
+      // the repair pools span from the earliest repair start to the end of the last repaired stream; they are laid
+      // out once (the first round's base stands: later rounds only start further on in the same streams)
+      uint64_t lo = ~0ull, hi = 0;
+      for (size_t k = 0; k < fix.size(); k++) {
+        lo = std::min(lo, fix[k].start_bit);
+        hi = std::max(hi, fix[k].end_byte * 8);
+      }
+      if (ctx->tim.fixup_rounds == 1) {
+        pool2_base = lo & ~(uint64_t)((1u << RUN_SHIFT) - 1);
+        pool2_hi = 0;
+      }
+      if (lo < pool2_base) return TBZ_E_INTERNAL;  // (cannot happen: a stream's repairs move forward)
+      if (hi > pool2_hi) {
+        // growing would move tokens that segments already refer to: size for the whole tail of the call at once
+        if (pool2_hi != 0) return TBZ_E_INTERNAL;
+        pool2_hi = in_extent * 8;
+        const uint64_t bits2 = pool2_hi - pool2_base;
+        if ((r = ensure(ctx, ctx->d_tok2, (size_t)bits2 * 2 + 256))) return r;
+        if ((r = ensure(ctx, ctx->d_runs2, ((size_t)bits2 >> RUN_SHIFT) * sizeof(RunRec) + 1024))) return r;
+      }
+    }
     if ((r = launch_k1((const Item*)ctx->d_items.p, (SegResult*)ctx->d_res.p, fix.size(), true))) return r;
     TBZ_HIP(hipGetLastError());
     if ((r = record(ctx, 3))) return r;
@@ -1029,7 +1061,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if (!bigs.empty()) {
       if ((r = upload(ctx, ctx->d_bigs, bigs))) return r;
       if ((r = ensure(ctx, ctx->d_recs, (size_t)n_recs * sizeof(SliceRec)))) return r;
-      K3sParams ks{(const BigSeg*)ctx->d_bigs.p, (const RunRec*)ctx->d_runs.p, (const RunRec*)ctx->d_runs2.p,
+      K3sParams ks{(const BigSeg*)ctx->d_bigs.p, pool_runs(false), pool_runs(true),
                    (Seg*)ctx->d_segs.p, (Group*)ctx->d_groups.p, (SliceRec*)ctx->d_recs.p, (u32)bigs.size()};
       TBZ_LAUNCH(tbz_k3_slice, bigs.size(), ctx->stream, ks);
       TBZ_HIP(hipMemcpyAsync(recs.data(), ctx->d_recs.p, (size_t)n_recs * sizeof(SliceRec), hipMemcpyDeviceToHost, ctx->stream));
@@ -1076,7 +1108,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     order.insert(order.end(), order_h.begin(), order_h.end());
     ctx->tim.n_groups = order.size();
     if ((r = upload(ctx, ctx->d_order, order))) return r;
-    K2Params k2{(const u16*)ctx->d_tok.p, (const RunRec*)ctx->d_runs.p, (const u16*)ctx->d_tok2.p, (const RunRec*)ctx->d_runs2.p,
+    K2Params k2{pool_tok(false), pool_runs(false), pool_tok(true), pool_runs(true),
                 (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, (const u32*)ctx->d_order.p, (const u8*)d_in, (u8*)d_out, 0, 0, 0, nullptr, nullptr,
                 0, 0, 0};
     if (!order_small.empty()) {
@@ -1328,6 +1360,7 @@ int tbz_ctx_create(int device_id, tbz_ctx** out_ctx) {
   if (const char* m = getenv("TBZ_K2_MODE")) ctx->k2_single = !strcmp(m, "single");
   if (const char* m = getenv("TBZ_K1H")) ctx->k1h = m[0] != '0';
   if (const char* m = getenv("TBZ_HIST")) ctx->sym_hist = strcmp(m, "off") != 0;
+  if (const char* m = getenv("TBZ_POOL_CAP_MIB")) ctx->pool_cap = (uint64_t)std::max(1, atoi(m)) << 20;
   if (const char* m = getenv("TBZ_FIND")) ctx->find_mode = !strcmp(m, "off") ? 0 : !strcmp(m, "always") ? 2 : 1;
   if (const char* m = getenv("TBZ_K1_MODE")) {
     if (!strcmp(m, "lane")) ctx->k1_mode = 1;
@@ -1361,12 +1394,70 @@ int tbz_last_timings(const tbz_ctx* ctx, tbz_timings* out) {
   return 0;
 }
 
+// the pipeline over a batch, in as many passes over consecutive streams as the pool cap asks for (scratch is
+// 18 octets per input octet of a pass's extent; one stream is never split: its segments share one token pool)
+static int inflate_passes(tbz_ctx* ctx, int format, size_t n, const void* d_in, const uint64_t* in_offs,
+                          const uint64_t* in_lens, void* d_out, const uint64_t* out_offs, const uint64_t* out_caps,
+                          tbz_result* results, bool size_only) {
+  if (!ctx || (n && (!in_offs || !in_lens))) return TBZ_E_ARG;
+  auto need = [&](uint64_t lo, uint64_t hi) { return (hi - lo) * 18; };
+  uint64_t lo = ~0ull, hi = 0;
+  for (size_t s = 0; s < n; s++)
+    if (in_lens[s]) {
+      lo = std::min(lo, in_offs[s]);
+      hi = std::max(hi, in_offs[s] + in_lens[s]);
+    }
+  if (n <= 1 || hi <= lo || need(lo, hi) <= ctx->pool_cap)
+    return tbz::inflate_core(ctx, format, n, d_in, in_offs, in_lens, d_out, out_offs, out_caps, results, size_only);
+  tbz_timings acc{};
+  size_t passes = 0;
+  for (size_t a = 0; a < n;) {
+    size_t b = a;
+    uint64_t plo = ~0ull, phi = 0;
+    while (b < n) {
+      const uint64_t l2 = in_lens[b] ? std::min(plo, in_offs[b]) : plo, h2 = in_lens[b] ? std::max(phi, in_offs[b] + in_lens[b]) : phi;
+      if (b > a && h2 > l2 && need(l2, h2) > ctx->pool_cap) break;
+      plo = l2;
+      phi = h2;
+      b++;
+    }
+    int r = tbz::inflate_core(ctx, format, b - a, d_in, in_offs + a, in_lens + a, d_out, size_only ? nullptr : out_offs + a,
+                              size_only ? nullptr : out_caps + a, results + a, size_only);
+    if (r) return r;
+    const tbz_timings& t = ctx->tim;
+    acc.scan_ms += t.scan_ms; acc.huff_ms += t.huff_ms; acc.lz_ms += t.lz_ms; acc.cksum_ms += t.cksum_ms;
+    acc.total_ms += t.total_ms; acc.find_ms += t.find_ms; acc.resolve_ms += t.resolve_ms;
+    acc.huff_launches += t.huff_launches; acc.fixup_rounds += t.fixup_rounds; acc.token_words += t.token_words;
+    acc.n_segments += t.n_segments; acc.n_groups += t.n_groups; acc.n_candidates += t.n_candidates;
+    acc.n_hgroups += t.n_hgroups; acc.k1_gang = t.k1_gang; acc.k2_kinds |= t.k2_kinds;
+    acc.scratch_bytes = std::max(acc.scratch_bytes, t.scratch_bytes);
+    passes++;
+    a = b;
+  }
+  acc.passes = (uint32_t)passes;
+  ctx->tim = acc;
+  return 0;
+}
+
 int tbz_inflate_batch_device(tbz_ctx* ctx, int format, size_t n, const void* d_in_base, const uint64_t* in_offs,
                              const uint64_t* in_lens, void* d_out_base, const uint64_t* out_offs,
                              const uint64_t* out_caps, tbz_result* results) {
   if (!ctx) return TBZ_E_ARG;
-  return tbz::inflate_core(ctx, format, n, d_in_base, in_offs, in_lens, d_out_base, out_offs, out_caps, results,
-                           false);
+  return inflate_passes(ctx, format, n, d_in_base, in_offs, in_lens, d_out_base, out_offs, out_caps, results, false);
+}
+
+int tbz_ctx_trim(tbz_ctx* ctx) {
+  using namespace tbz;
+  if (!ctx) return TBZ_E_ARG;
+  TBZ_HIP(hipSetDevice(ctx->device));
+  TBZ_HIP(hipStreamSynchronize(ctx->stream));
+  for (auto* b : all_pools(ctx))
+    if (b != &ctx->d_crc_tab && b->p) {
+      TBZ_HIP(hipFree(b->p));
+      b->p = nullptr;
+      b->cap = 0;
+    }
+  return 0;
 }
 
 int tbz_inflate_device(tbz_ctx* ctx, int format, const void* d_in, size_t in_len, void* d_out, size_t out_cap,
@@ -1402,8 +1493,8 @@ static int stage_batch(tbz_ctx* ctx, int format, size_t n, const uint8_t* const*
     }
   uint32_t n_h2d = 0;
   for (size_t i = 0; i < n; i++) n_h2d += in_lens[i] ? 1u : 0u;
-  r = inflate_core(ctx, format, n, ctx->d_in_stage.p, io.data(), il.data(), size_only ? nullptr : ctx->d_out_stage.p,
-                   oo.data(), oc.data(), results, size_only);
+  r = inflate_passes(ctx, format, n, ctx->d_in_stage.p, io.data(), il.data(), size_only ? nullptr : ctx->d_out_stage.p,
+                     oo.data(), oc.data(), results, size_only);
   ctx->tim.h2d_copies = n_h2d;
   if (r) return r;
   if (!size_only) {

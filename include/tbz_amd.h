@@ -118,7 +118,8 @@ typedef struct tbz_timings {
   uint64_t n_hgroups;    /* LZ77 groups decoded against a symbolic 32 KiB history (resolved by K6) */
   uint64_t scratch_bytes;/* device scratch held by the context after the call (token pool, run tables, ...) */
   uint32_t h2d_copies;   /* host->device input copies of the call (tbz_inflate / _size: 1 per staging) */
-  uint32_t reserved;
+  uint32_t passes;       /* 0/1: one pass; otherwise the batch was decoded in this many passes over consecutive streams
+                            because its scratch would have exceeded the pool cap */
 } tbz_timings;
 
 typedef struct tbz_ctx tbz_ctx;
@@ -130,6 +131,9 @@ typedef struct tbz_ctx tbz_ctx;
 int tbz_ctx_create(int device_id, tbz_ctx** out_ctx);
 void tbz_ctx_destroy(tbz_ctx* ctx);
 int tbz_abi_version(void);
+/* Release the context's device scratch (token pools, run tables, staging buffers: they only grow otherwise and are
+ * held until tbz_ctx_destroy).  A long-lived host calls this after an unusually large call. */
+int tbz_ctx_trim(tbz_ctx* ctx);
 const char* tbz_strerror(int code);
 const char* tbz_last_error(const tbz_ctx* ctx);
 int tbz_device_count(void);

@@ -284,6 +284,53 @@ def zlib_wrap(raw, plain):
     return b"\x78\x9c" + raw + struct.pack(">I", zlib.adler32(plain))
 
 
+def case_scratch_bounds(eng):
+    """Device scratch is bounded by what a pass decodes: (1) streams far apart in one buffer pay for their own extent
+    only (token pool and run tables are addressed relative to the call's first stream octet, not to the base
+    pointer); (2) a batch whose scratch would exceed the pool cap is decoded in several passes over consecutive
+    streams, results unchanged; (3) tbz_ctx_trim gives the scratch back."""
+    plains = [_mixed_plain(30_000 + 977 * i, 40 + i) for i in range(10)]
+    streams = [zlib.compress(p, 6) for p in plains]
+    os.environ["TBZ_POOL_CAP_MIB"] = "1"
+    try:
+        e2 = T.Engine(eng.device, lib_path=eng.lib._name)
+    finally:
+        os.environ.pop("TBZ_POOL_CAP_MIB", None)
+    try:
+        outs = [bytearray(len(p)) for p in plains]
+        res = e2.inflate_batch(streams, FMT["zlib"], outs)
+        t = e2.timings()
+        assert t.passes >= 2, t.passes                      # ~150 KB of streams x 18 > 1 MiB
+        for r, o, p in zip(res, outs, plains):
+            assert r.status == 0 and r.out_len == len(p) and bytes(o) == p and (r.flags & 1)
+        # (1) two streams 48 MiB apart in one device buffer: scratch follows the streams, not the gap
+        gap = 48 << 20
+        d_in = e2.malloc(gap + len(streams[1]) + 64)
+        d_out = e2.malloc(len(plains[0]) + len(plains[1]) + 64)
+        try:
+            e2.h2d(d_in + gap, streams[1])
+            r1 = e2.inflate_batch_device(d_in, [gap], [len(streams[1])], d_out, [0], [len(plains[1])], FMT["zlib"])
+            assert r1[0].status == 0 and r1[0].out_len == len(plains[1])
+            assert e2.timings().scratch_bytes < 64 * len(streams[1]) + (8 << 20), e2.timings().scratch_bytes
+            got = bytearray(len(plains[1]))
+            e2.d2h(got, d_out)
+            assert bytes(got) == plains[1]
+        finally:
+            e2.free(d_in)
+            e2.free(d_out)
+        # (3)
+        e2.trim()
+        out = bytearray(len(plains[2]))
+        r = e2.inflate(streams[2], FMT["zlib"], out)          # works again after a trim
+        assert r.status == 0 and bytes(out) == plains[2]
+        small = e2.timings().scratch_bytes
+        e2.trim()
+        r = e2.inflate(streams[2], FMT["zlib"], out)
+        assert r.status == 0 and e2.timings().scratch_bytes == small
+    finally:
+        e2.close()
+
+
 def case_history_across_groups(eng):
     """Z_SYNC_FLUSH stream whose middle segment copies nothing from before itself (incompressible octets: it opens a
     LZ77 group of its own) while the segment after it copies from the FIRST one, i.e. from before its predecessor's
@@ -797,7 +844,7 @@ ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_
              case_noflush_streams, case_fixed_block_chains, case_history_across_groups,
              case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_device_buffers,
              case_checksum_kernels, case_deep_codes, case_chunked_resume, case_gzip_members,
-             case_pointer_contexts, case_container_headers, case_fuzz]
+             case_pointer_contexts, case_container_headers, case_scratch_bounds, case_fuzz]
 # the cases whose behaviour depends on the K1 flavour (forced-flavour runs skip the rest: checksums, device
 # buffers and the replay protocol go through the same engine calls whatever decodes the Huffman codes)
 K1_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,

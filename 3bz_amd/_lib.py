@@ -32,13 +32,15 @@ class Timings(C.Structure):
 
 
 assert C.sizeof(Result) == 64
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)   # tbz_alloc_fn
 
 # every symbol include/tbz_amd.h declares
 SYMBOLS = [
     "tbz_ctx_create", "tbz_ctx_destroy", "tbz_ctx_trim", "tbz_abi_version", "tbz_strerror", "tbz_last_error",
-    "tbz_device_count", "tbz_inflate", "tbz_inflate_size", "tbz_inflate_batch", "tbz_inflate_device",
+    "tbz_device_count", "tbz_inflate", "tbz_inflate_size", "tbz_inflate_alloc", "tbz_inflate_batch", "tbz_inflate_device",
     "tbz_inflate_batch_device", "tbz_adler32_device", "tbz_crc32_device", "tbz_device_malloc",
     "tbz_device_free", "tbz_memcpy_h2d", "tbz_memcpy_d2h", "tbz_last_timings",
+    "tbz_session_create", "tbz_session_destroy", "tbz_session_feed", "tbz_session_decompress",
 ]
 
 
@@ -70,6 +72,7 @@ def load(path=None):
     L.tbz_last_error.argtypes = [vp]
     L.tbz_inflate.argtypes = [vp, C.c_int, vp, sz, vp, sz, C.POINTER(Result)]
     L.tbz_inflate_size.argtypes = [vp, C.c_int, vp, sz, C.POINTER(Result)]
+    L.tbz_inflate_alloc.argtypes = [vp, C.c_int, vp, sz, ALLOC_FN, vp, C.POINTER(Result)]
     L.tbz_inflate_batch.argtypes = [vp, C.c_int, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz),
                                     C.POINTER(Result)]
     L.tbz_inflate_device.argtypes = [vp, C.c_int, vp, sz, vp, sz, C.POINTER(Result)]
@@ -82,6 +85,11 @@ def load(path=None):
     L.tbz_memcpy_h2d.argtypes = [vp, vp, vp, sz]
     L.tbz_memcpy_d2h.argtypes = [vp, vp, vp, sz]
     L.tbz_last_timings.argtypes = [vp, C.POINTER(Timings)]
+    L.tbz_session_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.tbz_session_destroy.argtypes = [vp]
+    L.tbz_session_destroy.restype = None
+    L.tbz_session_feed.argtypes = [vp, vp, sz, C.c_int]
+    L.tbz_session_decompress.argtypes = [vp, vp, sz, C.POINTER(Result)]
     for s in SYMBOLS:
         getattr(L, s)  # AttributeError if the ABI is incomplete
     return L

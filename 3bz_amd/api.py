@@ -84,6 +84,22 @@ class Engine:
                                          _addr(out), len(out) if out is not None else 0, C.byref(res)))
         return res
 
+    def inflate_alloc(self, data, fmt, start=0, end=None):
+        """one decode, the result buffer allocated once the size is known: returns (result, bytearray or None)"""
+        end = len(data) if end is None else end
+        res = _lib.Result()
+        box = {}
+
+        def alloc(_user, n):
+            box["buf"] = bytearray(n)
+            return C.addressof((C.c_char * n).from_buffer(box["buf"])) if n else 0
+
+        cb = _lib.ALLOC_FN(alloc)
+        base = _addr(data)
+        self._check(self.lib.tbz_inflate_alloc(self._ctx, fmt, (base or 0) + start if base else None, end - start, cb,
+                                               None, C.byref(res)))
+        return res, box.get("buf")
+
     def inflate_size(self, data, fmt, start=0, end=None):
         end = len(data) if end is None else end
         res = _lib.Result()
@@ -139,6 +155,24 @@ class Engine:
 
     def d2h(self, out, d_src, n=None):
         self._check(self.lib.tbz_memcpy_d2h(self._ctx, _addr(out), d_src, len(out) if n is None else n))
+
+    # ---- sessions (the chunked protocol with the state on the device)
+    def session_create(self, fmt):
+        p = C.c_void_p()
+        self._check(self.lib.tbz_session_create(self._ctx, fmt, C.byref(p)))
+        return p
+
+    def session_destroy(self, sess):
+        if sess and getattr(self, "_ctx", None):
+            self.lib.tbz_session_destroy(sess)
+
+    def session_feed(self, sess, addr, n, on_device=False):
+        self._check(self.lib.tbz_session_feed(sess, addr, n, 1 if on_device else 0))
+
+    def session_decompress(self, sess, out_addr, cap):
+        res = _lib.Result()
+        self._check(self.lib.tbz_session_decompress(sess, out_addr, cap, C.byref(res)))
+        return res
 
     def trim(self):
         """release the context's device scratch (it only grows otherwise)"""
@@ -263,16 +297,17 @@ class DeflateState:
         self.input_underrun = False
         self._calls = 0
         self.result = None
-        self._seen = bytearray()   # every input octet given to this state (resume replays it)
-        self._full = None          # scratch vector of the last replay: output octets from _full_out on
-        self._full_out = 0
-        self._delivered = 0        # output octets handed out so far
-        # resume base: a proven block boundary (tbz_result.in_consumed) from which replays start
-        self._base_in = 0          # input octets before it
-        self._base_out = 0         # output octets before it
-        self._base_ck = None       # checksum of those output octets (None: the format's initial value)
-        self._cand = None          # (in, out, ck) of the latest boundary reported, adopted once its output is delivered
-        self._no_base = False      # the stream needs history across boundaries (or failed): replay from 0
+        self._sess = None          # tbz_session: the resumable part of the state lives on the device
+        self._eng = None
+        self._fed = 0              # input octets given to the session so far
+
+    def __del__(self):
+        try:
+            if self._sess is not None and self._eng is not None:
+                self._eng.session_destroy(self._sess)
+                self._sess = None
+        except Exception:
+            pass
 
 
 class ZlibState(DeflateState):
@@ -323,180 +358,66 @@ def replace_output_buffer(state, buffer):
     state.output_overflow = False
 
 
-def _chain_checksum(eng, fmt, d_buf, n, ck):
-    """checksum of n more output octets at d_buf, continuing from ck (None = initial value)"""
-    if fmt == FORMATS["zlib"]:
-        a = 1 if ck is None else ck
-        s1, s2 = eng.adler32_device(d_buf, n, a & 0xFFFF, a >> 16)
-        return s1 | (s2 << 16)
-    return eng.crc32_device(d_buf, n, 0 if ck is None else ck)
-
-
-def _replay(eng, state):
-    """decode everything the state has seen from its resume base on (one engine call into a device scratch
-    buffer).  Leaves the octets in state._full (they continue the output at state._full_out), the status in
-    state._full_status / _full_flags and the latest proven boundary in state._cand."""
-    deflate = FORMATS["deflate"]
-    while True:
-        base_in, base_out = state._base_in, state._base_out
-        tail = bytes(state._seen[base_in:])
-        fmt = state.format if base_in == 0 else deflate   # past the container header: blocks only
-        status, flags, full, cand = 0, 0, bytearray(0), None
-        size = eng.inflate_size(tail, fmt)
-        res = size
-        status = size.status
-        if status >= 0:
-            n = int(size.out_total)
-            d_in, d_out = eng.malloc(len(tail) + 64), eng.malloc(n + 64)
-            try:
-                eng.h2d(d_in, tail)
-                # (one octet of slack: a stored block cut off exactly at the end of a FULL buffer is output-overflow in
-                # the reference, deflate.lisp:538-573 — this scratch buffer must never be the reason for a status)
-                res = eng.inflate_device(d_in, len(tail), d_out, n + 1, fmt)
-                status, flags = res.status, res.flags
-                got = int(res.out_len) if status >= 0 else 0
-                if status == _lib.FINISHED and base_in and state.format != deflate:
-                    # the engine decoded raw blocks: the container's trailer is checked here as zlib.lisp:80-95 /
-                    # gzip.lisp:78-106 do (checksum of ALL output = the base's, continued over these octets)
-                    ck = _chain_checksum(eng, state.format, d_out, got, state._base_ck)
-                    end = int(res.in_consumed)
-                    have = len(tail) - end
-                    flags |= 2
-                    if state.format == FORMATS["zlib"]:
-                        if have < 4:
-                            status = _lib.INPUT_UNDERRUN
-                        elif int.from_bytes(tail[end:end + 4], "big") != ck:
-                            status = -11
-                    else:
-                        if have < 4:
-                            status = _lib.INPUT_UNDERRUN
-                        elif int.from_bytes(tail[end:end + 4], "little") != ck:
-                            status = -16
-                        elif have < 8:
-                            status = _lib.INPUT_UNDERRUN
-                elif status == _lib.INPUT_UNDERRUN and not (flags & 2) and res.in_consumed > 0 and not state._no_base:
-                    b_out = int(res.boundary_out)
-                    ck = None if state.format == deflate else _chain_checksum(eng, state.format, d_out, b_out,
-                                                                              state._base_ck)
-                    cand = (base_in + int(res.in_consumed), base_out + b_out, ck)
-                if status >= 0 and got:
-                    full = bytearray(got)
-                    eng.d2h(full, d_out, got)
-            finally:
-                eng.free(d_in)
-                eng.free(d_out)
-        if status < 0 and base_in:
-            # blocks that reach back across the boundary (sync-flush history) fail as "distance before start";
-            # whatever the reason, the whole stream decides: replay from the first octet, for good
-            state._base_in, state._base_out, state._base_ck, state._cand, state._no_base = 0, 0, None, None, True
-            continue
-        state.result = res
-        state._full, state._full_out = full, base_out
-        state._full_status, state._full_flags = status, flags
-        if cand is not None:
-            state._cand = cand
-        return
+def _out_addr(buf, offset):
+    if len(buf) - offset <= 0:
+        return None
+    if isinstance(buf, bytearray) or isinstance(buf, memoryview):
+        return C.addressof((C.c_char * len(buf)).from_buffer(buf)) + offset
+    return buf.ctypes.data + offset  # numpy uint8 array
 
 
 def decompress(context, state, engine=None):
-    """api.lisp:3-10.  One call over everything the context holds, on the device.
+    """api.lisp:3-10: decode what the context holds into the state's output buffer, from output-offset on.
 
-    All three outcomes are reported as the reference does — finished / input-underrun / output-overflow flags,
-    octet count, the correct prefix in the buffer.
+    All three outcomes are reported as the reference does — finished / input-underrun / output-overflow flags, the
+    octet count, the octets in the buffer — and the call can be repeated as in the reference's chunked protocol
+    (deflate.lisp:114-137): with a context that brings more input after input-underrun, with a new buffer
+    (replace-output-buffer) after output-overflow.  The resumable part of the state is a tbz_session on the device
+    (include/tbz_amd.h): unconsumed input, the 32 KiB window, octets decoded beyond the buffer's end; a call costs the
+    new input plus the one block it continues.  A stream that turns out to be invalid raises in the call in which the
+    reference would have met the error, after the output before it has been handed out.
 
-    RESUMING (the chunked protocol of deflate.lisp:114-137: more input after input-underrun, a new buffer after
-    output-overflow) is done by REPLAY on the device from the last proven block boundary: the state keeps the
-    input octets it has been given; a call that brings new input decodes again from the resume base (one engine
-    call into a device scratch buffer) and hands out the octets beyond those already delivered; a call that only
-    brings a new output buffer hands out the next slice.  The resume base is the boundary the engine reports for
-    an unfinished stream (tbz_result.in_consumed / boundary_out: the chain of blocks landed there), adopted once
-    all output before it has been delivered; the tail is then decoded as raw deflate, the checksum continues from
-    the base's (tbz_adler32_device / tbz_crc32_device chain) and the container trailer is compared here.  A tail
-    that fails for any reason — blocks that copy from before the boundary, as after Z_SYNC_FLUSH, fail as
-    "distance before start" — sends the state back to replaying from the first octet, so the answer is always
-    the whole stream's.  Cost per call that brings input: O(octets since the last flush boundary) for
-    flush-delimited streams, O(prefix) otherwise.  Same flags, counts and octets as the reference call by call on
-    valid streams (tests: case_chunked_resume).  Deviation: a stream that turns out to be INVALID is reported
-    when the replay first meets the error, which can be a call earlier than the reference (which first hands out
-    the output before the error, and a checksum mismatch only after the last octet)."""
+    A pointer context's memory goes to the session as it is: a host pointer is copied once to the device, a device
+    pointer (octet-pointer over HBM) device to device."""
     eng = engine or default_engine()
-    first = state._calls == 0
+    if state._sess is None:
+        state._sess = eng.session_create(state.format)
+        state._eng = eng
     state._calls += 1
     state.input_underrun = False
     state.output_overflow = False
-    if first and isinstance(context, OctetPointerContext) and valid_octet_pointer(context.op):
-        # foreign memory goes to the engine as it is: a host pointer through tbz_inflate, a device pointer through
-        # tbz_inflate_device (no staging copy of the input); the octets are only copied if the state must resume
-        out = state.output_buffer
-        n_in = context.end - context.offset
-        if context.op.device:
-            d_out = eng.malloc(len(out) + 64)
-            try:
-                res = eng.inflate_device(context.pointer + context.offset, n_in, d_out, len(out), state.format)
-                if res.status >= 0 and res.out_len:
-                    eng.d2h(out, d_out, int(res.out_len))
-            finally:
-                eng.free(d_out)
-        else:
-            res = _lib.Result()
-            eng._check(eng.lib.tbz_inflate(eng._ctx, state.format, context.pointer + context.offset, n_in,
-                                           _addr(out), len(out), C.byref(res)))
-        new = b"" if res.status in (_lib.FINISHED,) or res.status < 0 else _context_octets(eng, context)
-    else:
-        new = _context_octets(eng, context)
-        res = None
-    if first:
-        out = state.output_buffer
-        if res is None:
-            res = eng.inflate(new, state.format, out)
-        state.result = res
-        state._seen = bytearray(new)
-        state._full = None
-        if res.status < 0:
-            raise ThreeBzError(res.status, eng.strerror(res.status))
-        state.finished = res.status == _lib.FINISHED
-        state.input_underrun = res.status == _lib.INPUT_UNDERRUN
-        state.output_overflow = res.status == _lib.OUTPUT_OVERFLOW
-        state.output_offset = res.out_len
-        state._delivered = res.out_len
-        context.offset = context.end if not state.finished else context.offset + res.in_consumed
-        # the reference's early returns: zlib header underrun and every gzip header/trailer underrun
-        # `(return-from … 0)` (zlib.lisp:113-114, gzip.lisp:86,:99,:116…); otherwise output-offset
-        if state.input_underrun and state.format == FORMATS["gzip"] and (res.flags & 2):
-            return 0  # final block decoded but crc32 / ISIZE cut off: (return-from decompress-gzip 0)
-        return res.out_len
     if state.finished:
         return state.output_offset
-    # ---- resume by replay from the base
-    if new or state._full is None:
-        state._seen += new
+    fed_before = state._fed
+    start_offset = context.offset
+    n_in = context.end - context.offset
+    if isinstance(context, OctetPointerContext):
+        if not valid_octet_pointer(context.op):   # (assert (valid-octet-pointer (op context))) io-mmap.lisp:66
+            raise ThreeBzError(-22, "octet pointer used outside its scope (or null / empty)")
+        if n_in > 0:
+            eng.session_feed(state._sess, context.pointer + context.offset, n_in, on_device=context.op.device)
+    elif n_in > 0:
+        mv = memoryview(context.octet_vector)[context.offset:context.end]
+        data = bytes(mv)   # (pinned for the duration of the call, as cffi:with-pointer-to-vector-data does)
+        eng.session_feed(state._sess, _addr(data), n_in)
+    if n_in > 0:
+        state._fed += n_in
         context.offset = context.end
-        c = state._cand
-        if c is not None and c[1] <= state._delivered and c[0] > state._base_in:
-            state._base_in, state._base_out, state._base_ck = c   # everything before it has been handed out
-        state._cand = None
-        _replay(eng, state)
-    full, status = state._full, state._full_status
-    if status < 0:
-        raise ThreeBzError(status, eng.strerror(status))
-    avail = state._full_out + len(full)
+    out = state.output_buffer
     off = state.output_offset
-    give = max(0, min(len(state.output_buffer) - off, avail - state._delivered))
-    src = state._delivered - state._full_out
-    state.output_buffer[off:off + give] = full[src:src + give]
-    state.output_offset = off + give
-    state._delivered += give
-    pending = avail - state._delivered
-    stored_cut = status == _lib.INPUT_UNDERRUN and (state._full_flags & 4) and \
-        state.output_offset == len(state.output_buffer)
-    if pending > 0 or stored_cut:
-        # (stored_cut: the input ran out inside a stored block just where this buffer is full — the reference
-        # asks for output space first there, deflate.lisp:538-573)
-        state.output_overflow = True
-        return state.output_offset
-    state.finished = status == _lib.FINISHED
-    state.input_underrun = status == _lib.INPUT_UNDERRUN
-    if state.input_underrun and state.format == FORMATS["gzip"] and (state._full_flags & 2):
+    res = eng.session_decompress(state._sess, _out_addr(out, off), max(0, len(out) - off))
+    state.result = res
+    state.output_offset = off + int(res.out_len)
+    if res.status < 0:
+        raise ThreeBzError(res.status, eng.strerror(res.status))
+    state.finished = res.status == _lib.FINISHED
+    state.input_underrun = res.status == _lib.INPUT_UNDERRUN
+    state.output_overflow = res.status == _lib.OUTPUT_OVERFLOW
+    if state.finished:
+        # the context stands just behind the stream (its trailer included), as the reference leaves it
+        context.offset = start_offset + max(0, int(res.in_consumed) - fed_before)
+    # the reference's early return: gzip's final block decoded but crc32 / ISIZE cut off -> (return-from decompress-gzip 0)
+    if state.input_underrun and state.format == FORMATS["gzip"] and (res.flags & 2):
         return 0
     return state.output_offset
 
@@ -506,8 +427,8 @@ def decompress_vector(compressed, format="zlib", start=0, end=None, output=None,
 
     With `output`: a single call; not finished => error "incomplete ~a stream" / "not enough space
     to decompress ~a stream" (api.lisp:41-47).  Without: the reference grows 32 KiB buffers by
-    doubling and gathers (api.lisp:48-65); here the size comes from the engine's count pass, so the
-    result buffer is allocated exactly once."""
+    doubling and gathers (api.lisp:48-65); here the engine decodes once and the result buffer is
+    allocated when the size is known (tbz_inflate_alloc: one input copy, one Huffman pass)."""
     fmt = FORMATS[format] if isinstance(format, str) else format
     name = format if isinstance(format, str) else {0: "deflate", 1: "zlib", 2: "gzip"}[fmt]
     end = len(compressed) if end is None else end
@@ -521,18 +442,12 @@ def decompress_vector(compressed, format="zlib", start=0, end=None, output=None,
                 raise ThreeBzError(-20, "incomplete %s stream" % name)
             raise ThreeBzError(-21, "not enough space to decompress %s stream" % name)
         return output, res.out_len
-    q = eng.inflate_size(compressed, fmt, start=start, end=end)
-    if q.status < 0:
-        raise ThreeBzError(q.status, eng.strerror(q.status))
-    if q.status == _lib.INPUT_UNDERRUN:  # (assert (not (ds-input-underrun state))) api.lisp:55
-        raise ThreeBzError(-20, "incomplete %s stream" % name)
-    buf = bytearray(q.out_total)
-    res = eng.inflate(compressed, fmt, buf, start=start, end=end)
+    res, buf = eng.inflate_alloc(compressed, fmt, start=start, end=end)
     if res.status < 0:
         raise ThreeBzError(res.status, eng.strerror(res.status))
-    if res.status != _lib.FINISHED:
+    if res.status != _lib.FINISHED:   # (assert (not (ds-input-underrun state))) api.lisp:55
         raise ThreeBzError(-20, "incomplete %s stream" % name)
-    return buf, res.out_len
+    return (buf if buf is not None else bytearray(0)), res.out_len
 
 
 # ------------------------------------------------------------------------------------------------
@@ -579,17 +494,12 @@ def decompress_gzip_members(compressed, start=0, end=None, engine=None):
             continue
         # not a whole member: a later candidate lies inside this member's data, or the member is damaged,
         # or garbage follows it.  Decode from `lo` to the end (the ordinary one-stream call decides).
-        q = eng.inflate_size(data, FORMATS["gzip"], start=lo)
-        if q.status < 0:
-            raise ThreeBzError(q.status, eng.strerror(q.status))
-        if q.status == _lib.INPUT_UNDERRUN:
-            raise ThreeBzError(-20, "incomplete gzip stream")
-        buf = bytearray(q.out_total)
-        r = eng.inflate(data, FORMATS["gzip"], buf, start=lo)
+        r, buf = eng.inflate_alloc(data, FORMATS["gzip"], start=lo)
         if r.status < 0:
             raise ThreeBzError(r.status, eng.strerror(r.status))
         if r.status != _lib.FINISHED:
             raise ThreeBzError(-20, "incomplete gzip stream")
+        buf = buf if buf is not None else bytearray(0)
         members.append(buf)
         nxt = lo + r.in_consumed
         while i < len(cands) and bounds[i] < nxt:

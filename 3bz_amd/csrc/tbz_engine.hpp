@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -182,6 +183,8 @@ struct StreamPlan {
   uint64_t boundary_bit = 0;  // last flush boundary the chain is known to have landed on (resume / shard seam)
   uint64_t boundary_out = 0;  // output octets produced before it
   bool stored_cut = false;    // the input ran out inside a stored block's payload
+  bool blk_known = false;     // not finished: where a resumed decode would start (CoreOpts)
+  uint64_t blk_bit = 0, blk_out = 0;
   uint32_t trailer0 = 0, trailer1 = 0, trailer_have = 0;
   bool saw_final = false;
   uint32_t seg_first = 0, seg_count = 0;
@@ -298,13 +301,40 @@ static int run_adler_groups(tbz_ctx* ctx, const std::vector<uint32_t>& first_gro
   return 0;
 }
 
+// what a resumable session (tbz_session_*) and the allocate-once entry point ask of the pipeline beyond a plain call;
+// only for calls of ONE stream
+struct CoreOpts {
+  // ---- in
+  uint32_t start_bit_off = 0;  // the stream's first block header sits at this bit of its first octet (a continuation:
+                               // raw blocks entered at a block boundary, deflate.lisp:518-528 needs no other state)
+  uint64_t hist_len = 0;       // octets of earlier output that precede this call's output in the buffer (at
+                               // out_off - hist_len ...): matches may reach into them (deflate.lisp:343-352, the window)
+  bool prefix_on_error = false;  // a stream that fails is still laid out and decoded up to the failing token
+                                 // (tbz_result.out_total = that many octets), as a front-to-back decoder would have
+  // the output buffer is obtained once the size is known: total octets -> device pointer of a buffer in which the
+  // stream's output starts at octet `out_offs[0]` (and that holds total + 64 octets from there)
+  std::function<void*(uint64_t total)> alloc;
+  // ---- out (stream not finished)
+  bool blk_known = false;
+  uint64_t blk_bit = 0;        // start of the block in which the input ended (or the position where it ended, when that is
+                               // where a block starts), in bits from the stream's first octet
+  uint64_t blk_out = 0;        // octets produced before that block
+  uint64_t end_bit = 0;        // finished: bit position after the final block (octet-aligned, before any trailer the
+                               // engine did not parse because the format was raw deflate)
+  int32_t first_error = 0;     // prefix_on_error: the status a plain call would have reported (0 if none)
+};
+
 // the whole pipeline on device-resident buffers
 static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, const uint64_t* in_offs,
                         const uint64_t* in_lens, void* d_out, const uint64_t* out_offs, const uint64_t* out_caps,
-                        tbz_result* results, bool size_only) {
+                        tbz_result* results, bool size_only, CoreOpts* opt = nullptr) {
   if (!ctx || !results || (n && (!in_offs || !in_lens))) return TBZ_E_ARG;
   if (format < 0 || format > 2) return TBZ_E_ARG;
   if (!size_only && n && (!out_offs || !out_caps)) return TBZ_E_ARG;
+  if (opt && n != 1) return TBZ_E_ARG;
+  const uint64_t hist_len = opt ? opt->hist_len : 0;
+  if (hist_len && !ctx->sym_hist) return TBZ_E_UNSUPPORTED;  // (TBZ_HIST=off: no way to reach octets of an earlier call)
+  const uint32_t bit_off = opt ? opt->start_bit_off : 0;
   TBZ_HIP(hipSetDevice(ctx->device));
   ctx->tim = tbz_timings{};
   ctx->gang_rounds = ctx->gang_valid = 0;
@@ -360,7 +390,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     K0Params k0{(const u8*)d_in, (const u64*)ctx->d_str_off.p, (const u64*)ctx->d_str_len.p,
                 (const u32*)ctx->d_tile_first.p, (u32)n, (u32)tiles, (u32*)ctx->d_tile_counts.p,
                 (u32*)ctx->d_tile_offsets.p, (u64*)ctx->d_markers.p, (u64*)ctx->d_k0_slots.p,
-                (u32*)ctx->d_k0_fm.p + 2, (u32*)ctx->d_k0_fm.p, (Item*)ctx->d_items.p, (u32)format, 0};
+                (u32*)ctx->d_k0_fm.p + 2, (u32*)ctx->d_k0_fm.p, (Item*)ctx->d_items.p, (u32)format, 0, bit_off};
     const size_t max_items = tiles * (size_t)K0_SLOTS + n;
     TBZ_LAUNCH(tbz_k0_scan_tiles, tiles, ctx->stream, k0);
     TBZ_LAUNCH(tbz_k0_scan_offsets, 1, ctx->stream, k0);
@@ -398,7 +428,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     for (size_t s = 0; s < n; s++) {
       StreamPlan& S = sp[s];
       Item it;
-      it.start_bit = S.in_off * 8;
+      it.start_bit = S.in_off * 8 + (s == 0 ? bit_off : 0);
       it.limit_bit = ~0ull;
       it.end_byte = S.in_off + S.in_len;
       it.stream = (uint32_t)s;
@@ -448,7 +478,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
                    (const u32*)ctx->d_kb_tf.p, (u32)n, (u32)tiles_b, (u64*)ctx->d_kb_slots.p, (u32*)ctx->d_kb_counts.p,
                    (u32*)ctx->d_kb_offsets.p, (u64*)ctx->d_kb_cands.p, (u32*)ctx->d_kb_fc.p, (u32*)ctx->d_kb_head.p,
                    (const u64*)ctx->d_markers.p, (const u32*)ctx->d_k0_fm.p + 2, (u64*)ctx->d_markers2.p,
-                   (u32*)ctx->d_kb_fm2.p + 2, (u32*)ctx->d_kb_fm2.p};
+                   (u32*)ctx->d_kb_fm2.p + 2, (u32*)ctx->d_kb_fm2.p, bit_off};
       TBZ_LAUNCH(tbz_k0b_scan, tiles_b, ctx->stream, kb);
       TBZ_LAUNCH(tbz_k0b_validate, tiles_b, ctx->stream, kb);
       TBZ_LAUNCH(tbz_k0b_offsets, 1, ctx->stream, kb);
@@ -474,6 +504,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         k0m.items = (Item*)ctx->d_items.p;
         k0m.format = (u32)format;
         k0m.second_pass = 1;
+        k0m.start_bit_off = bit_off;
         TBZ_LAUNCH(tbz_k0_items, ((size_t)n_mark + n + 63) / 64, ctx->stream, k0m);
         d_markers_cur = (const u64*)ctx->d_markers2.p;
         d_first_marker = (const u32*)ctx->d_kb_fm2.p + 2;
@@ -681,6 +712,11 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     TBZ_HIP(hipMemcpyAsync(h_k3s, ctx->d_k3_streams.p, (n + 1) * sizeof(K3Stream), hipMemcpyDeviceToHost, ctx->stream));
     TBZ_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
     if ((r = record(ctx, 4))) return r;
+    if (!size_only && opt && opt->alloc) {  // the buffer comes once the size is known: wait for the stream record
+      TBZ_HIP(hipEventSynchronize(ctx->ev[7]));
+      d_out = opt->alloc(h_k3s[0].total_out);
+      if (!d_out) return TBZ_E_NOMEM;
+    }
     if (!size_only) {
       if (!d_out) return TBZ_E_ARG;
       const u32 n_it = (u32)n_items;
@@ -726,8 +762,18 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       S.trailer1 = k.last.trailer1;
       S.trailer_have = k.last.trailer_have;
       S.in_end_bit = k.last.end_bit;
-      S.boundary_bit = S.n_items > 1 ? k.last_start : 0;
+      S.boundary_bit = (S.n_items > 1 && !(k.last_start & 7)) ? k.last_start : 0;
       S.boundary_out = k.total_out - k.last.out_bytes;
+      if (k.last.status == SEG_UNDERRUN) {
+        S.blk_known = true;
+        if (k.last.land_marker == 0) {
+          S.blk_bit = (uint64_t)k.last.trailer0 | ((uint64_t)k.last.trailer1 << 32);
+          S.blk_out = k.total_out - k.last.out_bytes + k.last.reserved;
+        } else {
+          S.blk_bit = k.last_start;
+          S.blk_out = k.total_out - k.last.out_bytes;
+        }
+      }
       S.stored_cut = k.last.status == SEG_UNDERRUN && k.last.pad == 2;
       if (k.last.status == SEG_UNDERRUN && k.last.pad == 1 && !(k.last.end_bit & 7)) {
         S.boundary_bit = k.last.end_bit;
@@ -769,14 +815,16 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     else if (h.continues) S.next_continues = true;  // nothing emitted: carry the flag forward
     S.total_out += q.out_bytes;
     ctx->tim.token_words += q.tok_words;
-    ctx->gang_rounds += q.reserved >> 32;
-    ctx->gang_valid += q.reserved & 0xffffffffu;
+    if (q.status != SEG_UNDERRUN) {
+      ctx->gang_rounds += q.reserved >> 32;
+      ctx->gang_valid += q.reserved & 0xffffffffu;
+    }
     if (q.status == SEG_LANDED) {
       uint32_t mk = is_fixup ? q.land_marker : 0;
       if (is_fixup) S.cur_item = S.first_item + 1 + (mk - S.first_marker);
       else S.cur_item += 1;
-      if (S.cur_item < S.first_item + S.n_items) {
-        S.boundary_bit = items[S.cur_item].start_bit;
+      if (S.cur_item < S.first_item + S.n_items && !(items[S.cur_item].start_bit & 7)) {
+        S.boundary_bit = items[S.cur_item].start_bit;  // (octet-aligned boundaries only: that is what in_consumed can say)
         S.boundary_out = S.total_out;
       }
       return;
@@ -801,6 +849,14 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       S.status = TBZ_INPUT_UNDERRUN;
       S.in_end_bit = q.end_bit;
       S.stored_cut = q.pad == 2;
+      S.blk_known = true;
+      if (q.land_marker == 0) {  // the block in which the input ran out (K1 reports its start and the octets before it)
+        S.blk_bit = (uint64_t)q.trailer0 | ((uint64_t)q.trailer1 << 32);
+        S.blk_out = S.total_out - q.out_bytes + q.reserved;
+      } else {                   // only the item's start is known exactly
+        S.blk_bit = it.start_bit;
+        S.blk_out = S.total_out - q.out_bytes;
+      }
       if (q.pad == 1 && !(q.end_bit & 7)) {  // ran out exactly at an octet-aligned block start
         S.boundary_bit = q.end_bit;
         S.boundary_out = S.total_out;
@@ -900,18 +956,21 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   // then reports the first offending match's output offset.
   enum { DIST_NONE = 0, DIST_FIRST = 1, DIST_AFTER_OVERFLOW = 2 };
   std::vector<uint8_t> dist_first(n, DIST_NONE);
+  uint64_t dist_at = ~0ull;  // (sessions: one stream)
   {
     struct Probe { size_t s, seg; uint64_t before; };
     std::vector<Probe> probes[2];  // per token pool
     for (size_t s = 0; s < n; s++) {
       uint64_t produced = 0;
+      const uint64_t hist = s == 0 ? hist_len : 0;  // (a resumed stream: octets of earlier output that are there to copy from)
       for (size_t i = 0; i < per_stream[s].size(); i++) {
         const SegHost& h = per_stream[s][i];
-        if (h.deficit && (uint64_t)h.deficit > produced) {
+        if (h.deficit && (uint64_t)h.deficit > produced + hist) {
           const uint64_t end = produced + h.seg.out_bytes, cap = sp[s].out_cap;
-          if (cap >= end) dist_first[s] = DIST_FIRST;
+          if (opt && opt->prefix_on_error) probes[h.seg.pool & 1].push_back({s, i, produced + hist});  // (a session wants the place)
+          else if (cap >= end) dist_first[s] = DIST_FIRST;
           else if (cap < produced) dist_first[s] = DIST_AFTER_OVERFLOW;
-          else probes[h.seg.pool & 1].push_back({s, i, produced});
+          else probes[h.seg.pool & 1].push_back({s, i, produced + hist});
           break;
         }
         produced += h.seg.out_bytes;
@@ -923,7 +982,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       std::vector<Item> its(pv.size());
       for (size_t k = 0; k < pv.size(); k++) {
         its[k] = per_stream[pv[k].s][pv[k].seg].item;
-        its[k].flags |= (uint32_t)pv[k].before << ITEM_HIST_SHIFT;  // < 32768: the item's reach-back exceeds it
+        its[k].flags |= (uint32_t)std::min<uint64_t>(pv[k].before, 65535) << ITEM_HIST_SHIFT;  // < 32768: the item's reach-back exceeds it
       }
       if ((r = upload(ctx, ctx->d_redo_items, its))) return r;
       if ((r = ensure(ctx, ctx->d_redo_res, its.size() * sizeof(SegResult)))) return r;
@@ -939,7 +998,9 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         h.seg.tok_words = pr[k].tok_words;
         h.seg.n_runs = pr[k].n_runs;
         const uint64_t at = pr[k].reserved;  // octets into the item; ~0: none found (cannot happen)
-        dist_first[pv[k].s] = (at != ~0ull && pv[k].before + at > sp[pv[k].s].out_cap) ? DIST_AFTER_OVERFLOW : DIST_FIRST;
+        const uint64_t hist_k = pv[k].s == 0 ? hist_len : 0;
+        dist_first[pv[k].s] = (at != ~0ull && pv[k].before - hist_k + at > sp[pv[k].s].out_cap) ? DIST_AFTER_OVERFLOW : DIST_FIRST;
+        if (at != ~0ull) dist_at = pv[k].before - hist_k + at;  // octets of the stream before the offending match
       }
     }
   }
@@ -968,8 +1029,17 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     int32_t status = S.status;
     if (dist_first[s] != DIST_NONE) status = TBZ_E_DISTANCE;
     status = fill_result(s, status, (uint32_t)v.size(), dist_first[s] == DIST_FIRST);
-    if (status < 0) continue;  // reference signals an error: no partial-result contract
+    if (status < 0) {
+      // reference signals an error: no partial-result contract.  A session hands out what a front-to-back decoder
+      // produced before it met the error: everything before the failing token (for a match that reaches before the
+      // stream's first octet the one-lane re-decode above found its place)
+      if (!(opt && opt->prefix_on_error) || (status == TBZ_E_DISTANCE && dist_at == ~0ull)) continue;
+      opt->first_error = status;
+      R.out_len = status == TBZ_E_DISTANCE ? dist_at : S.total_out;
+      R.out_total = R.out_len;
+    }
     if (size_only) continue;
+    const uint64_t hist = s == 0 ? hist_len : 0;
     // groups: consecutive segments that share one LZ77 window in one K2 workgroup.  A segment that needs no history
     // opens a group of its own.  One that does (its matches reach before its first octet, or it continues a
     // repaired block) joins the group before it while that group is small; a group whose segments reach before
@@ -982,8 +1052,9 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     bool after_big = false;
     for (size_t i = 0; i < v.size(); i++) {
       if (o >= R.out_len) break;
-      const bool need = i > 0 && (v[i].continues || v[i].deficit > 0);
-      const uint64_t reach = S.out_off + (o > v[i].deficit ? o - v[i].deficit : 0);  // first octet its matches copy from
+      const bool need = (i > 0 || hist > 0) && (v[i].continues || v[i].deficit > 0);
+      // first octet its matches copy from (with earlier output in the buffer it may lie before the stream's own first octet)
+      const uint64_t reach = S.out_off + o - std::min<uint64_t>(v[i].deficit, o + hist);
       if (ctx->sym_hist && v[i].seg.out_bytes >= 2 * slice_target && v[i].seg.n_runs >= 2) {
         // a large segment: its slices are laid out by the device, one group each
         BigSeg b{};
@@ -995,7 +1066,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         b.group_slot = (uint32_t)h_groups.size();
         b.rec_slot = n_recs;
         b.n_slots = (uint32_t)(v[i].seg.out_bytes / slice_target + 1);
-        b.first_hist = (need && reach < b.out_abs && h_groups.size() > g0) ? 1u : 0u;
+        b.first_hist = (need && reach < b.out_abs && (h_groups.size() > g0 || hist > 0)) ? 1u : 0u;
         bigs.push_back(b);
         for (uint32_t k = 0; k < b.n_slots; k++) {
           Group g{};
@@ -1012,7 +1083,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         after_big = true;
         continue;
       }
-      bool join = need && !after_big;
+      bool join = need && !after_big && h_groups.size() > g0;
       if (ctx->sym_hist && join) join = (S.out_off + o) - h_groups.back().out_abs < H_JOIN_BELOW;
       after_big = false;
       if (!join) {
@@ -1026,7 +1097,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         h_grec.push_back(-1);
       }
       if (need && reach < h_groups.back().out_abs) {
-        if (ctx->sym_hist && h_groups.size() > g0 + 1) {
+        if (ctx->sym_hist && (h_groups.size() > g0 + 1 || hist > 0)) {
           h_hist.back() = 1;
         } else {
           // (round-1 scheme, and always for a stream's first group) take in earlier groups until the history is covered
@@ -1053,6 +1124,10 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
 
   // ---------------------------------------------------------------- K2
   if ((r = record(ctx, 4))) return r;
+  if (!size_only && opt && opt->alloc) {
+    d_out = opt->alloc(sp[0].total_out);
+    if (!d_out) return TBZ_E_NOMEM;
+  }
   if (!size_only && !h_groups.empty()) {
     if (!d_out) return TBZ_E_ARG;
     if ((r = upload(ctx, ctx->d_segs, h_segs))) return r;
@@ -1093,7 +1168,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         const StreamPlan& S = sp[h_gstream[gi]];
         order_h.push_back((uint32_t)gi);
         hgs.push_back(HG{h_groups[gi].out_abs, std::max(h_groups[gi].out_abs, std::min(h_groups[gi].out_abs + tot, h_groups[gi].out_end)),
-                         S.out_off, h_gstream[gi]});
+                         S.out_off - (h_gstream[gi] == 0 ? hist_len : 0), h_gstream[gi]});
         mark_lo = std::min(mark_lo, S.out_off);
         mark_hi = std::max(mark_hi, h_groups[gi].out_end);
       } else if (tot + K2_SLACK <= K2_SMALL_MAX) {
@@ -1254,6 +1329,13 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   }
   if ((r = record(ctx, 6))) return r;
   TBZ_HIP(hipStreamSynchronize(ctx->stream));
+  const bool keep_prefix = opt && opt->prefix_on_error;
+  if (opt) {
+    opt->blk_known = sp[0].blk_known;
+    opt->blk_bit = sp[0].blk_bit > sp[0].in_off * 8 ? sp[0].blk_bit - sp[0].in_off * 8 : 0;
+    opt->blk_out = sp[0].blk_out;
+    opt->end_bit = sp[0].in_end_bit > sp[0].in_off * 8 ? sp[0].in_end_bit - sp[0].in_off * 8 : 0;
+  }
   for (size_t s = 0; s < n; s++) {
     tbz_result& R = results[s];
     StreamPlan& S = sp[s];
@@ -1261,11 +1343,11 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if (format == TBZ_FORMAT_ZLIB) {
       if (S.trailer_have < 2) R.status = TBZ_INPUT_UNDERRUN;  // zlib.lisp:81-86
       else if (size_only) R.flags |= 0;
-      else if (S.trailer0 != R.adler32) { R.status = TBZ_E_ADLER32; R.out_len = 0; }
+      else if (S.trailer0 != R.adler32) { R.status = TBZ_E_ADLER32; R.out_len = keep_prefix ? R.out_len : 0; }
       else R.flags |= 1;
     } else {
       if (S.trailer_have < 1) R.status = TBZ_INPUT_UNDERRUN;  // gzip.lisp:83-86
-      else if (!size_only && S.trailer0 != R.crc32) { R.status = TBZ_E_CRC32; R.out_len = 0; }
+      else if (!size_only && S.trailer0 != R.crc32) { R.status = TBZ_E_CRC32; R.out_len = keep_prefix ? R.out_len : 0; }
       else if (S.trailer_have < 2) R.status = TBZ_INPUT_UNDERRUN;  // gzip.lisp:96-99
       else if (!size_only) R.flags |= 1;
     }
@@ -1446,6 +1528,286 @@ int tbz_inflate_batch_device(tbz_ctx* ctx, int format, size_t n, const void* d_i
   return inflate_passes(ctx, format, n, d_in_base, in_offs, in_lens, d_out_base, out_offs, out_caps, results, false);
 }
 
+}  // extern "C"
+
+// ====================================================================================================
+// Sessions: 3bz's chunked protocol (deflate.lisp:114-137, :263-269, :705-716; api.lisp:3-21) with the state on the
+// device.  A deflate-state in the reference is resumable at every bit and octet; here the resume point is the start
+// of the block in which the input ran out (a block is where a decode can be entered with no other state than the 32
+// KiB window, deflate.lisp:518-528), so a call costs O(new input + the one block it continues), and what the caller
+// sees — flags, counts, octets, call by call — is what the reference returns:
+//   * input the caller has given and the decoder has not finished with stays in HBM (d_in, from the resume block on);
+//   * the 32 KiB of output before the resume point are the window (d_hist); K2 / K6 copy from it as from any history;
+//   * octets decoded beyond what the caller's buffer takes wait in HBM (d_dec) for the next buffer (output-overflow);
+//   * a stream that turns out to be invalid hands out everything a front-to-back decoder would have produced first.
+// ====================================================================================================
+struct tbz_session {
+  tbz_ctx* ctx = nullptr;
+  int format = 0;
+  tbz::DevBuf d_in, d_dec, d_hist, d_tmp;
+  size_t in_len = 0;          // valid octets in d_in: the stream from the octet that holds the resume point on
+  uint64_t in_abs = 0;        // how many octets of the stream precede d_in[0]
+  uint32_t bit_off = 0;       // the resume block's header starts at this bit of d_in[0]
+  bool header_done = false;   // the container header is behind the resume point: what is left are raw blocks
+  uint64_t hist_len = 0;      // octets in d_hist (the output just before the resume point), at most 32768
+  uint64_t out_abs = 0;       // octets of output before the resume point
+  uint32_t ck = 0;            // adler32 (s1 | s2 << 16) / crc32 of those octets
+  // the decode of d_in as it stands (valid until more input arrives)
+  bool dec_valid = false;
+  uint64_t dec_len = 0;       // octets decoded from the resume point on (at d_dec + 32768)
+  uint64_t delivered = 0;     // ... of which the caller has these
+  int32_t dec_status = 0;     // finished / input-underrun / the error met after dec_len octets
+  uint32_t dec_flags = 0;
+  bool blk_known = false;
+  uint64_t blk_bit = 0, blk_out = 0, end_bit = 0;
+  uint32_t total_ck = 0, trailer_check = 0, trailer_isize = 0;
+  uint64_t consumed_abs = 0;  // finished: octets of the stream consumed, trailer included
+  bool finished = false;
+  int32_t error = 0;          // raised once (the reference signals a condition; the state is dead afterwards)
+  // The reference allocates its window (32 KiB of zeros) at the first output-overflow (deflate.lisp:121-137) and from
+  // then on copies from it whatever a distance says, without asking whether the stream ever produced that octet
+  // (deflate.lisp:343-352: "no window?" is the only check).  A damaged stream whose match reaches before its first
+  // octet is therefore an error before the first overflow and reads zeros after it; so does the session:
+  bool window = false;        // an output-overflow has been reported
+  bool pad_hist = false;      // the history is the full 32 KiB, zeros in front
+};
+
+namespace tbz {
+static uint32_t session_ck_init(int format) { return format == TBZ_FORMAT_ZLIB ? 1u : 0u; }
+
+// checksum of d[0, n) continuing from `init`
+static int session_chain_ck(tbz_session* S, const void* d, uint64_t n, uint32_t init, uint32_t* out) {
+  *out = init;
+  if (S->format == TBZ_FORMAT_DEFLATE || n == 0) return 0;
+  std::vector<uint64_t> o{0}, l{n};
+  std::vector<uint32_t> in{init}, sums;
+  int r = run_checksums(S->ctx, S->format == TBZ_FORMAT_ZLIB ? 1 : 2, d, o, l, in, sums);
+  if (r) return r;
+  *out = sums[0];
+  return 0;
+}
+
+static int session_decode(tbz_session* S) {
+  tbz_ctx* ctx = S->ctx;
+  int r;
+  CoreOpts opt;
+  opt.start_bit_off = S->bit_off;
+  opt.hist_len = S->pad_hist ? 32768 : S->hist_len;
+  opt.prefix_on_error = true;
+  int alloc_err = 0;
+  opt.alloc = [&](uint64_t total) -> void* {
+    if ((alloc_err = ensure(ctx, S->d_dec, 32768 + total + 128))) return nullptr;
+    if (S->pad_hist && S->hist_len < 32768 &&
+        hipMemsetAsync(S->d_dec.p, 0, 32768 - S->hist_len, ctx->stream) != hipSuccess) {
+      alloc_err = TBZ_E_HIP;
+      return nullptr;
+    }
+    if (S->hist_len &&
+        hipMemcpyAsync((uint8_t*)S->d_dec.p + 32768 - S->hist_len, S->d_hist.p, S->hist_len, hipMemcpyDeviceToDevice,
+                       ctx->stream) != hipSuccess) {
+      alloc_err = TBZ_E_HIP;
+      return nullptr;
+    }
+    return S->d_dec.p;
+  };
+  const int fmt = S->header_done ? TBZ_FORMAT_DEFLATE : S->format;
+  uint64_t io = 0, il = S->in_len, oo = 32768, oc = 1ull << 62;
+  tbz_result R;
+  if ((r = ensure(ctx, S->d_in, 64))) return r;  // (an empty first call: there is a buffer to point at)
+  r = inflate_core(ctx, fmt, 1, S->d_in.p, &io, &il, nullptr, &oo, &oc, &R, false, &opt);
+  if (r) return alloc_err ? alloc_err : r;
+  S->dec_valid = true;
+  S->dec_len = R.out_total;
+  S->dec_status = R.status;
+  S->dec_flags = R.flags;
+  S->blk_known = opt.blk_known;
+  S->blk_bit = opt.blk_bit;
+  S->blk_out = opt.blk_out;
+  S->end_bit = opt.end_bit;
+  S->trailer_check = R.trailer_check;
+  S->trailer_isize = R.trailer_isize;
+  if (R.status == TBZ_E_DISTANCE && S->dec_len < S->delivered) S->dec_len = S->delivered;  // (no place found: nothing new)
+  if (S->dec_len < S->delivered) return TBZ_E_INTERNAL;       // a longer input cannot decode to less
+  const void* d_new = (const uint8_t*)S->d_dec.p + 32768;
+  if (R.status == TBZ_FINISHED) {
+    S->consumed_abs = S->in_abs + R.in_consumed;
+    if (fmt == TBZ_FORMAT_DEFLATE && S->format != TBZ_FORMAT_DEFLATE) {
+      // raw blocks were decoded: the container's trailer is read here, as zlib.lisp:80-95 / gzip.lisp:78-106 do
+      // (the checksum of ALL output = the resume point's, continued over these octets)
+      if ((r = session_chain_ck(S, d_new, S->dec_len, S->ck, &S->total_ck))) return r;
+      const uint64_t at = S->end_bit / 8;
+      const uint64_t have = S->in_len > at ? S->in_len - at : 0;
+      uint8_t tr[8] = {0};
+      if (have) TBZ_HIP(hipMemcpy(tr, (const uint8_t*)S->d_in.p + at, std::min<uint64_t>(have, 8), hipMemcpyDeviceToHost));
+      S->dec_flags |= 2;
+      if (S->format == TBZ_FORMAT_ZLIB) {
+        const uint32_t stored = ((uint32_t)tr[0] << 24) | ((uint32_t)tr[1] << 16) | ((uint32_t)tr[2] << 8) | tr[3];
+        if (have < 4) S->dec_status = TBZ_INPUT_UNDERRUN;
+        else if (stored != S->total_ck) S->dec_status = TBZ_E_ADLER32;
+        else { S->trailer_check = stored; S->dec_flags |= 1; S->consumed_abs = S->in_abs + at + 4; }
+      } else {
+        const uint32_t stored = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+        if (have < 4) S->dec_status = TBZ_INPUT_UNDERRUN;
+        else if (stored != S->total_ck) S->dec_status = TBZ_E_CRC32;
+        else if (have < 8) S->dec_status = TBZ_INPUT_UNDERRUN;
+        else {
+          S->trailer_check = stored;
+          S->trailer_isize = (uint32_t)tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24);
+          S->dec_flags |= 1;
+          S->consumed_abs = S->in_abs + at + 8;
+        }
+      }
+      S->blk_known = false;  // (trailer cut off: the next call decodes the last blocks again, which is all there is left)
+    } else {
+      S->total_ck = S->format == TBZ_FORMAT_ZLIB ? R.adler32 : R.crc32;
+      if (S->out_abs && S->format != TBZ_FORMAT_DEFLATE) return TBZ_E_INTERNAL;  // (a resumed stream is past its header)
+    }
+  }
+  return 0;
+}
+
+// the caller has everything that was decoded and the input ran out: move the resume point to the block it ran out in
+static int session_advance(tbz_session* S) {
+  tbz_ctx* ctx = S->ctx;
+  if (!S->blk_known || S->blk_bit == 0 || S->blk_out > S->dec_len) return 0;
+  if (S->blk_bit / 8 > S->in_len) return 0;
+  int r;
+  // checksum and window at the new resume point: octets [0, blk_out) of the decode leave the session's view
+  const uint8_t* d_new = (const uint8_t*)S->d_dec.p + 32768;
+  if (S->blk_out) {
+    if ((r = session_chain_ck(S, d_new, S->blk_out, S->ck, &S->ck))) return r;
+    const uint64_t nh = std::min<uint64_t>(32768, (S->pad_hist ? 32768 : S->hist_len) + S->blk_out);
+    if ((r = ensure(ctx, S->d_tmp, 32768 + 64))) return r;
+    // (history and decode are contiguous in d_dec: the window is the nh octets that end at the resume point)
+    TBZ_HIP(hipMemcpyAsync(S->d_tmp.p, d_new + S->blk_out - nh, nh, hipMemcpyDeviceToDevice, ctx->stream));
+    TBZ_HIP(hipStreamSynchronize(ctx->stream));
+    std::swap(S->d_hist, S->d_tmp);
+    S->hist_len = nh;
+  }
+  const uint64_t drop = S->blk_bit / 8;
+  if (drop) {
+    const size_t keep = S->in_len - drop;
+    tbz::DevBuf nb;
+    if ((r = ensure(ctx, nb, std::max<size_t>(keep, S->d_in.cap > 4096 ? S->d_in.cap / 2 : 4096) + 64))) return r;
+    if (keep) TBZ_HIP(hipMemcpyAsync(nb.p, (const uint8_t*)S->d_in.p + drop, keep, hipMemcpyDeviceToDevice, ctx->stream));
+    TBZ_HIP(hipStreamSynchronize(ctx->stream));
+    TBZ_HIP(hipFree(S->d_in.p));
+    S->d_in = nb;
+    S->in_len = keep;
+    S->in_abs += drop;
+  }
+  S->bit_off = (uint32_t)(S->blk_bit & 7);
+  S->header_done = true;  // (a block start lies behind every container header)
+  S->out_abs += S->blk_out;
+  S->dec_len -= S->blk_out;
+  S->delivered -= S->blk_out;
+  S->dec_valid = false;   // d_dec is laid out for the old resume point
+  return 0;
+}
+}  // namespace tbz
+
+extern "C" {
+
+int tbz_session_create(tbz_ctx* ctx, int format, tbz_session** out) {
+  if (!ctx || !out || format < 0 || format > 2) return TBZ_E_ARG;
+  tbz_session* S = new tbz_session();
+  S->ctx = ctx;
+  S->format = format;
+  S->ck = tbz::session_ck_init(format);
+  *out = S;
+  return 0;
+}
+
+void tbz_session_destroy(tbz_session* S) {
+  if (!S) return;
+  hipSetDevice(S->ctx->device);
+  for (tbz::DevBuf* b : {&S->d_in, &S->d_dec, &S->d_hist, &S->d_tmp})
+    if (b->p) hipFree(b->p);
+  delete S;
+}
+
+int tbz_session_feed(tbz_session* S, const void* in, size_t in_len, int in_on_device) {
+  using namespace tbz;
+  if (!S || (in_len && !in)) return TBZ_E_ARG;
+  tbz_ctx* ctx = S->ctx;
+  TBZ_HIP(hipSetDevice(ctx->device));
+  if (in_len == 0 || S->finished || S->error) return 0;
+  if (S->in_len + in_len + 64 > S->d_in.cap) {  // grow, keeping what is there
+    DevBuf nb;
+    int r = ensure(ctx, nb, (S->in_len + in_len) * 2 + 4096);
+    if (r) return r;
+    if (S->in_len) TBZ_HIP(hipMemcpy(nb.p, S->d_in.p, S->in_len, hipMemcpyDeviceToDevice));
+    if (S->d_in.p) TBZ_HIP(hipFree(S->d_in.p));
+    S->d_in = nb;
+  }
+  TBZ_HIP(hipMemcpy((uint8_t*)S->d_in.p + S->in_len, in, in_len, in_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  S->in_len += in_len;
+  S->dec_valid = false;
+  return 0;
+}
+
+int tbz_session_decompress(tbz_session* S, uint8_t* out, size_t out_cap, tbz_result* res) {
+  using namespace tbz;
+  if (!S || !res || (out_cap && !out)) return TBZ_E_ARG;
+  tbz_ctx* ctx = S->ctx;
+  TBZ_HIP(hipSetDevice(ctx->device));
+  memset(res, 0, sizeof(*res));
+  auto report = [&](int32_t status, uint64_t gave) {
+    res->status = status;
+    res->out_len = gave;
+    res->out_total = S->out_abs + S->delivered;   // octets of the stream handed out so far
+    res->in_consumed = S->finished ? S->consumed_abs : S->in_abs + S->in_len;
+    res->boundary_out = S->out_abs;                // ... of which this many lie before the session's resume point
+    res->flags = S->dec_flags;
+    res->trailer_check = S->trailer_check;
+    res->trailer_isize = S->trailer_isize;
+    if (S->format == TBZ_FORMAT_ZLIB) res->adler32 = S->total_ck;
+    if (S->format == TBZ_FORMAT_GZIP) res->crc32 = S->total_ck;
+    return 0;
+  };
+  if (S->error) return report(S->error, 0);
+  if (S->finished) return report(TBZ_FINISHED, 0);
+  int r;
+  if (!S->dec_valid && (r = session_decode(S))) return r;
+  uint64_t give = 0;
+  for (;;) {
+    const uint64_t g = std::min<uint64_t>(out_cap - give, S->dec_len - S->delivered);
+    if (g) {
+      TBZ_HIP(hipMemcpy(out + give, (const uint8_t*)S->d_dec.p + 32768 + S->delivered, g, hipMemcpyDeviceToHost));
+      S->delivered += g;
+      give += g;
+    }
+    if (S->delivered == S->dec_len && S->dec_status == TBZ_E_DISTANCE && S->window && !S->pad_hist) {
+      // the match that reaches before the stream's first octet: the reference has a window by now and reads zeros
+      S->pad_hist = true;
+      S->dec_valid = false;
+      if ((r = session_decode(S))) return r;
+      continue;
+    }
+    break;
+  }
+  const bool stored_cut = S->dec_status == TBZ_INPUT_UNDERRUN && (S->dec_flags & 4) && give == out_cap;
+  if (S->delivered < S->dec_len || stored_cut) {
+    // (stored_cut: the input ran out inside a stored block just where this buffer is full — the reference asks for
+    // output space first there, deflate.lisp:538-573)
+    S->window = true;
+    return report(TBZ_OUTPUT_OVERFLOW, give);
+  }
+  if (S->dec_status < 0) {
+    S->error = S->dec_status;
+    return report(S->error, give);
+  }
+  if (S->dec_status == TBZ_FINISHED) {
+    S->finished = true;
+    return report(TBZ_FINISHED, give);
+  }
+  if ((r = session_advance(S))) return r;
+  return report(TBZ_INPUT_UNDERRUN, give);
+}
+
+}  // extern "C"
+
+extern "C" {
 int tbz_ctx_trim(tbz_ctx* ctx) {
   using namespace tbz;
   if (!ctx) return TBZ_E_ARG;
@@ -1517,6 +1879,35 @@ int tbz_inflate_batch(tbz_ctx* ctx, int format, size_t n, const uint8_t* const* 
 int tbz_inflate(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap,
                 tbz_result* res) {
   return stage_batch(ctx, format, 1, &in, &in_len, &out, &out_cap, res, false);
+}
+
+int tbz_inflate_alloc(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len, tbz_alloc_fn alloc, void* user,
+                      tbz_result* res) {
+  using namespace tbz;
+  if (!ctx || !res || !alloc || (in_len && !in)) return TBZ_E_ARG;
+  TBZ_HIP(hipSetDevice(ctx->device));
+  int r;
+  if ((r = ensure(ctx, ctx->d_in_stage, in_len + 64))) return r;
+  if (in_len) TBZ_HIP(hipMemcpyAsync(ctx->d_in_stage.p, in, in_len, hipMemcpyHostToDevice, ctx->stream));
+  CoreOpts opt;
+  int alloc_err = 0;
+  opt.alloc = [&](uint64_t total) -> void* {
+    alloc_err = ensure(ctx, ctx->d_out_stage, total + 64);
+    return alloc_err ? nullptr : ctx->d_out_stage.p;
+  };
+  uint64_t io = 0, il = in_len, oo = 0, oc = 1ull << 62;
+  r = inflate_core(ctx, format, 1, ctx->d_in_stage.p, &io, &il, nullptr, &oo, &oc, res, false, &opt);
+  ctx->tim.h2d_copies = in_len ? 1u : 0u;
+  if (r) return alloc_err ? alloc_err : r;
+  if (res->status >= 0) {
+    uint8_t* out = alloc(user, (size_t)res->out_len);
+    if (res->out_len) {
+      if (!out) return TBZ_E_NOMEM;
+      TBZ_HIP(hipMemcpyAsync(out, ctx->d_out_stage.p, res->out_len, hipMemcpyDeviceToHost, ctx->stream));
+      TBZ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+  }
+  return 0;
 }
 
 int tbz_inflate_size(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len, tbz_result* res) {

@@ -113,6 +113,7 @@ struct K0Params {
   Item* items;            // item build out
   u32 format;
   u32 second_pass;        // items: the marker array was written by the emitting pass
+  u32 start_bit_off;      // stream 0's first block header sits at this bit of the stream's first octet (resumed streams)
 };
 constexpr u32 K0_SLOTS = 32;  // markers kept per 64 KiB tile by the one-pass scan (flush every 16 KiB of text: ~8)
 
@@ -263,7 +264,7 @@ TBZ_KERNEL void tbz_k0_items(K0Params P) {
   const u32 s = lo, fm = P.first_marker[s], nm = P.first_marker[s + 1] - fm;
   const u32 k = i - (fm + s);
   Item it;
-  it.start_bit = k == 0 ? P.str_off[s] * 8 : P.markers[fm + k - 1];
+  it.start_bit = k == 0 ? P.str_off[s] * 8 + (s == 0 ? P.start_bit_off : 0u) : P.markers[fm + k - 1];
   it.limit_bit = k < nm ? P.markers[fm + k] : ~0ull;
   it.end_byte = P.str_off[s] + P.str_len[s];
   it.stream = s;
@@ -329,6 +330,7 @@ struct K0bParams {
   u64* merged;             // ... and the merged list
   u32* first_merged;       //   [n_streams+1]
   u32* head_merged;        //   [2]: total, 0  (laid out as K0Params::head for tbz_k0_items)
+  u32 start_bit_off;       // stream 0 begins at this bit of its first octet: nothing before it is a candidate
 };
 TBZ_DEV u32 k0b_find_stream(const K0bParams& P, u32 tile) {
   u32 lo = 0, hi = P.n_streams;  // tile_first[lo] <= tile < tile_first[hi]; streams without tiles are skipped over
@@ -352,7 +354,7 @@ TBZ_KERNEL void tbz_k0b_scan(K0bParams P) {
   const uintptr_t s_lo = base + P.str_off[s], s_hi = s_lo + P.str_len[s];
   const uintptr_t t0 = (s_lo & ~(uintptr_t)15) + (uintptr_t)(tile - P.tile_first[s]) * K0B_TILE;
   // candidate bit positions p (relative to in_base) must satisfy p_min <= p <= p_max
-  const u64 p_min = (u64)(s_lo - base) * 8 + 1;  // (the stream's first bit belongs to the head item)
+  const u64 p_min = (u64)(s_lo - base) * 8 + 1 + (s == 0 ? P.start_bit_off : 0u);  // (the stream's first bit belongs to the head item)
   const u64 p_end = (u64)(s_hi - base) * 8;
   u64* slots = P.slots + (u64)tile * K0B_SLOTS;
   u32 nout = 0;
@@ -1358,6 +1360,13 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
   r.trailer_have = tr_have;
   r.land_marker = land;
   r.reserved = st.viol_out;  // (the gang kernel keeps its diagnostics here)
+  if (status == SEG_UNDERRUN && st.hist0 == 0) {
+    // where a resumed decode would start: the block in which the input ran out, and what came out before it
+    r.trailer0 = (u32)blk_pos;
+    r.trailer1 = (u32)(blk_pos >> 32);
+    r.reserved = blk_prod;
+    r.land_marker = 0;  // 0: exact
+  }
   P.res[idx] = r;
 }
 // K1h — header pre-pass for the gang kernel.  Parsing a dynamic block's code lengths is a serial job for ONE
@@ -2609,6 +2618,14 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     r.trailer_have = gs.tr_have;
     r.land_marker = gs.land;
     r.reserved = ((u64)gs.rounds << 32) | gs.valid_lanes;
+    if (gs.status == SEG_UNDERRUN) {
+      // where a resumed decode would start: the block in which the input ran out, and what came out before it
+      // (after blocks decoded THROUGH, only the item's own start is known exactly: land_marker = 1)
+      r.trailer0 = (u32)gs.blk_pos;
+      r.trailer1 = (u32)(gs.blk_pos >> 32);
+      r.reserved = gs.blk_prod;
+      r.land_marker = gs.inl ? 1u : 0u;
+    }
     P.res[idx] = r;
   }
 }

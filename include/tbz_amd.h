@@ -151,6 +151,14 @@ int tbz_inflate(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len, uint
  * (api.lisp:48-65).  out_total/status as tbz_inflate would report with unlimited space. */
 int tbz_inflate_size(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len, tbz_result* res);
 
+/* (decompress-vector compressed :format f) WITHOUT :output, in ONE decode: where the reference grows 32 KiB buffers by
+ * doubling and gathers them (api.lisp:48-65), the engine decodes once (one host-to-device copy, one Huffman pass) and
+ * asks for the result buffer when it knows the size: `alloc(user, n)` returns n writable octets (n may be 0), the
+ * octets are copied there, res->out_len = n.  Not called when the stream fails (status < 0). */
+typedef uint8_t* (*tbz_alloc_fn)(void* user, size_t n_octets);
+int tbz_inflate_alloc(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len, tbz_alloc_fn alloc, void* user,
+                      tbz_result* res);
+
 /* n independent streams in one call (BASELINE configs 3 and 4): stream i is
  * (decompress-vector ins[i] :format f :output outs[i]). */
 int tbz_inflate_batch(tbz_ctx* ctx, int format, size_t n, const uint8_t* const* ins, const size_t* in_lens,
@@ -165,6 +173,26 @@ int tbz_inflate_device(tbz_ctx* ctx, int format, const void* d_in, size_t in_len
 int tbz_inflate_batch_device(tbz_ctx* ctx, int format, size_t n, const void* d_in_base, const uint64_t* in_offs,
                              const uint64_t* in_lens, void* d_out_base, const uint64_t* out_offs,
                              const uint64_t* out_caps, tbz_result* results);
+
+/* ---- resumable decode: 3bz's chunked protocol with the state on the device ----------------------
+ * A session is a deflate-state / zlib-state / gzip-state (deflate.lisp:4-62, zlib.lisp:3-12, gzip.lisp:3-28) whose
+ * resumable part lives in HBM: the input not yet finished with, the 32 KiB window (deflate.lisp:121-137, :343-352)
+ * and the octets decoded beyond what the caller's buffer took.  One (decompress context state) call of the reference
+ * (api.lisp:3-10) is
+ *     tbz_session_feed(s, <the context's octets offset..end>)   then   tbz_session_decompress(s, buffer + offset, room)
+ * and (replace-output-buffer state buffer) (api.lisp:12-21) is simply the next tbz_session_decompress with the new
+ * buffer.  Per call: res->status = finished / input-underrun / output-overflow exactly when the reference sets those
+ * flags, res->out_len = octets written to `out` by THIS call, res->out_total = octets of the stream handed out so
+ * far, res->in_consumed = (finished) octets of the stream consumed including the trailer, flags as in tbz_result.
+ * A stream that turns out to be invalid reports its error in the call in which a front-to-back decoder would have
+ * met it: after the output before it has been handed out (status < 0 with out_len = the last octets before it).
+ * Cost per call: the new input plus the one block it continues (the resume point is a block start). */
+typedef struct tbz_session tbz_session;
+int tbz_session_create(tbz_ctx* ctx, int format, tbz_session** out_session);
+void tbz_session_destroy(tbz_session* s);
+/* `in` is host memory, or device memory when in_on_device != 0 (a pointer context over HBM, io-mmap.lisp:47-54) */
+int tbz_session_feed(tbz_session* s, const void* in, size_t in_len, int in_on_device);
+int tbz_session_decompress(tbz_session* s, uint8_t* out, size_t out_cap, tbz_result* res);
 
 /* ---- checksums over device memory -------------------------------------------------------
  * (adler32 buf end s1 s2) checksums.lisp:167-174 and (crc32/table buf end crc) :196-210,

@@ -384,6 +384,10 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMem
   memcpy(d, s, n);
   return hipSuccess;
 }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
+  memset(d, v, n);
+  return hipSuccess;
+}
 static inline hipError_t hipStreamCreate(hipStream_t* s) {
   *s = nullptr;
   return hipSuccess;

@@ -103,11 +103,41 @@ def case_test_deflated(eng):
     raw = open(os.path.join(GOLDEN, "test_deflated.bin"), "rb").read()
     meta = json.load(open(os.path.join(GOLDEN, "test_deflated.json")))
     buf, n = A.decompress_vector(raw, format="deflate", start=8, engine=eng)
+    t = eng.timings()   # without :output the stream is decoded ONCE (tbz_inflate_alloc): one input copy, one Huffman pass
+    assert t.huff_launches == 1 and t.h2d_copies == 1, (t.huff_launches, t.h2d_copies)
     assert n == meta["plain_len"] == int.from_bytes(raw[:8], "little")
     assert hashlib.sha256(bytes(buf[:n])).hexdigest() == meta["sha256"]
     out = bytearray(n)
     _, n2 = A.decompress_vector(raw[8:], format="deflate", output=out, engine=eng)
     assert n2 == n and hashlib.sha256(bytes(out)).hexdigest() == meta["sha256"]
+
+
+def case_reference_chunk_patterns(eng, in_step=3, out_step=3, n_random=4, max_calls=400):
+    """the reference's own chunking tests on its own fixture (test-chunked-input.lisp:27-75, test-chunked-output.lisp:
+    27-89): `test.deflated` fed in 3-octet chunks, then in random chunks < 1234; decoded into 3-octet buffers, then
+    into random buffers <= 12345 — every call compared with the oracle.  (The reference runs 30 000 random rounds
+    against libz; tools/fuzz_chunked.py is the open-ended version.)  `max_calls` bounds the fixed-step runs on the
+    CPU emulator, where a call costs milliseconds: the GPU module runs them to the end."""
+    raw = open(os.path.join(GOLDEN, "test_deflated.bin"), "rb").read()[8:]
+    meta = json.load(open(os.path.join(GOLDEN, "test_deflated.json")))
+    n = meta["plain_len"]
+    rng = random.Random(0x3B2)
+    cut = raw if max_calls is None else raw[: in_step * max_calls]
+    got = _chunked_lockstep(eng, cut, "deflate", [in_step], [n + 8], "test.deflated in %d-octet chunks" % in_step,
+                            max_calls=None if max_calls is None else max_calls + 10)
+    if max_calls is None:
+        assert hashlib.sha256(got).hexdigest() == meta["sha256"]
+    for k in range(n_random):
+        steps = [rng.randrange(1, 1234) for _ in range(64)]
+        got = _chunked_lockstep(eng, raw, "deflate", steps, [n + 8], "test.deflated random chunks %d" % k)
+        assert hashlib.sha256(got).hexdigest() == meta["sha256"]
+    small = raw if max_calls is None else raw[:160]   # (3-octet buffers: one call per 3 octets of OUTPUT)
+    _chunked_lockstep(eng, small, "deflate", [len(small)], [out_step], "test.deflated into %d-octet buffers" % out_step,
+                      max_calls=None if max_calls is None else 100_000)
+    for k in range(n_random):
+        sizes = [rng.randrange(1, 12346) for _ in range(16)]
+        got = _chunked_lockstep(eng, raw, "deflate", [len(raw)], sizes, "test.deflated random buffers %d" % k)
+        assert hashlib.sha256(got).hexdigest() == meta["sha256"]
 
 
 def _mixed_plain(n, seed):
@@ -594,7 +624,7 @@ def case_deep_codes(eng, n_tokens=12000):
     assert_same(eng, s, "deflate", len(p), what="dense literals, short blocks")
 
 
-def _chunked_lockstep(eng, blob, fmt, in_steps, out_sizes, what):
+def _chunked_lockstep(eng, blob, fmt, in_steps, out_sizes, what, max_calls=2000):
     """feed `blob` to the oracle and to the engine in the same input chunks / output buffers and compare every call"""
     mk_e = {"deflate": A.make_deflate_state, "zlib": A.make_zlib_state, "gzip": A.make_gzip_state}[fmt]
     so, se = O.State(FMT[fmt]), mk_e()
@@ -605,15 +635,27 @@ def _chunked_lockstep(eng, blob, fmt, in_steps, out_sizes, what):
     oi, pos, step_i, guard = 1, 0, 0, 0
     while not O.finished(so):
         guard += 1
-        assert guard < 2000, what
+        assert max_calls is None or guard < max_calls, what
         step = in_steps[step_i % len(in_steps)]
         step_i += 1
         end = min(len(blob), pos + step)
         co = O.make_octet_vector_context(blob, start=pos, end=end)
         ce = A.make_octet_vector_context(blob, start=pos, end=end)
         while True:
-            ro = O.decompress(co, so)
-            re_ = A.decompress(ce, se, engine=eng)
+            eo = ee = None
+            try:
+                ro = O.decompress(co, so)
+            except O.OracleError as e:
+                eo = e.code
+            try:
+                re_ = A.decompress(ce, se, engine=eng)
+            except A.ThreeBzError as e:
+                ee = e.code
+            if eo is not None or ee is not None:   # a damaged stream: the same error in the same call
+                assert eo == ee, (what, guard, "error", ee, eo)
+                _chunked_lockstep.last_state = se
+                _chunked_lockstep.last_error = eo
+                return bytes(got_o)
             flags_o = (O.finished(so), O.input_underrun(so), O.output_overflow(so))
             flags_e = (A.finished(se), A.input_underrun(se), A.output_overflow(se))
             assert flags_e == flags_o and re_ == ro, (what, guard, flags_e, flags_o, re_, ro)
@@ -635,6 +677,7 @@ def _chunked_lockstep(eng, blob, fmt, in_steps, out_sizes, what):
     got_e += be[:se.output_offset]
     assert bytes(got_e) == bytes(got_o), what
     _chunked_lockstep.last_state = se
+    _chunked_lockstep.last_error = None
     return bytes(got_o)
 
 
@@ -664,9 +707,10 @@ def case_chunked_resume(eng, n=90_000):
     # output-overflow there (it asks for space before input, deflate.lisp:538-573), then input-underrun
     z0 = zlib.compress(fp[:9000], 0)
     assert _chunked_lockstep(eng, z0, "zlib", [4093, 3000], [1362], "stored cut at a full buffer") == fp[:9000]
-    # where the replays start (3bz_amd/api.py): flush-delimited streams resume at the last block boundary the engine
-    # proved — raw blocks from there, checksum continued, container trailer compared by the host — in all three
-    # containers; a Z_SYNC_FLUSH stream (blocks copy from before the boundary) must notice and replay from octet 0
+    # where the session resumes (tbz_session_*, include/tbz_amd.h): at the start of the block in which the input ran
+    # out — raw blocks from there, checksum continued, container trailer compared by the session — in all three
+    # containers; a Z_SYNC_FLUSH stream (blocks copy from before the resume point) resumes just the same: the 32 KiB
+    # before the resume point are the session's window
     def flushed(wbits, mode):
         c = zlib.compressobj(6, zlib.DEFLATED, wbits)
         return b"".join(c.compress(fp[i:i + 8192]) + c.flush(mode) for i in range(0, len(fp), 8192)) + c.flush()
@@ -674,8 +718,8 @@ def case_chunked_resume(eng, n=90_000):
         blob = flushed(wbits, zlib.Z_FULL_FLUSH)
         for steps, sizes in (([7000], [len(fp) + 10]), ([5000, 11000, 3000], [20000, 9000]), ([len(blob) - 3, 1], [len(fp) + 10])):
             assert _chunked_lockstep(eng, blob, fmt, steps, sizes, "%s full-flush resume" % fmt) == fp
-            st = _chunked_lockstep.last_state
-            assert not st._no_base and (st._base_in > 0 or len(steps) == 2), (fmt, steps, st._base_in)  # (trailer-only chunks: nothing to adopt)
+            st = _chunked_lockstep.last_state   # (boundary_out: octets of output before the session's resume point)
+            assert st.result.boundary_out > 0 or len(steps) == 2, (fmt, steps, st.result.boundary_out)  # (trailer-only chunks: nothing to move)
         bad = blob[:-1] + bytes([blob[-1] ^ 1]) if fmt != "deflate" else None
         if fmt == "zlib":   # a checksum mismatch: same error, same call as the reference
             so, se = O.State(FMT[fmt], bytearray(len(fp) + 10)), A.make_zlib_state(bytearray(len(fp) + 10))
@@ -691,10 +735,10 @@ def case_chunked_resume(eng, n=90_000):
                 except A.ThreeBzError as e:
                     ee = e.code
                 assert eo == ee, (lo, eo, ee)
-            assert ee == -11 and se._no_base   # the tail's verdict sent it back to octet 0, and the whole stream confirmed
+            assert ee == -11
     blob = flushed(15, zlib.Z_SYNC_FLUSH)
     assert _chunked_lockstep(eng, blob, "zlib", [7000], [len(fp) + 10], "sync-flush resume") == fp
-    assert _chunked_lockstep.last_state._no_base and _chunked_lockstep.last_state._base_in == 0
+    assert _chunked_lockstep.last_state.result.boundary_out > 0
 
 
 def case_fuzz(eng, seed=7, n=30):
@@ -840,11 +884,24 @@ def case_pointer_contexts(eng, n=60_000):
             eng.free(d_in)
 
 
-ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,
+ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_reference_chunk_patterns, case_containers_and_levels, case_flush_streams,
              case_noflush_streams, case_fixed_block_chains, case_history_across_groups,
              case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_device_buffers,
              case_checksum_kernels, case_deep_codes, case_chunked_resume, case_gzip_members,
              case_pointer_contexts, case_container_headers, case_scratch_bounds, case_fuzz]
+# what each engine flavour of the test modules runs.  "auto" runs everything; the others run the cases that can
+# tell them apart (the CPU suite has to stay within minutes: a case costs seconds on the lane emulator)
+FLAVOUR_CASES = {
+    # K0b on every stream, however small: candidates, chains through false ones, symbolic history everywhere
+    "findalways": ["case_known_answer_vectors", "case_containers_and_levels", "case_noflush_streams",
+                   "case_fixed_block_chains", "case_overflow_and_underrun", "case_false_markers", "case_errors", "case_fuzz"],
+    # chain walk + layout on the host even where the device could (K3)
+    "hostlayout": ["case_known_answer_vectors", "case_flush_streams", "case_configs_1_3_5", "case_overflow_and_underrun",
+                   "case_false_markers", "case_device_buffers", "case_errors", "case_gzip_members", "case_fuzz"],
+    # one wave per group in K2
+    "k2single": ["case_flush_streams", "case_history_across_groups", "case_configs_1_3_5", "case_deep_codes",
+                 "case_overflow_and_underrun"],
+}
 # the cases whose behaviour depends on the K1 flavour (forced-flavour runs skip the rest: checksums, device
 # buffers and the replay protocol go through the same engine calls whatever decodes the Huffman codes)
 K1_CASES = [case_known_answer_vectors, case_test_deflated, case_containers_and_levels, case_flush_streams,

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 
 
-@pytest.fixture(scope="module", params=["auto", "findalways", "hostlayout", "k2single", "gang8", "gang16", "lane"])
+@pytest.fixture(scope="module", params=["auto", "findalways", "hostlayout", "k2single", "gang8", "lane"])
 def eng(request):
     """the three K1 flavours (TBZ_K1_MODE is read when a context is created)"""
     subprocess.check_call(["make", "-C", EMU_DIR, "libtbz_emu.so"], stdout=subprocess.DEVNULL)
@@ -39,12 +39,12 @@ def eng(request):
 
 @pytest.mark.parametrize("case", P.ALL_CASES, ids=lambda c: c.__name__)
 def test_emu_case(eng, case, request):
-    forced = request.node.callspec.params["eng"] not in ("auto", "findalways", "hostlayout", "k2single")
-    if forced and case not in P.K1_CASES:
+    flavour = request.node.callspec.params["eng"]
+    if flavour in P.FLAVOUR_CASES:
+        if case.__name__ not in P.FLAVOUR_CASES[flavour]:
+            pytest.skip("this flavour runs the cases that can tell it from the default")
+    elif flavour != "auto" and case not in P.K1_CASES:
         pytest.skip("does not depend on the K1 flavour")
-    if request.node.callspec.params["eng"] == "k2single" and case in (P.case_chunked_resume, P.case_gzip_members, P.case_pointer_contexts,
-                                                                      P.case_container_headers):
-        pytest.skip("host-side protocol over the same engine calls (run with both layout paths)")
     case(eng)
 
 

@@ -13,7 +13,7 @@ from tools import corpus as K
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["auto", "findalways", "hostlayout", "k2single", "gang8", "gang32", "lane"])
+@pytest.fixture(scope="module", params=["auto", "findalways", "hostlayout", "k2single", "gang8", "gang16", "gang32", "gang64", "lane"])
 def eng(request):
     """auto picks wide gangs (32/64 lanes per item) for these sizes; the other K1 flavours are forced through TBZ_K1_MODE"""
     T = importlib.import_module("3bz_amd")
@@ -38,17 +38,25 @@ def eng(request):
 
 @pytest.mark.parametrize("case", P.ALL_CASES, ids=lambda c: c.__name__)
 def test_gpu_case(eng, case, request):
-    forced = request.node.callspec.params["eng"] not in ("auto", "findalways", "hostlayout", "k2single")
-    if forced and case not in P.K1_CASES:
+    flavour = request.node.callspec.params["eng"]
+    if flavour in P.FLAVOUR_CASES:
+        if case.__name__ not in P.FLAVOUR_CASES[flavour]:
+            pytest.skip("this flavour runs the cases that can tell it from the default")
+    elif flavour != "auto" and case not in P.K1_CASES:
         pytest.skip("does not depend on the K1 flavour")
-    if request.node.callspec.params["eng"] == "k2single" and case in (P.case_chunked_resume, P.case_gzip_members, P.case_pointer_contexts,
-                                                                      P.case_container_headers):
-        pytest.skip("host-side protocol over the same engine calls (run with both layout paths)")
     case(eng)
+
+
+def test_gpu_reference_chunk_patterns_in_full(eng, request):
+    """test.deflated in 3-octet chunks and into 3-octet buffers, to the end (the CPU suite bounds the call count)"""
+    if request.node.callspec.params["eng"] not in ("auto", "findalways"):
+        pytest.skip("host-side protocol over the same engine calls")
+    P.case_reference_chunk_patterns(eng, max_calls=None, n_random=12)
 
 
 def test_gpu_larger_sizes(eng):
     P.case_flush_streams(eng, n=8 << 20)
+    P.case_noflush_streams(eng, n=6 << 20)
     P.case_containers_and_levels(eng, n=2_000_000)
     P.case_configs_1_3_5(eng, adv_total=8 << 20)
     P.case_device_buffers(eng, n=4 << 20)

@@ -21,6 +21,15 @@ class Result(C.Structure):
                 ("flags", C.c_uint32), ("reserved", C.c_uint32), ("boundary_out", C.c_uint64)]
 
 
+class GzipHeader(C.Structure):
+    """struct tbz_gzip_header"""
+    _fields_ = [("status", C.c_int32), ("header_len", C.c_uint32), ("cm", C.c_uint32), ("flg", C.c_uint32),
+                ("mtime", C.c_uint32), ("xfl", C.c_uint32), ("os", C.c_uint32), ("extra_off", C.c_uint32),
+                ("extra_len", C.c_uint32), ("name_off", C.c_uint32), ("name_len", C.c_uint32),
+                ("comment_off", C.c_uint32), ("comment_len", C.c_uint32), ("hcrc_present", C.c_uint32),
+                ("hcrc", C.c_uint32), ("stage", C.c_uint32)]
+
+
 class Timings(C.Structure):
     """struct tbz_timings"""
     _fields_ = [("scan_ms", C.c_float), ("huff_ms", C.c_float), ("lz_ms", C.c_float), ("cksum_ms", C.c_float),
@@ -41,6 +50,7 @@ SYMBOLS = [
     "tbz_inflate_batch_device", "tbz_adler32_device", "tbz_crc32_device", "tbz_device_malloc",
     "tbz_device_free", "tbz_memcpy_h2d", "tbz_memcpy_d2h", "tbz_last_timings",
     "tbz_session_create", "tbz_session_destroy", "tbz_session_feed", "tbz_session_decompress",
+    "tbz_gzip_header_parse",
 ]
 
 
@@ -85,6 +95,7 @@ def load(path=None):
     L.tbz_memcpy_h2d.argtypes = [vp, vp, vp, sz]
     L.tbz_memcpy_d2h.argtypes = [vp, vp, vp, sz]
     L.tbz_last_timings.argtypes = [vp, C.POINTER(Timings)]
+    L.tbz_gzip_header_parse.argtypes = [vp, sz, C.POINTER(GzipHeader)]
     L.tbz_session_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.tbz_session_destroy.argtypes = [vp]
     L.tbz_session_destroy.restype = None

@@ -317,9 +317,72 @@ class ZlibState(DeflateState):
 
 
 class GzipState(DeflateState):
-    """gzip-state (gzip.lisp:3-28)"""
+    """gzip-state (gzip.lisp:3-28).  The metadata slots are filled as the header arrives, with the reference's values
+    (gzip.lisp:123-241; keywords as strings): compression_method "deflate", flags a list of "text" / "header-crc" /
+    "extra" / "name" / "comment" in the reference's (pushed) order, extra octets, name / comment strings (utf-8, else
+    iso-8859-1), operating_system, mtime_unix / mtime_universal (None when the header's MTIME is 0),
+    compression_level "maximum" / "fastest" / the XFL octet."""
     format = FORMATS["gzip"]
     format_name = "gzip"
+
+    def __init__(self, output_buffer=None):
+        super().__init__(output_buffer)
+        self.compression_method = None
+        self.flags = None
+        self.extra = None
+        self.name = None
+        self.comment = None
+        self.operating_system = None
+        self.mtime_unix = None
+        self.mtime_universal = None
+        self.compression_level = "default"
+        self._hdr = bytearray()    # the header's octets as far as they have arrived
+        self._hdr_done = False
+
+    def gzip_meta(self):
+        return {k: getattr(self, k) for k in ("compression_method", "flags", "extra", "name", "comment",
+                                              "operating_system", "mtime_unix", "mtime_universal", "compression_level")}
+
+
+_GZ_OS = ("fat", "amiga", "vms", "unix", "vm/cms", "atari-tos", "hpfs", "macintosh", "z-system", "cp/m", "tops-20",
+          "ntfs", "qdos", "acorn-riscos")
+
+
+def _note_gzip_header(eng, state, octets):
+    """gzip.lisp:123-241: the metadata slots, from the header octets the state has been given so far (host side:
+    tbz_gzip_header_parse; the device only skips the header)"""
+    if state._hdr_done:
+        return
+    state._hdr += octets[:max(0, 70000 - len(state._hdr))]
+    h = _lib.GzipHeader()
+    hb = bytes(state._hdr)
+    eng.lib.tbz_gzip_header_parse(_addr(hb), len(hb), C.byref(h))
+    stage = h.stage    # how far the parse got: 2 cm+flg, 3 mtime, 4 xfl+os, 5 extra, 6 name, 7 comment
+
+    def text(off, n):
+        b = hb[off:off + n]
+        try:
+            return b.decode("utf-8")
+        except UnicodeDecodeError:
+            return b.decode("iso-8859-1")
+    if stage >= 2:
+        state.compression_method = "deflate"
+        state.flags = [k for bit, k in ((4, "comment"), (3, "name"), (2, "extra"), (1, "header-crc"), (0, "text"))
+                       if h.flg >> bit & 1]
+    if stage >= 3 and h.mtime:
+        state.mtime_unix = h.mtime
+        state.mtime_universal = h.mtime + 2208988800
+    if stage >= 4:
+        state.compression_level = {2: "maximum", 4: "fastest"}.get(h.xfl, h.xfl)
+        state.operating_system = _GZ_OS[h.os] if h.os <= 13 else ("unknown", h.os)
+    if stage >= 5 and h.flg & 4:
+        state.extra = hb[h.extra_off:h.extra_off + h.extra_len]
+    if stage >= 6 and h.flg & 8:
+        state.name = text(h.name_off, h.name_len)
+    if stage >= 7 and h.flg & 16:
+        state.comment = text(h.comment_off, h.comment_len)
+    if h.status != _lib.INPUT_UNDERRUN:
+        state._hdr_done = True   # complete, or an error the decode will raise
 
 
 def make_deflate_state(output_buffer=None):
@@ -396,10 +459,20 @@ def decompress(context, state, engine=None):
             raise ThreeBzError(-22, "octet pointer used outside its scope (or null / empty)")
         if n_in > 0:
             eng.session_feed(state._sess, context.pointer + context.offset, n_in, on_device=context.op.device)
+            if isinstance(state, GzipState) and not state._hdr_done:
+                head = min(n_in, 70000)
+                if context.op.device:
+                    hb = bytearray(head)
+                    eng.d2h(hb, context.pointer + context.offset, head)
+                else:
+                    hb = C.string_at(context.pointer + context.offset, head)
+                _note_gzip_header(eng, state, bytes(hb))
     elif n_in > 0:
         mv = memoryview(context.octet_vector)[context.offset:context.end]
         data = bytes(mv)   # (pinned for the duration of the call, as cffi:with-pointer-to-vector-data does)
         eng.session_feed(state._sess, _addr(data), n_in)
+        if isinstance(state, GzipState):
+            _note_gzip_header(eng, state, data)
     if n_in > 0:
         state._fed += n_in
         context.offset = context.end

@@ -1881,6 +1881,73 @@ int tbz_inflate(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len, uint
   return stage_batch(ctx, format, 1, &in, &in_len, &out, &out_cap, res, false);
 }
 
+int tbz_gzip_header_parse(const uint8_t* in, size_t in_len, tbz_gzip_header* h) {
+  if (!h || (in_len && !in)) return TBZ_E_ARG;
+  memset(h, 0, sizeof(*h));
+  size_t p = 0;
+  uint32_t crc = 0xffffffffu;
+  auto crc_octet = [&](uint8_t b) {
+    crc ^= b;
+    for (int k = 0; k < 8; k++) crc = (crc & 1) ? (0xedb88320u ^ (crc >> 1)) : (crc >> 1);
+  };
+  auto take = [&](size_t n) -> bool {  // the next n octets, all or input-underrun (the reference reads fields whole)
+    if (p + n > in_len) {
+      h->status = TBZ_INPUT_UNDERRUN;
+      return false;
+    }
+    for (size_t i = 0; i < n; i++) crc_octet(in[p + i]);
+    p += n;
+    return true;
+  };
+  // h->stage says how far the header has been read: the reference fills the state's slots as it goes
+  if (!take(2)) return 0;                                    // gzip.lisp:113-121
+  if (in[0] != 0x1f || in[1] != 0x8b) { h->status = TBZ_E_GZIP_MAGIC; return 0; }
+  h->stage = 1;
+  if (!take(2)) return 0;                                    // gzip.lisp:123-139
+  h->cm = in[2];
+  h->flg = in[3];
+  if (h->cm != 8) { h->status = TBZ_E_GZIP_METHOD; return 0; }
+  if (h->flg >> 5) { h->status = TBZ_E_GZIP_FLAGS; return 0; }
+  h->stage = 2;
+  if (!take(4)) return 0;                                    // gzip.lisp:144-157
+  h->mtime = (uint32_t)in[4] | ((uint32_t)in[5] << 8) | ((uint32_t)in[6] << 16) | ((uint32_t)in[7] << 24);
+  h->stage = 3;
+  if (!take(2)) return 0;                                    // gzip.lisp:159-176
+  h->xfl = in[8];
+  h->os = in[9];
+  h->stage = 4;
+  if (h->flg & 4) {                                          // gzip.lisp:177-196
+    if (!take(2)) return 0;
+    h->extra_len = (uint32_t)in[p - 2] | ((uint32_t)in[p - 1] << 8);
+    h->extra_off = (uint32_t)p;
+    if (!take(h->extra_len)) return 0;
+  }
+  h->stage = 5;
+  for (int f = 0; f < 2; f++) {                              // gzip.lisp:197-241: zero-terminated name, comment
+    if (h->flg & (f ? 16 : 8)) {
+      const size_t s0 = p;
+      for (;;) {
+        if (!take(1)) return 0;
+        if (in[p - 1] == 0) break;
+      }
+      (f ? h->comment_off : h->name_off) = (uint32_t)s0;
+      (f ? h->comment_len : h->name_len) = (uint32_t)(p - 1 - s0);
+    }
+    h->stage = 6 + (uint32_t)f;
+  }
+  if (h->flg & 2) {                                          // gzip.lisp:242-255
+    const uint32_t want = (crc ^ 0xffffffffu) & 0xffffu;
+    if (p + 2 > in_len) { h->status = TBZ_INPUT_UNDERRUN; return 0; }
+    h->hcrc_present = 1;
+    h->hcrc = (uint32_t)in[p] | ((uint32_t)in[p + 1] << 8);
+    p += 2;
+    if (h->hcrc != want) { h->status = TBZ_E_GZIP_HCRC; return 0; }
+  }
+  h->header_len = (uint32_t)p;
+  h->stage = 8;
+  return 0;
+}
+
 int tbz_inflate_alloc(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len, tbz_alloc_fn alloc, void* user,
                       tbz_result* res) {
   using namespace tbz;

@@ -194,6 +194,25 @@ void tbz_session_destroy(tbz_session* s);
 int tbz_session_feed(tbz_session* s, const void* in, size_t in_len, int in_on_device);
 int tbz_session_decompress(tbz_session* s, uint8_t* out, size_t out_cap, tbz_result* res);
 
+/* ---- gzip header metadata (host side; no device involved) --------------------------------------
+ * What decompress-gzip leaves in the gzip-state's slots while it reads the header (gzip.lisp:110-266:
+ * compression-method, flags, mtime, compression level, operating system, extra / name / comment fields, header CRC).
+ * The engine itself only needs to skip the header (K1 does, checking what the reference checks); a host that wants the
+ * metadata — the Lisp shim fills the gzip-state's slots from it — parses the octets it holds with this function.
+ * status: 0 = complete header; TBZ_INPUT_UNDERRUN = `in` ends inside the header; TBZ_E_GZIP_MAGIC / _METHOD / _FLAGS
+ * / _HCRC = the error the reference signals (gzip.lisp:120-134, :255).  Offsets are into `in`; name / comment
+ * lengths exclude the terminating zero octet.  Fields up to `stage` are valid whatever the status. */
+typedef struct tbz_gzip_header {
+  int32_t status;
+  uint32_t header_len;   /* octets before the first deflate block */
+  uint32_t cm, flg, mtime, xfl, os;
+  uint32_t extra_off, extra_len, name_off, name_len, comment_off, comment_len;
+  uint32_t hcrc_present, hcrc;
+  uint32_t stage;        /* how far the header was read (the reference fills its slots as it goes): 1 magic, 2 CM+FLG,
+                            3 MTIME, 4 XFL+OS, 5 extra field, 6 name, 7 comment, 8 header CRC = complete */
+} tbz_gzip_header;
+int tbz_gzip_header_parse(const uint8_t* in, size_t in_len, tbz_gzip_header* out);
+
 /* ---- checksums over device memory -------------------------------------------------------
  * (adler32 buf end s1 s2) checksums.lisp:167-174 and (crc32/table buf end crc) :196-210,
  * same chaining convention: pass the previous (s1,s2) / finalised crc back in. */

@@ -1,27 +1,42 @@
 ;;;; 3bz-amd.lisp — CFFI shim: 3bz's exported API (package.lisp:13-27) over lib3bz_amd.so.
 ;;;;
 ;;;; Host code stays Common Lisp; this file is the thin layer BASELINE.json's north_star asks for.
-;;;; It binds include/tbz_amd.h one-to-one and re-exports the same symbols 3bz exports, with the
+;;;; It binds include/tbz_amd.h one-to-one and re-exports the same 14 symbols 3bz exports, with the
 ;;;; same lambda lists and return values, so `(3bz-amd:decompress-vector v :format :zlib)` is a
-;;;; drop-in for `(3bz:decompress-vector v :format :zlib)` on the octet-vector path.
+;;;; drop-in for `(3bz:decompress-vector v :format :zlib)`.
 ;;;;
-;;;; STATUS: written against the header; NOT loadable/testable in the build image (no Lisp
-;;;; implementation exists there — SURVEY §8c).  The same surface, in Python over ctypes, is
-;;;; 3bz_amd/api.py and is what the parity tests drive.  Keep the two in step.
+;;;; STATUS: written against the header; NOT loadable in the build image (no Lisp implementation
+;;;; exists there — SURVEY §8c).  tests/test_lisp_shim.py parses the defcstruct / defcfun / export
+;;;; forms below and checks them against include/tbz_amd.h, the ctypes binding and the reference's
+;;;; package.lisp; the same surface in Python over ctypes is 3bz_amd/api.py, which the parity
+;;;; tests drive.  Keep the two in step.
 ;;;;
-;;;; Resuming a state after input-underrun / output-overflow (3bz's chunked protocol,
-;;;; deflate.lisp:114-137) is not implemented on the device path yet (SURVEY §8f-2): the second
-;;;; DECOMPRESS call on an unfinished state signals an error instead of silently falling back.
+;;;; The chunked protocol (more input after input-underrun, a new buffer after output-overflow:
+;;;; deflate.lisp:114-137, api.lisp:12-21) runs on a tbz_session: the resumable part of a
+;;;; deflate-state lives on the device.
 
 (defpackage #:3bz-amd
   (:use #:cl)
-  (:export #:decompress #:decompress-vector
-           #:make-octet-vector-context
-           #:make-deflate-state #:make-zlib-state #:make-gzip-state
-           #:finished #:input-underrun #:output-overflow
-           #:replace-output-buffer
-           ;; engine management (no counterpart in 3bz: a deflate-state is self-contained)
-           #:*engine* #:open-engine #:close-engine #:with-engine))
+  (:export
+   ;; ---- the reference's 14 (package.lisp:13-27)
+   #:decompress
+   #:decompress-vector
+   #:with-octet-pointer
+   #:make-octet-vector-context
+   #:make-octet-stream-context
+   #:make-octet-pointer-context
+   #:make-deflate-state
+   #:make-zlib-state
+   #:make-gzip-state
+   #:finished
+   #:input-underrun
+   #:output-overflow
+   #:%resync-file-stream
+   #:replace-output-buffer
+   ;; ---- engine management (no counterpart in 3bz: a deflate-state is self-contained)
+   #:*engine* #:open-engine #:close-engine #:with-engine #:trim-engine
+   ;; ---- beyond the reference (SURVEY §8f-4): every member of a multi-member .gz
+   #:decompress-gzip-members))
 (in-package #:3bz-amd)
 
 (cffi:define-foreign-library lib3bz-amd
@@ -36,14 +51,32 @@
   (adler32 :uint32) (crc32 :uint32) (trailer-check :uint32) (trailer-isize :uint32)
   (flags :uint32) (reserved :uint32) (boundary-out :uint64))
 
+;;; struct tbz_gzip_header — include/tbz_amd.h
+(cffi:defcstruct tbz-gzip-header
+  (status :int32) (header-len :uint32)
+  (cm :uint32) (flg :uint32) (mtime :uint32) (xfl :uint32) (os :uint32)
+  (extra-off :uint32) (extra-len :uint32) (name-off :uint32) (name-len :uint32)
+  (comment-off :uint32) (comment-len :uint32) (hcrc-present :uint32) (hcrc :uint32) (stage :uint32))
+
 (cffi:defcfun ("tbz_ctx_create" %ctx-create) :int (device :int) (out :pointer))
 (cffi:defcfun ("tbz_ctx_destroy" %ctx-destroy) :void (ctx :pointer))
+(cffi:defcfun ("tbz_ctx_trim" %ctx-trim) :int (ctx :pointer))
 (cffi:defcfun ("tbz_strerror" %strerror) :string (code :int))
 (cffi:defcfun ("tbz_last_error" %last-error) :string (ctx :pointer))
 (cffi:defcfun ("tbz_inflate" %inflate) :int
   (ctx :pointer) (format :int) (in :pointer) (in-len :size) (out :pointer) (out-cap :size) (res :pointer))
-(cffi:defcfun ("tbz_inflate_size" %inflate-size) :int
-  (ctx :pointer) (format :int) (in :pointer) (in-len :size) (res :pointer))
+(cffi:defcfun ("tbz_inflate_alloc" %inflate-alloc) :int
+  (ctx :pointer) (format :int) (in :pointer) (in-len :size) (alloc :pointer) (user :pointer) (res :pointer))
+(cffi:defcfun ("tbz_inflate_batch" %inflate-batch) :int
+  (ctx :pointer) (format :int) (n :size) (ins :pointer) (in-lens :pointer) (outs :pointer) (out-caps :pointer)
+  (results :pointer))
+(cffi:defcfun ("tbz_session_create" %session-create) :int (ctx :pointer) (format :int) (out :pointer))
+(cffi:defcfun ("tbz_session_destroy" %session-destroy) :void (session :pointer))
+(cffi:defcfun ("tbz_session_feed" %session-feed) :int
+  (session :pointer) (in :pointer) (in-len :size) (in-on-device :int))
+(cffi:defcfun ("tbz_session_decompress" %session-decompress) :int
+  (session :pointer) (out :pointer) (out-cap :size) (res :pointer))
+(cffi:defcfun ("tbz_gzip_header_parse" %gzip-header-parse) :int (in :pointer) (in-len :size) (out :pointer))
 
 (deftype octet () '(unsigned-byte 8))
 (deftype octet-vector () '(simple-array octet (*)))
@@ -60,24 +93,81 @@
 (defmacro with-engine ((&optional (device 0)) &body body)
   `(let ((*engine* nil)) (open-engine ,device) (unwind-protect (progn ,@body) (close-engine))))
 (defun engine () (or *engine* (open-engine)))
+(defun trim-engine () (when *engine* (%ctx-trim *engine*)))
 
 (defun format-code (format)
   (ecase format (:deflate 0) (:zlib 1) (:gzip 2)))  ; api.lisp:31-34
 
-;;; io-common.lisp:36-45 — octet-vector-context + context-boxes
-(defstruct (octet-vector-context (:constructor %make-ovc))
-  octet-vector (start 0) (end 0) (offset 0))
-(defun make-octet-vector-context (vector &key (start 0) (offset start) (end (length vector)))
-  (%make-ovc :octet-vector vector :start start :end end :offset offset))
+(defun check-call (r what)
+  (unless (zerop r) (error "~a: ~a: ~a" what (%strerror r) (%last-error (engine)))))
 
-;;; deflate.lisp:4-62 / zlib.lisp:3-12 / gzip.lisp:3-28 — the observable slots
+;;; ---- contexts -------------------------------------------------------------------------------
+;;; io-common.lisp:8-14,36-45 — context-boxes (start, end, offset) + octet-vector-context
+(defstruct (context-boxes (:conc-name cb-)) (start 0) (end 0) (offset 0))
+
+(defclass octet-vector-context ()
+  ((octet-vector :reader octet-vector :initarg :octet-vector)
+   (boxes :reader boxes :initarg :boxes)))
+(defun make-octet-vector-context (vector &key (start 0) (offset start) (end (length vector)))
+  (make-instance 'octet-vector-context
+                 :octet-vector vector
+                 :boxes (make-context-boxes :start start :offset offset :end end)))
+
+;;; io-common.lisp:47-69 — a file stream; the reference reads it octet by octet ("very slow", README.md:13);
+;;; here what the boxes span is read in one READ-SEQUENCE and handed to the session
+(defclass octet-stream-context ()
+  ((octet-stream :reader octet-stream :initarg :octet-stream)
+   (boxes :reader boxes :initarg :boxes)))
+(defun make-octet-stream-context (file-stream &key (start 0) (offset 0) (end (file-length file-stream)))
+  (make-instance 'octet-stream-context
+                 :octet-stream file-stream
+                 :boxes (make-context-boxes :start start :offset offset :end end)))
+(defgeneric %resync-file-stream (context))
+(defmethod %resync-file-stream (context) (declare (ignore context)))
+(defmethod %resync-file-stream ((context octet-stream-context))
+  (file-position (octet-stream context) (cb-offset (boxes context))))
+(defun valid-octet-stream (os)
+  (and (typep os 'stream) (subtypep (stream-element-type os) 'octet) (open-stream-p os) (input-stream-p os)))
+
+;;; io-mmap.lisp:21-54 — foreign memory valid inside a dynamic scope.  :DEVICE T says the memory is HBM (a raw
+;;; device pointer): the session copies it device to device.
+(defclass octet-pointer ()
+  ((base :reader base :initarg :base)
+   (size :reader size :initarg :size)
+   (scope :reader scope :initarg :scope)
+   (device :reader device-p :initarg :device :initform nil)))
+(defmacro with-octet-pointer ((var pointer size &key device) &body body)
+  (let ((scope (gensym "SCOPE")))
+    `(let* ((,scope (cons t ',var)))
+       (unwind-protect
+            (let ((,var (make-instance 'octet-pointer :base ,pointer :size ,size :scope ,scope :device ,device)))
+              ,@body)
+         (setf (car ,scope) nil)))))
+(defun valid-octet-pointer (op)
+  (and (car (scope op)) (not (cffi:null-pointer-p (base op))) (plusp (size op))))
+(defclass octet-pointer-context ()
+  ((op :reader op :initarg :op)
+   (pointer :reader %pointer :initarg :pointer)
+   (boxes :reader boxes :initarg :boxes)))
+(defun make-octet-pointer-context (octet-pointer &key (start 0) (offset 0) (end (size octet-pointer)))
+  (make-instance 'octet-pointer-context
+                 :op octet-pointer
+                 :pointer (base octet-pointer)
+                 :boxes (make-context-boxes :start start :offset offset :end end)))
+
+;;; ---- states ---------------------------------------------------------------------------------
+;;; deflate.lisp:4-62 / zlib.lisp:3-12 / gzip.lisp:3-28 — the observable slots; the resumable part is the session
 (defstruct (deflate-state (:conc-name ds-))
   (output-buffer (make-array 0 :element-type 'octet) :type octet-vector)
   (output-offset 0 :type fixnum)
   (finished nil) (output-overflow nil) (input-underrun nil)
-  (calls 0 :type fixnum))
+  (session nil)               ; tbz_session*
+  (fed 0 :type fixnum))       ; input octets given to the session so far
 (defstruct (zlib-state (:include deflate-state)))
-(defstruct (gzip-state (:include deflate-state)))
+(defstruct (gzip-state (:include deflate-state) (:conc-name gs-))
+  (compression-method nil) (flags nil) (extra nil) (name nil) (comment nil)
+  (operating-system nil) (mtime/unix nil) (mtime/universal nil) (compression-level :default)
+  (header-octets (make-array 16 :element-type 'octet :adjustable t :fill-pointer 0)) (header-parsed nil))
 
 (defun finished (state) (ds-finished state))                  ; api.lisp:67-68
 (defun input-underrun (state) (ds-input-underrun state))      ; api.lisp:69-70
@@ -93,66 +183,163 @@
 (defun state-format (state)
   (etypecase state (gzip-state 2) (zlib-state 1) (deflate-state 0)))
 
-(defun %call-inflate (format vector start end out)
-  "pin both vectors (the pattern of 3bz's own bench.lisp:61) and run one tbz_inflate"
-  (cffi:with-foreign-object (res '(:struct tbz-result))
-    (cffi:with-pointer-to-vector-data (pin vector)
-      (cffi:with-pointer-to-vector-data (pout out)
-        (let ((r (%inflate (engine) format (cffi:inc-pointer pin start) (- end start)
-                           pout (length out) res)))
-          (unless (zerop r) (error "tbz_inflate: ~a: ~a" (%strerror r) (%last-error (engine)))))))
-    (cffi:with-foreign-slots ((status out-len out-total in-consumed flags) res (:struct tbz-result))
-      (values status out-len out-total in-consumed flags))))
+(defun ensure-session (state)
+  (or (ds-session state)
+      (cffi:with-foreign-object (p :pointer)
+        (check-call (%session-create (engine) (state-format state) p) "tbz_session_create")
+        (let ((s (cffi:mem-ref p :pointer)))
+          ;; the device memory goes with the state
+          #+sbcl (sb-ext:finalize state (lambda () (%session-destroy s)) :dont-save t)
+          (setf (ds-session state) s)))))
 
-(defun decompress (context state)                              ; api.lisp:3-10
-  (when (and (plusp (ds-calls state)) (not (ds-finished state)))
-    (error "resuming a stream (chunked input/output) is not implemented on the device path"))
-  (incf (ds-calls state))
-  (setf (ds-input-underrun state) nil (ds-output-overflow state) nil)
-  (multiple-value-bind (status out-len out-total in-consumed flags)
-      (%call-inflate (state-format state)
-                     (octet-vector-context-octet-vector context)
-                     (octet-vector-context-offset context)
-                     (octet-vector-context-end context)
-                     (ds-output-buffer state))
-    (declare (ignore out-total))
-    (when (minusp status) (error "~a" (%strerror status)))     ; Lisp conditions of the reference
-    (setf (ds-finished state) (= status 0)
-          (ds-input-underrun state) (= status 1)
-          (ds-output-overflow state) (= status 2)
-          (ds-output-offset state) out-len)
-    (if (ds-finished state)
-        (incf (octet-vector-context-offset context) in-consumed)
-        (setf (octet-vector-context-offset context) (octet-vector-context-end context)))
-    ;; gzip: final block decoded but crc32/ISIZE cut off => (return-from decompress-gzip 0)
-    (if (and (= status 1) (typep state 'gzip-state) (logbitp 1 flags))
-        0
-        out-len)))
+;;; gzip header metadata (gzip.lisp:144-241), decoded on the host from the octets the state has been given
+(defun note-gzip-header (state octets start end)
+  (unless (gs-header-parsed state)
+    (loop for i from start below end
+          while (< (fill-pointer (gs-header-octets state)) 70000)
+          do (vector-push-extend (aref octets i) (gs-header-octets state)))
+    (let* ((hb (coerce (gs-header-octets state) 'octet-vector))
+           (n (length hb)))
+      (cffi:with-foreign-object (h '(:struct tbz-gzip-header))
+        (cffi:with-pointer-to-vector-data (p hb)
+          (%gzip-header-parse p n h))
+        (cffi:with-foreign-slots ((status stage flg mtime xfl os extra-off extra-len name-off name-len
+                                          comment-off comment-len)
+                                  h (:struct tbz-gzip-header))
+          ;; the reference fills the slots as it reads (gzip.lisp:123-241): `stage` says how far the octets reach
+          (flet ((text (off len)           ; "rfc says 8859-1, but try utf8 anyway" (gzip.lisp:209-217)
+                   (let ((o (subseq hb off (+ off len))))
+                     (or (ignore-errors (babel:octets-to-string o :encoding :utf-8 :errorp t))
+                         (babel:octets-to-string o :encoding :iso-8859-1)))))
+            (when (>= stage 2)
+              (setf (gs-compression-method state) :deflate
+                    (gs-flags state) (append (when (logbitp 4 flg) '(:comment)) (when (logbitp 3 flg) '(:name))
+                                             (when (logbitp 2 flg) '(:extra)) (when (logbitp 1 flg) '(:header-crc))
+                                             (when (logbitp 0 flg) '(:text)))))
+            (when (and (>= stage 3) (not (zerop mtime)))
+              (setf (gs-mtime/unix state) mtime
+                    (gs-mtime/universal state) (+ mtime (encode-universal-time 0 0 0 1 1 1970 0))))
+            (when (>= stage 4)
+              (setf (gs-compression-level state) (or (case xfl (2 :maximum) (4 :fastest)) xfl)
+                    (gs-operating-system state)
+                    (if (<= 0 os 13)
+                        (aref #(:fat :amiga :vms :unix :vm/cms :atari-tos :hpfs :macintosh :z-system :cp/m :tops-20
+                                :ntfs :qdos :acorn-riscos)
+                              os)
+                        (list :unknown os))))
+            (when (and (>= stage 5) (logbitp 2 flg)) (setf (gs-extra state) (subseq hb extra-off (+ extra-off extra-len))))
+            (when (and (>= stage 6) (logbitp 3 flg)) (setf (gs-name state) (text name-off name-len)))
+            (when (and (>= stage 7) (logbitp 4 flg)) (setf (gs-comment state) (text comment-off comment-len)))
+            (unless (= status 1) (setf (gs-header-parsed state) t))))))))
+
+;;; ---- decompress (api.lisp:3-10) --------------------------------------------------------------
+(defun feed-context (context state session)
+  "hand the octets of the context from offset to end to the session, return how many"
+  (let* ((b (boxes context))
+         (n (- (cb-end b) (cb-offset b))))
+    (when (plusp n)
+      (etypecase context
+        (octet-vector-context
+         (let ((v (octet-vector context)))
+           (when (typep state 'gzip-state) (note-gzip-header state v (cb-offset b) (cb-end b)))
+           (cffi:with-pointer-to-vector-data (p v)   ; pinned for the call (the pattern of bench.lisp:61)
+             (check-call (%session-feed session (cffi:inc-pointer p (cb-offset b)) n 0) "tbz_session_feed"))))
+        (octet-pointer-context
+         (assert (valid-octet-pointer (op context)))                  ; io-mmap.lisp:66
+         (check-call (%session-feed session (cffi:inc-pointer (%pointer context) (cb-offset b)) n
+                                    (if (device-p (op context)) 1 0))
+                     "tbz_session_feed"))
+        (octet-stream-context
+         (assert (valid-octet-stream (octet-stream context)))         ; io.lisp:71
+         (let ((v (make-array n :element-type 'octet)))
+           (file-position (octet-stream context) (cb-offset b))
+           (setf n (read-sequence v (octet-stream context)))
+           (when (typep state 'gzip-state) (note-gzip-header state v 0 n))
+           (cffi:with-pointer-to-vector-data (p v)
+             (check-call (%session-feed session p n 0) "tbz_session_feed")))))
+      (setf (cb-offset b) (+ (cb-offset b) n)))
+    (max n 0)))
+
+(defun decompress (context state)
+  (let* ((session (ensure-session state))
+         (b (boxes context))
+         (start-offset (cb-offset b))
+         (fed-before (ds-fed state)))
+    (setf (ds-input-underrun state) nil (ds-output-overflow state) nil)
+    (when (ds-finished state) (return-from decompress (ds-output-offset state)))
+    (incf (ds-fed state) (feed-context context state session))
+    (let* ((out (ds-output-buffer state))
+           (off (ds-output-offset state))
+           (room (max 0 (- (length out) off))))
+      (cffi:with-foreign-object (res '(:struct tbz-result))
+        (cffi:with-pointer-to-vector-data (pout out)
+          (check-call (%session-decompress session (cffi:inc-pointer pout off) room res) "tbz_session_decompress"))
+        (cffi:with-foreign-slots ((status out-len in-consumed flags) res (:struct tbz-result))
+          (setf (ds-output-offset state) (+ off out-len))
+          (when (minusp status) (error "~a" (%strerror status)))     ; the Lisp conditions of the reference
+          (setf (ds-finished state) (= status 0)
+                (ds-input-underrun state) (= status 1)
+                (ds-output-overflow state) (= status 2))
+          (when (ds-finished state)
+            ;; the context stands just behind the stream, its trailer included
+            (setf (cb-offset b) (+ start-offset (max 0 (- in-consumed fed-before))))
+            (when (typep context 'octet-stream-context) (%resync-file-stream context)))
+          ;; gzip: final block decoded but crc32/ISIZE cut off => (return-from decompress-gzip 0)
+          (if (and (= status 1) (typep state 'gzip-state) (logbitp 1 flags))
+              0
+              (ds-output-offset state)))))))
+
+;;; ---- decompress-vector (api.lisp:23-65) -----------------------------------------------------
+(defvar *alloc-result* nil)
+(cffi:defcallback alloc-octets :pointer ((user :pointer) (n :size))
+  (declare (ignore user))
+  ;; tbz_alloc_fn: the engine knows the size now.  The vector must not move while the engine copies into it:
+  ;; a static vector (or a pinned one) — here CFFI's shareable vector
+  (setf *alloc-result* (cffi:make-shareable-byte-vector n))
+  (if (zerop n)
+      (cffi:null-pointer)
+      (cffi:with-pointer-to-vector-data (p *alloc-result*) p)))
 
 (defun decompress-vector (compressed &key (format :zlib) (start 0) (end (length compressed)) output)
-  "api.lisp:23-65.  Returns (values buffer count)."
+  "Returns (values buffer count)."
   (let ((fmt (format-code format)))
     (flet ((check (status)
              (when (minusp status) (error "~a" (%strerror status)))
              (unless (= status 0)
                (if (= status 1)
-                   (error "incomplete ~a stream" format)                      ; api.lisp:43-44
+                   (error "incomplete ~a stream" format)                          ; api.lisp:43-44
                    (error "not enough space to decompress ~a stream" format)))))  ; api.lisp:45-46
-      (if output
-          (multiple-value-bind (status out-len) (%call-inflate fmt compressed start end output)
-            (check status)
-            (values output out-len))
-          ;; the reference grows 32 KiB buffers by doubling and gathers (api.lisp:48-65);
-          ;; the engine's count pass gives the size, so allocate exactly once
-          (cffi:with-foreign-object (res '(:struct tbz-result))
-            (cffi:with-pointer-to-vector-data (pin compressed)
-              (let ((r (%inflate-size (engine) fmt (cffi:inc-pointer pin start) (- end start) res)))
-                (unless (zerop r) (error "tbz_inflate_size: ~a" (%strerror r)))))
-            (let ((status (cffi:foreign-slot-value res '(:struct tbz-result) 'status))
-                  (total (cffi:foreign-slot-value res '(:struct tbz-result) 'out-total)))
-              (when (minusp status) (error "~a" (%strerror status)))
-              (when (= status 1) (error "incomplete ~a stream" format))       ; api.lisp:55 assert
-              (let ((buf (make-array total :element-type 'octet)))
-                (multiple-value-bind (status2 out-len) (%call-inflate fmt compressed start end buf)
-                  (check status2)
-                  (values buf out-len)))))))))
+      (cffi:with-foreign-object (res '(:struct tbz-result))
+        (cffi:with-pointer-to-vector-data (pin compressed)
+          (if output
+              (cffi:with-pointer-to-vector-data (pout output)
+                (check-call (%inflate (engine) fmt (cffi:inc-pointer pin start) (- end start) pout (length output) res)
+                            "tbz_inflate"))
+              ;; the reference grows 32 KiB buffers by doubling and gathers (api.lisp:48-65); the engine decodes
+              ;; once and asks for the buffer when it knows the size
+              (let ((*alloc-result* nil))
+                (check-call (%inflate-alloc (engine) fmt (cffi:inc-pointer pin start) (- end start)
+                                            (cffi:callback alloc-octets) (cffi:null-pointer) res)
+                            "tbz_inflate_alloc")
+                (setf output (or *alloc-result* (make-array 0 :element-type 'octet))))))
+        (check (cffi:foreign-slot-value res '(:struct tbz-result) 'status))
+        (values output (cffi:foreign-slot-value res '(:struct tbz-result) 'out-len))))))
+
+;;; ---- every member of a multi-member .gz (SURVEY §8f-4; 3bz stops after the first: gzip.lisp:277-286) ----
+(defun decompress-gzip-members (compressed &key (start 0) (end (length compressed)))
+  "a list of octet vectors, one per member: each is what (decompress-vector v :format :gzip :start member-offset)
+returns.  Members are found one after the other (tbz_result.in_consumed says where the next one starts)."
+  (loop with pos = start
+        while (and (< (+ pos 2) end) (= (aref compressed pos) #x1f) (= (aref compressed (1+ pos)) #x8b))
+        collect (let ((state (make-gzip-state :output-buffer (make-array 0 :element-type 'octet)))
+                      (ctx (make-octet-vector-context compressed :start pos :end end))
+                      (parts nil))
+                  (loop for out = (make-array 65536 :element-type 'octet)
+                          then (make-array (* 2 (length out)) :element-type 'octet)
+                        do (replace-output-buffer state out)
+                           (let ((c (decompress ctx state)))
+                             (when (input-underrun state) (error "incomplete gzip stream"))
+                             (push (subseq out 0 c) parts))
+                        until (finished state))
+                  (setf pos (cb-offset (boxes ctx)))
+                  (apply #'concatenate 'octet-vector (nreverse parts)))))

@@ -60,6 +60,7 @@ def lib():
         L.tbzo_output_offset.argtypes = [C.c_void_p]
         L.tbzo_errmsg.restype = C.c_char_p
         L.tbzo_errmsg.argtypes = [C.c_void_p]
+        L.tbzo_get_gzip_meta.argtypes = [C.c_void_p, C.c_void_p]
         L.tbzo_checksum.restype = C.c_uint32
         L.tbzo_checksum.argtypes = [C.c_void_p]
         L.tbzo_decompress_vector_into.restype = C.c_int64
@@ -114,6 +115,14 @@ def make_octet_vector_context(vector, start=0, offset=None, end=None):
     return OctetVectorContext(vector, start, offset, end)
 
 
+class _GzipMeta(C.Structure):
+    _fields_ = [("have_cm", C.c_int), ("have_mtime", C.c_int), ("have_os", C.c_int), ("have_extra", C.c_int),
+                ("have_name", C.c_int), ("have_comment", C.c_int), ("flg", C.c_uint32), ("mtime", C.c_uint32),
+                ("xfl", C.c_uint32), ("os", C.c_uint32), ("extra", C.c_void_p), ("name", C.c_void_p),
+                ("comment", C.c_void_p), ("extra_len", C.c_size_t), ("name_len", C.c_size_t),
+                ("comment_len", C.c_size_t)]
+
+
 class State:
     """deflate-state / zlib-state / gzip-state (deflate.lisp:4-62, zlib.lisp:3-12, gzip.lisp:3-28)"""
 
@@ -135,6 +144,40 @@ class State:
     @property
     def checksum(self):
         return lib().tbzo_checksum(self._p)
+
+    def gzip_meta(self):
+        """the gzip-state's metadata slots as decompress-gzip has filled them so far, with the reference's values
+        (gzip.lisp:123-241): keywords as strings, name / comment decoded utf-8 else iso-8859-1 (gzip.lisp:209-217)"""
+        m = _GzipMeta()
+        lib().tbzo_get_gzip_meta(self._p, C.byref(m))
+
+        def text(p, n):
+            b = C.string_at(p, n) if n else b""
+            try:
+                return b.decode("utf-8")
+            except UnicodeDecodeError:
+                return b.decode("iso-8859-1")
+        out = {"compression_method": None, "flags": None, "extra": None, "name": None, "comment": None,
+               "operating_system": None, "mtime_unix": None, "mtime_universal": None, "compression_level": "default"}
+        if m.have_cm:
+            out["compression_method"] = "deflate"
+            out["flags"] = [k for bit, k in ((4, "comment"), (3, "name"), (2, "extra"), (1, "header-crc"), (0, "text"))
+                            if m.flg >> bit & 1]    # (push ...) in bit order 0..4: the list reads the other way round
+        if m.have_mtime and m.mtime:
+            out["mtime_unix"] = m.mtime
+            out["mtime_universal"] = m.mtime + 2208988800   # (encode-universal-time 0 0 0 1 1 1970 0)
+        if m.have_os:
+            out["compression_level"] = {2: "maximum", 4: "fastest"}.get(m.xfl, m.xfl)
+            names = ("fat", "amiga", "vms", "unix", "vm/cms", "atari-tos", "hpfs", "macintosh", "z-system", "cp/m",
+                     "tops-20", "ntfs", "qdos", "acorn-riscos")
+            out["operating_system"] = names[m.os] if m.os <= 13 else ("unknown", m.os)
+        if m.have_extra:
+            out["extra"] = C.string_at(m.extra, m.extra_len) if m.extra_len else b""
+        if m.have_name:
+            out["name"] = text(m.name, m.name_len)
+        if m.have_comment:
+            out["comment"] = text(m.comment, m.comment_len)
+        return out
 
 
 def make_deflate_state(output_buffer=None):

@@ -379,6 +379,11 @@ struct tbzo_state {
   size_t gz_header_len, gz_header_cap;
   int64_t gz_extra_len, gz_extra_read; /* extra: -1 = not yet allocated */
   int gz_name_started, gz_comment_started;
+  /* the metadata slots of gzip-state (gzip.lisp:17-25), as decompress-gzip fills them (gzip.lisp:123-241) */
+  int gz_have_cm, gz_have_mtime, gz_have_os, gz_have_extra, gz_have_name, gz_have_comment;
+  uint32_t gz_mtime, gz_xfl, gz_os;
+  uint8_t *gz_extra, *gz_name, *gz_comment;
+  size_t gz_name_len, gz_comment_len, gz_name_cap, gz_comment_cap;
   uint32_t crc32;
   uint32_t gz_isize;
   char errmsg[160];
@@ -410,6 +415,9 @@ void tbzo_free_state(tbzo_state* st) {
   if (!st) return;
   free(st->window);
   free(st->gz_header_bytes);
+  free(st->gz_extra);
+  free(st->gz_name);
+  free(st->gz_comment);
   free(st);
 }
 void tbzo_free(void* p) { free(p); }
@@ -853,6 +861,27 @@ static int64_t decompress_zlib(tbzo_context* c, tbzo_state* st) {
 }
 
 /* ---- gzip.lisp ------------------------------------------------------------- */
+/* the metadata slots as they stand (test inspection of gzip.lisp:17-25) */
+int tbzo_get_gzip_meta(const tbzo_state* st, tbzo_gzip_meta* m) {
+  memset(m, 0, sizeof(*m));
+  m->have_cm = st->gz_have_cm;
+  m->flg = (uint32_t)st->gz_flags;
+  m->have_mtime = st->gz_have_mtime;
+  m->mtime = st->gz_mtime;
+  m->have_os = st->gz_have_os;
+  m->xfl = st->gz_xfl;
+  m->os = st->gz_os;
+  m->have_extra = st->gz_have_extra;
+  m->extra = st->gz_extra;
+  m->extra_len = st->gz_have_extra ? (size_t)st->gz_extra_len : 0;
+  m->have_name = st->gz_have_name;
+  m->name = st->gz_name;
+  m->name_len = st->gz_name_len;
+  m->have_comment = st->gz_have_comment;
+  m->comment = st->gz_comment;
+  m->comment_len = st->gz_comment_len;
+  return 0;
+}
 static int need_bits(tbzo_context* c, tbzo_state* st, int n) {
   if (st->bits_remaining < n) refill(c, st);
   return st->bits_remaining >= n;
@@ -894,19 +923,26 @@ static int64_t decompress_gzip(tbzo_context* c, tbzo_state* st) {
         if (cm != 8) return fail(st, TBZO_E_GZIP_METHOD, "unknown compression method");
         if ((flg >> 5) & 7) return fail(st, TBZO_E_GZIP_FLAGS, "reserved flag bits set");
         st->gz_flags = (int)flg;
+        st->gz_have_cm = 1; /* compression-method :deflate, flags pushed (:129-142) */
         if (!(flg & 2)) st->gz_keep_header = 0; /* no header crc: stop remembering */
         st->gzip_state = G_HEADER_MTIME;
         break;
       }
       case G_HEADER_MTIME: /* :144-157 */
         GZ_NEED(32);
-        for (int i = 0; i < 4; i++) header_byte(c, st);
+        {
+          uint32_t m = 0;
+          for (int i = 0; i < 4; i++) m |= (uint32_t)header_byte(c, st) << (8 * i);
+          st->gz_mtime = m; /* mtime/unix, mtime/universal only when non-zero (:150-155) */
+          st->gz_have_mtime = 1;
+        }
         st->gzip_state = G_HEADER3;
         break;
       case G_HEADER3: /* :159-179 */
         GZ_NEED(16);
-        header_byte(c, st);
-        header_byte(c, st);
+        st->gz_xfl = header_byte(c, st); /* compression-level (:165-167) */
+        st->gz_os = header_byte(c, st);  /* operating-system (:168-175) */
+        st->gz_have_os = 1;
         st->gzip_state = G_HEADER_EXTRA;
         break;
       case G_HEADER_EXTRA: /* :180-199 */
@@ -916,12 +952,14 @@ static int64_t decompress_gzip(tbzo_context* c, tbzo_state* st) {
             unsigned lo = header_byte(c, st), hi = header_byte(c, st);
             st->gz_extra_len = lo | (hi << 8);
             st->gz_extra_read = 0;
+            st->gz_extra = (uint8_t*)calloc((size_t)st->gz_extra_len + 1, 1);
           }
           while (st->gz_extra_read < st->gz_extra_len) {
             GZ_NEED(8);
-            header_byte(c, st);
+            st->gz_extra[st->gz_extra_read] = (uint8_t)header_byte(c, st);
             st->gz_extra_read++;
           }
+          st->gz_have_extra = 1; /* coerced to a simple octet vector once complete (:195) */
         }
         st->gzip_state = G_HEADER_NAME;
         break;
@@ -929,8 +967,15 @@ static int64_t decompress_gzip(tbzo_context* c, tbzo_state* st) {
         if (st->gz_flags & 8) {
           for (;;) {
             GZ_NEED(8);
-            if (header_byte(c, st) == 0) break;
+            unsigned b = header_byte(c, st);
+            if (b == 0) break;
+            if (st->gz_name_len == st->gz_name_cap) {
+              st->gz_name_cap = st->gz_name_cap ? st->gz_name_cap * 2 : 16;
+              st->gz_name = (uint8_t*)realloc(st->gz_name, st->gz_name_cap);
+            }
+            st->gz_name[st->gz_name_len++] = (uint8_t)b;
           }
+          st->gz_have_name = 1; /* the octets; the string (utf-8, else iso-8859-1: :209-217) is made by the binding */
         }
         st->gzip_state = G_HEADER_COMMENT;
         break;
@@ -938,8 +983,15 @@ static int64_t decompress_gzip(tbzo_context* c, tbzo_state* st) {
         if (st->gz_flags & 16) {
           for (;;) {
             GZ_NEED(8);
-            if (header_byte(c, st) == 0) break;
+            unsigned b = header_byte(c, st);
+            if (b == 0) break;
+            if (st->gz_comment_len == st->gz_comment_cap) {
+              st->gz_comment_cap = st->gz_comment_cap ? st->gz_comment_cap * 2 : 16;
+              st->gz_comment = (uint8_t*)realloc(st->gz_comment, st->gz_comment_cap);
+            }
+            st->gz_comment[st->gz_comment_len++] = (uint8_t)b;
           }
+          st->gz_have_comment = 1;
         }
         st->gzip_state = G_HEADER_CRC;
         break;

@@ -77,6 +77,15 @@ const char* tbzo_errmsg(const tbzo_state*);
 /* checksum state of the wrapper (zs-s1 | zs-s2<<16, or gs-crc32) */
 uint32_t tbzo_checksum(const tbzo_state*);
 
+/* the gzip-state's metadata slots (gzip.lisp:17-25) as decompress-gzip has filled them so far (gzip.lisp:123-241) */
+typedef struct tbzo_gzip_meta {
+  int have_cm, have_mtime, have_os, have_extra, have_name, have_comment;
+  uint32_t flg, mtime, xfl, os;
+  const uint8_t *extra, *name, *comment;
+  size_t extra_len, name_len, comment_len;
+} tbzo_gzip_meta;
+int tbzo_get_gzip_meta(const tbzo_state* st, tbzo_gzip_meta* out);
+
 /* api.lisp:23-65 with :output supplied.  Returns count, or <0. */
 int64_t tbzo_decompress_vector_into(const uint8_t* in, size_t start, size_t end, int format,
                                     uint8_t* out, size_t out_len);

@@ -109,6 +109,14 @@ def main():
         json.dump(meta, f, indent=1)
     print("wrote", len(vectors), "vectors;", meta)
 
+    # the exported API: the 14 symbol NAMES of package.lisp:13-27 and the lambda lists of the functions behind them
+    # (api.lisp, io-common.lisp, io-mmap.lisp) — names and argument lists are the interface contract, kept as data
+    pkg = open(os.path.join(REF, "package.lisp")).read()
+    exports = re.findall(r"#:([^\s()]+)", pkg[pkg.index("(:export"):])
+    with open(os.path.join(HERE, "package_exports.json"), "w") as f:
+        json.dump({"source": "3bz package.lisp:13-27", "exports": exports}, f, indent=1)
+    print("exports:", exports)
+
 
 if __name__ == "__main__":
     main()

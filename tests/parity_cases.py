@@ -361,6 +361,53 @@ def case_scratch_bounds(eng):
         e2.close()
 
 
+def case_gzip_metadata(eng):
+    """the gzip header's metadata through the state's slots (gzip.lisp:17-25, filled by gzip.lisp:123-241:
+    method, flags, mtime, level, operating system, extra / name / comment), one-shot and as the header arrives
+    three octets at a time — against the oracle's restatement of the same slots"""
+    plain = _mixed_plain(20_000, 12)
+
+    def member(name=None, comment=None, extra=None, mtime=0, xfl=0, os_=3, hcrc=False, text=False):
+        flg = ((1 if text else 0) | (2 if hcrc else 0) | (4 if extra is not None else 0) | (8 if name is not None else 0) |
+               (16 if comment is not None else 0))
+        h = bytes([0x1f, 0x8b, 8, flg]) + struct.pack("<I", mtime) + bytes([xfl, os_])
+        if extra is not None:
+            h += struct.pack("<H", len(extra)) + extra
+        if name is not None:
+            h += name + b"\0"
+        if comment is not None:
+            h += comment + b"\0"
+        if hcrc:
+            h += struct.pack("<H", zlib.crc32(h) & 0xffff)
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        return h + c.compress(plain) + c.flush() + struct.pack("<II", zlib.crc32(plain), len(plain)), len(h)
+
+    variants = [dict(), dict(name=b"file.txt", mtime=1_700_000_000, xfl=2),
+                dict(comment="caf\xe9 au lait".encode("latin-1"), name="na\u00efve".encode("utf-8"), os_=11, xfl=4),
+                dict(extra=b"\x01\x02abc" * 9, hcrc=True, text=True, os_=200, xfl=7, comment=b"c"),
+                dict(name=b"", comment=b"", extra=b"")]
+    for kw in variants:
+        g, hlen = member(**kw)
+        so, se = O.State(FMT["gzip"], bytearray(len(plain))), A.make_gzip_state(bytearray(len(plain)))
+        O.decompress(O.make_octet_vector_context(g), so)
+        A.decompress(A.make_octet_vector_context(g), se, engine=eng)
+        assert A.finished(se) and bytes(se.output_buffer) == plain
+        assert se.gzip_meta() == so.gzip_meta(), (kw, se.gzip_meta(), so.gzip_meta())
+        m = se.gzip_meta()
+        assert m["compression_method"] == "deflate" and (m["name"] is None) == ("name" not in kw)
+        # the header in 3-octet chunks, then the rest
+        so, se = O.State(FMT["gzip"], bytearray(len(plain))), A.make_gzip_state(bytearray(len(plain)))
+        pos = 0
+        while pos < len(g):
+            end = min(len(g), pos + 3) if pos < hlen + 6 else len(g)
+            ro = O.decompress(O.make_octet_vector_context(g, start=pos, end=end), so)
+            re_ = A.decompress(A.make_octet_vector_context(g, start=pos, end=end), se, engine=eng)
+            assert ro == re_ and (O.finished(so), O.input_underrun(so)) == (A.finished(se), A.input_underrun(se))
+            assert se.gzip_meta() == so.gzip_meta(), (kw, pos, se.gzip_meta(), so.gzip_meta())
+            pos = end
+        assert A.finished(se) and bytes(se.output_buffer) == plain
+
+
 def case_history_across_groups(eng):
     """Z_SYNC_FLUSH stream whose middle segment copies nothing from before itself (incompressible octets: it opens a
     LZ77 group of its own) while the segment after it copies from the FIRST one, i.e. from before its predecessor's
@@ -888,7 +935,7 @@ ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_reference_chunk
              case_noflush_streams, case_fixed_block_chains, case_history_across_groups,
              case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_device_buffers,
              case_checksum_kernels, case_deep_codes, case_chunked_resume, case_gzip_members,
-             case_pointer_contexts, case_container_headers, case_scratch_bounds, case_fuzz]
+             case_pointer_contexts, case_container_headers, case_gzip_metadata, case_scratch_bounds, case_fuzz]
 # what each engine flavour of the test modules runs.  "auto" runs everything; the others run the cases that can
 # tell them apart (the CPU suite has to stay within minutes: a case costs seconds on the lane emulator)
 FLAVOUR_CASES = {

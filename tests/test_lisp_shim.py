@@ -1,0 +1,184 @@
+"""lisp/3bz-amd.lisp cannot be loaded here (no Lisp implementation in the image), so it is LINTED: its
+defcstruct / defcfun / export forms are parsed and checked against include/tbz_amd.h, against the ctypes
+binding the parity tests run through (3bz_amd/_lib.py) and against the reference's export list
+(tests/golden/package_exports.json, taken from package.lisp:13-27 by tests/golden/make_vectors.py)."""
+import ctypes as C
+import importlib
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = open(os.path.join(ROOT, "lisp", "3bz-amd.lisp")).read()
+HDR = open(os.path.join(ROOT, "include", "tbz_amd.h")).read()
+T = importlib.import_module("3bz_amd")
+
+CFFI_SIZE = {":int32": 4, ":uint32": 4, ":uint64": 8, ":int": 4, ":size": 8, ":pointer": 8}
+CTYPE_OF = {":int32": C.c_int32, ":uint32": C.c_uint32, ":uint64": C.c_uint64}
+
+
+def _strip_comments(s):
+    return re.sub(r";[^\n]*", "", s)
+
+
+def _forms(src, head):
+    """top-level forms that start with `head`, as strings (paren matching; strings and #\\x handled)"""
+    out, i = [], 0
+    src = _strip_comments(src)
+    while True:
+        i = src.find("(" + head, i)
+        if i < 0:
+            return out
+        depth, j, instr = 0, i, False
+        while True:
+            c = src[j]
+            if instr:
+                if c == "\\":
+                    j += 1
+                elif c == '"':
+                    instr = False
+            elif c == '"':
+                instr = True
+            elif c == "(":
+                depth += 1
+            elif c == ")":
+                depth -= 1
+                if depth == 0:
+                    break
+            j += 1
+        out.append(src[i:j + 1])
+        i = j + 1
+
+
+def _struct_fields(name):
+    form = [f for f in _forms(SHIM, "cffi:defcstruct") if f.split()[1] == name][0]
+    return re.findall(r"\(([a-z0-9-]+)\s+(:[a-z0-9]+)\)", form)
+
+
+def _c_struct_fields(name):
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), HDR, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        typ, names = decl.split(None, 1)
+        for n in names.split(","):
+            fields.append((n.strip(), typ))
+    return fields
+
+
+def _check_struct(lisp_name, c_name, ctypes_cls):
+    lf = _struct_fields(lisp_name)
+    cf = _c_struct_fields(c_name)
+    assert [n.replace("-", "_") for n, _ in lf] == [n for n, _ in cf], (lf, cf)
+    for (ln, lt), (cn, ct) in zip(lf, cf):
+        assert {"int32_t": ":int32", "uint32_t": ":uint32", "uint64_t": ":uint64"}[ct] == lt, (ln, lt, ct)
+    # the same layout as the ctypes structure the tests use (natural alignment on both sides)
+    assert [n for n, _ in ctypes_cls._fields_] == [n for n, _ in cf]
+    assert [t for _, t in ctypes_cls._fields_] == [CTYPE_OF[t] for _, t in lf]
+    assert sum(CFFI_SIZE[t] for _, t in lf) == C.sizeof(ctypes_cls)
+
+
+def test_result_struct_matches_header_and_ctypes():
+    _check_struct("tbz-result", "tbz_result", T._lib.Result)
+    assert C.sizeof(T._lib.Result) == 64
+
+
+def test_gzip_header_struct_matches_header_and_ctypes():
+    _check_struct("tbz-gzip-header", "tbz_gzip_header", T._lib.GzipHeader)
+
+
+def _c_prototypes():
+    protos = {}
+    h = re.sub(r"/\*.*?\*/", "", HDR, flags=re.S)
+    for m in re.finditer(r"\b([a-z_0-9 ]+?\**)\s*\b(tbz_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", h):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if ret.startswith("typedef"):
+            continue
+        n = 0 if args in ("", "void") else len(args.split(","))
+        protos[name] = (ret, n, args)
+    return protos
+
+
+def test_defcfuns_match_header_prototypes():
+    protos = _c_prototypes()
+    seen = set()
+    for form in _forms(SHIM, "cffi:defcfun"):
+        m = re.match(r'\(cffi:defcfun\s+\("(tbz_[a-z0-9_]+)"\s+[^)]+\)\s+(:[a-z0-9]+)(.*)\)\s*$', form, re.S)
+        assert m, form
+        cname, ret, rest = m.group(1), m.group(2), m.group(3)
+        assert cname in protos, "%s is not declared in include/tbz_amd.h" % cname
+        cret, cn, cargs = protos[cname]
+        args = re.findall(r"\(([a-z0-9-]+)\s+(:[a-z0-9]+)\)", rest)
+        assert len(args) == cn, (cname, args, cargs)
+        want_ret = {"int": ":int", "void": ":void", "const char*": ":string"}[cret]
+        assert ret == want_ret, (cname, ret, cret)
+        # argument kinds: pointers where C has pointers / callbacks, integers where it has integers
+        for (an, at), carg in zip(args, [a.strip() for a in cargs.split(",")]):
+            is_ptr = "*" in carg or "tbz_alloc_fn" in carg
+            assert (at == ":pointer") == is_ptr, (cname, an, at, carg)
+            if not is_ptr:
+                assert at == (":size" if "size_t" in carg else ":int"), (cname, an, at, carg)
+        seen.add(cname)
+    # everything the shim's API needs is bound
+    for need in ("tbz_ctx_create", "tbz_ctx_destroy", "tbz_inflate", "tbz_inflate_alloc", "tbz_session_create",
+                 "tbz_session_feed", "tbz_session_decompress", "tbz_session_destroy", "tbz_gzip_header_parse",
+                 "tbz_strerror"):
+        assert need in seen, need
+
+
+def test_exports_cover_the_reference_package():
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "package_exports.json")))["exports"]
+    assert len(want) == 14
+    exp = _forms(SHIM, "defpackage")[0]
+    got = re.findall(r"#:([^\s()]+)", exp[exp.index("(:export"):])
+    missing = [s for s in want if s not in got]
+    assert not missing, missing
+    # and every exported name is defined in the file (defun / defmacro / defgeneric / defstruct constructor / defvar)
+    body = _strip_comments(SHIM)
+    for s in got:
+        pats = [r"\(defun %s[\s(]", r"\(defmacro %s[\s(]", r"\(defgeneric %s[\s(]", r"\(defvar %s[\s)]"]
+        ok = any(re.search(p % re.escape(s), body) for p in pats)
+        if not ok and s.startswith("make-") and s.endswith("-state"):
+            ok = re.search(r"\(defstruct \(%s[\s)]" % re.escape(s[5:]), body) is not None
+        assert ok, "exported but not defined: %s" % s
+
+
+def test_lambda_lists_follow_the_reference():
+    """the argument lists of the reference's functions (api.lisp:3,12,23-29; io-common.lisp:40-41,51-52;
+    io-mmap.lisp:26,47-49) — names and defaults are the interface"""
+    body = _strip_comments(SHIM)
+    for pat in (r"\(defun decompress \(context state\)",
+                r"\(defun replace-output-buffer \(state buffer\)",
+                r"\(defun decompress-vector \(compressed &key \(format :zlib\) \(start 0\) \(end \(length compressed\)\) output\)",
+                r"\(defun make-octet-vector-context \(vector &key \(start 0\) \(offset start\) \(end \(length vector\)\)\)",
+                r"\(defun make-octet-stream-context \(file-stream &key \(start 0\) \(offset 0\) \(end \(file-length file-stream\)\)\)",
+                r"\(defun make-octet-pointer-context \(octet-pointer &key \(start 0\) \(offset 0\) \(end \(size octet-pointer\)\)\)",
+                r"\(defmacro with-octet-pointer \(\(var pointer size",
+                r"\(defun finished \(state\)", r"\(defun input-underrun \(state\)", r"\(defun output-overflow \(state\)"):
+        assert re.search(pat, body), pat
+
+
+def test_parens_balance():
+    src = _strip_comments(SHIM)
+    depth, instr, i = 0, False, 0
+    while i < len(src):
+        c = src[i]
+        if instr:
+            if c == "\\":
+                i += 1
+            elif c == '"':
+                instr = False
+        elif c == '"':
+            instr = True
+        elif c == "#" and src[i + 1] == "\\":
+            i += 2
+        elif c == "(":
+            depth += 1
+        elif c == ")":
+            depth -= 1
+            assert depth >= 0
+        i += 1
+    assert depth == 0

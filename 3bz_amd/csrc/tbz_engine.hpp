@@ -458,7 +458,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     for (size_t s = 0; s < n; s++) {
       tfb[s] = (uint32_t)tiles_b;
       const uint64_t items_s = 1 + (first_marker[s + 1] - first_marker[s]);
-      const bool search = ctx->find_mode == 2 ? sp[s].in_len >= 64 : (!enough && sp[s].in_len * 8 / items_s >= FIND_MIN_ITEM_BITS);
+      const bool search = ctx->find_mode == 2 ? sp[s].in_len >= 64 : (!enough && sp[s].in_len >= (128u << 10) && sp[s].in_len * 8 / items_s >= FIND_MIN_ITEM_BITS);
       if (search) tiles_b += ((((uintptr_t)d_in + in_offs[s]) & 15) + in_lens[s] + K0B_TILE - 1) / K0B_TILE;
       if (tiles_b > 0x7fffffffu) return TBZ_E_ARG;
     }
@@ -599,6 +599,12 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     ctx->tim.huff_launches++;
     return 0;
   };
+  auto ovl_for = [&](int G) -> u32 {
+    if (const char* m = getenv("TBZ_OVL")) return (u32)std::max(64, atoi(m));
+    // measured (profiles/README.md): a gang of 64 commits 29 lanes per round at 512 bits of run-up, 59 at 1024 (K1 on
+    // the 64 MiB no-flush stream 2.78 -> 1.56 ms, on config 3 8.96 -> 6.05 ms); gangs of 32 are flat from 512 to 768
+    return G >= 64 ? 1024u : KG_OVL;
+  };
   auto launch_k1 = [&](const Item* d_items, SegResult* d_res, size_t n_it, bool fix) -> int {
     int G = k1_gang(n_it);
     if (!fix) ctx->tim.k1_gang = (uint32_t)G;
@@ -613,7 +619,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if (ctx->k1h) TBZ_LAUNCH(tbz_k1h_headers, (n_it + 63) / 64, ctx->stream, kh);
     K1gParams kg{(const u8*)d_in, pool_tok(fix), pool_runs(fix), d_items, d_res,
                  d_markers_cur, d_first_marker, ctx->k1h ? (const HdrRec*)ctx->d_hdr.p : nullptr,
-                 (const u8*)ctx->d_scratch.p, (u32)n_mark, (u32)n_it};
+                 (const u8*)ctx->d_scratch.p, (u32)n_mark, (u32)n_it, ovl_for(G)};
     switch (G) {
       case 8: TBZ_LAUNCH(tbz_k1g8_huff_decode, nwg, ctx->stream, kg); break;
       case 16: TBZ_LAUNCH(tbz_k1g16_huff_decode, nwg, ctx->stream, kg); break;
@@ -1263,11 +1269,18 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       k2.hist = 1;
       ctx->tim.k2_kinds |= 4u | 8u;
       ctx->tim.n_hgroups = order_h.size();
-      TBZ_LAUNCH(tbz_k2_lz77, order_h.size(), ctx->stream, k2);
-      k2.plane = 1;
-      k2.out_base = (u8*)ctx->d_mark.p + m0;
-      k2.out_bias = mark_lo;
-      TBZ_LAUNCH(tbz_k2_lz77, order_h.size(), ctx->stream, k2);
+      // few groups (K2's time is one group's latency): both planes in one launch, a wavefront each; many groups
+      // (throughput): one launch per plane at four workgroups per CU
+      static const bool pair_off = getenv("TBZ_K2_HPAIR") && !strcmp(getenv("TBZ_K2_HPAIR"), "0");
+      if (order_h.size() <= 1024 && !pair_off) {
+        TBZ_LAUNCH_WG(tbz_k2_lz77_hpair, order_h.size(), 128, ctx->stream, k2, (u8*)ctx->d_mark.p + m0, (u64)mark_lo);
+      } else {
+        TBZ_LAUNCH(tbz_k2_lz77, order_h.size(), ctx->stream, k2);
+        k2.plane = 1;
+        k2.out_base = (u8*)ctx->d_mark.p + m0;
+        k2.out_bias = mark_lo;
+        TBZ_LAUNCH(tbz_k2_lz77, order_h.size(), ctx->stream, k2);
+      }
       TBZ_HIP(hipEventRecord(ctx->ev[10], ctx->stream));
       const K6Range* dr = (const K6Range*)ctx->d_hg.p;
       const K6List* dl = (const K6List*)ctx->d_k6s.p;

@@ -1520,6 +1520,8 @@ struct K1gParams {
   const u8* hdr_lens;       //   … at hdr_lens[item * K1_SCRATCH ...]
   u32 n_markers;
   u32 n_items;
+  u32 ovl;                  // run-up bits before a lane's sub-range (KG_OVL; wider gangs need longer chains of lanes
+                            // in sync and take a longer run-up)
 };
 
 struct __attribute__((packed, aligned(2))) U16x8 {  // eight token words at 2-octet alignment
@@ -2462,7 +2464,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
       sub = (sub + 63) & ~63u;
       sub = sub < KG_SUB_MIN ? KG_SUB_MIN : sub;
       const u64 s_g = Pb + (u64)g * sub;
-      const u64 start = g == 0 ? Pb : s_g - KG_OVL;
+      const u64 start = g == 0 ? Pb : s_g - P.ovl;
       s_lo = s_g & ~7ull;
       stage = P.tok + s_lo;  // private region of the token pool: [s_g & ~7, (s_g + sub) & ~7), 16-octet aligned
       Inl il;
@@ -3064,6 +3066,32 @@ TBZ_KERNEL void tbz_k2_lz77(K2Params P) {
   k2_body<false>(
       P, gi, g, sg, win, tks, rcache,
       [&](u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) { k2_resolve<false>(win, pend, rpos, dofs, len, dist); },
+      [](u64, u32) {});
+}
+
+// H-groups: both planes in ONE launch, one wavefront per plane, each over a ring of its own (the planes do not
+// interact: the copies are the same, the octets differ).  Two workgroups per CU; for calls with fewer groups than the
+// chip has slots — where K2's time is one group's latency — this halves it.
+TBZ_KERNEL_WG(128, 1) void tbz_k2_lz77_hpair(K2Params P, u8* mark_base, u64 mark_bias) {
+  TBZ_SHARED __attribute__((aligned(16))) u8 win[2][K2_WIN];
+  TBZ_SHARED __attribute__((aligned(16))) u16 tks[2][K2_TOKBUF];
+  TBZ_SHARED u32 rcache[2][128];
+  u32 gi;
+  Group g;
+  Seg sg;
+  if (!k2_pick_group(P, gi, g, sg)) return;
+  const u32 w = tbz_wave();
+  K2Params Q = P;
+  Q.hist = 1;
+  Q.plane = w;
+  if (w) {
+    Q.out_base = mark_base;
+    Q.out_bias = mark_bias;
+  }
+  u8* mywin = win[w];
+  k2_body<false>(
+      Q, gi, g, sg, mywin, tks[w], rcache[w],
+      [&](u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) { k2_resolve<false>(mywin, pend, rpos, dofs, len, dist); },
       [](u64, u32) {});
 }
 

@@ -221,7 +221,9 @@ def case_noflush_streams(eng, n=200_000):
     res = eng.inflate(s, 1, out)
     t = eng.timings()
     assert res.status == 0 and bytes(out) == p and res.adler32 == zlib.adler32(p)
-    assert t.n_candidates >= 2 and t.n_groups >= 3 and t.n_hgroups >= 2, (t.n_candidates, t.n_groups, t.n_hgroups)
+    assert t.n_groups >= 3 and t.n_hgroups >= 2, (t.n_candidates, t.n_groups, t.n_hgroups)
+    if len(s) >= 128 << 10 or os.environ.get("TBZ_FIND") == "always":   # (K0b searches streams of at least 128 KiB)
+        assert t.n_candidates >= 2, t.n_candidates
     assert_same(eng, pygzip.compress(p, 6, mtime=0), "gzip", n, what="no-flush gzip")
     # capacities that end inside an H-group, inside its last 32 KiB, at a group seam ...
     for cap in (n - 1, n // 2, 100_000, 70_001, 33_000, 1):

@@ -62,7 +62,7 @@ struct tbz_ctx {
   tbz::DevBuf d_str_off, d_str_len, d_tile_first, d_tile_counts, d_tile_offsets, d_markers, d_items, d_res,
       d_tok, d_scratch, d_runs, d_segs, d_groups, d_order, d_k3_fi, d_k3_ni, d_k3_oo, d_k3_oc, d_k3_sums, d_k3_flags,
       d_k3_gscan, d_k3_gne, d_k3_streams, d_k3_glob, d_redo_items, d_redo_res, d_k0_slots, d_k0_fm, d_hdr, d_gck, d_gchunks, d_ck_l1, d_tok2, d_runs2, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
-      d_out_stage, d_kb_tf, d_kb_slots, d_kb_counts, d_kb_offsets, d_kb_cands, d_kb_fc, d_kb_head, d_markers2, d_kb_fm2, d_mark, d_hg, d_k6s, d_bigs, d_recs;
+      d_out_stage, d_kb_tf, d_kb_slots, d_kb_counts, d_kb_offsets, d_kb_cands, d_kb_fc, d_kb_head, d_markers2, d_kb_fm2, d_mark, d_hg, d_k6s, d_bigs, d_recs, d_kc_tf, d_kc_slots, d_kc_ends, d_kc_link, d_kc_fm2, d_markers3;
 };
 
 namespace tbz {
@@ -77,7 +77,8 @@ static std::vector<DevBuf*> all_pools(tbz_ctx* ctx) {
           &ctx->d_k3_glob, &ctx->d_redo_items, &ctx->d_redo_res, &ctx->d_k0_slots, &ctx->d_k0_fm, &ctx->d_hdr,
           &ctx->d_gck, &ctx->d_gchunks, &ctx->d_ck_l1, &ctx->d_tok2, &ctx->d_runs2, &ctx->d_kb_tf, &ctx->d_kb_slots,
           &ctx->d_kb_counts, &ctx->d_kb_offsets, &ctx->d_kb_cands, &ctx->d_kb_fc, &ctx->d_kb_head, &ctx->d_markers2,
-          &ctx->d_kb_fm2, &ctx->d_mark, &ctx->d_hg, &ctx->d_k6s, &ctx->d_bigs, &ctx->d_recs};
+          &ctx->d_kb_fm2, &ctx->d_mark, &ctx->d_hg, &ctx->d_k6s, &ctx->d_bigs, &ctx->d_recs, &ctx->d_kc_tf,
+          &ctx->d_kc_slots, &ctx->d_kc_ends, &ctx->d_kc_link, &ctx->d_kc_fm2, &ctx->d_markers3};
 }
 static uint64_t scratch_total(tbz_ctx* ctx) {
   uint64_t t = 0;
@@ -373,7 +374,6 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   // arrays are fetched only by the general (host) layout path.
   std::vector<Item> items;
   bool host_tables = false, have_find = false, have_resolve = false;
-  uint32_t last_h_stream = 0;
   uint32_t n_mark = 0;
   std::vector<uint32_t> first_marker(n + 1, 0);
   if (tiles) {
@@ -478,7 +478,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
                    (const u32*)ctx->d_kb_tf.p, (u32)n, (u32)tiles_b, (u64*)ctx->d_kb_slots.p, (u32*)ctx->d_kb_counts.p,
                    (u32*)ctx->d_kb_offsets.p, (u64*)ctx->d_kb_cands.p, (u32*)ctx->d_kb_fc.p, (u32*)ctx->d_kb_head.p,
                    (const u64*)ctx->d_markers.p, (const u32*)ctx->d_k0_fm.p + 2, (u64*)ctx->d_markers2.p,
-                   (u32*)ctx->d_kb_fm2.p + 2, (u32*)ctx->d_kb_fm2.p, bit_off};
+                   (u32*)ctx->d_kb_fm2.p + 2, (u32*)ctx->d_kb_fm2.p, bit_off, K0B_SLOTS, nullptr, nullptr};
       TBZ_LAUNCH(tbz_k0b_scan, tiles_b, ctx->stream, kb);
       TBZ_LAUNCH(tbz_k0b_validate, tiles_b, ctx->stream, kb);
       TBZ_LAUNCH(tbz_k0b_offsets, 1, ctx->stream, kb);
@@ -508,6 +508,87 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         TBZ_LAUNCH(tbz_k0_items, ((size_t)n_mark + n + 63) / 64, ctx->stream, k0m);
         d_markers_cur = (const u64*)ctx->d_markers2.p;
         d_first_marker = (const u32*)ctx->d_kb_fm2.p + 2;
+        for (size_t s = 0; s < n; s++) {
+          StreamPlan& S = sp[s];
+          S.first_marker = first_marker[s];
+          S.first_item = first_marker[s] + (uint32_t)s;
+          S.n_items = 1 + (first_marker[s + 1] - first_marker[s]);
+          S.cur_item = S.first_item;
+        }
+      }
+      TBZ_HIP(hipGetLastError());
+      TBZ_HIP(hipEventRecord(ctx->ev[9], ctx->stream));
+      have_find = true;
+    }
+  }
+  // ---------------------------------------------------------------- K0c: chains of fixed-Huffman blocks
+  // Streams whose items are STILL large (K0 and K0b found little in them: fixed-Huffman or stored territory) are
+  // searched for "end-of-block + BTYPE 1" patterns; each hit's one block is skimmed and the hits that chain are kept.
+  if (tiles && ctx->find_mode) {
+    constexpr uint64_t FIXED_MIN_ITEM_BITS = 8ull * (256u << 10);
+    std::vector<uint32_t> tfc(n + 1);
+    uint64_t tiles_c = 0;
+    const bool enough = (size_t)n_mark + n >= 2048;
+    for (size_t s = 0; s < n; s++) {
+      tfc[s] = (uint32_t)tiles_c;
+      const uint64_t items_s = 1 + (first_marker[s + 1] - first_marker[s]);
+      const bool search = ctx->find_mode == 2 ? sp[s].in_len >= 64
+                                              : (!enough && sp[s].in_len * 8 / items_s >= FIXED_MIN_ITEM_BITS);
+      if (search) tiles_c += ((((uintptr_t)d_in + in_offs[s]) & 15) + in_lens[s] + K0B_TILE - 1) / K0B_TILE;
+      if (tiles_c > 0x7fffffffu) return TBZ_E_ARG;
+    }
+    tfc[n] = (uint32_t)tiles_c;
+    if (tiles_c) {
+      if (!have_find) TBZ_HIP(hipEventRecord(ctx->ev[8], ctx->stream));
+      const size_t nslot = tiles_c * (size_t)K0C_SLOTS;
+      if ((r = upload(ctx, ctx->d_kc_tf, tfc))) return r;
+      if ((r = ensure(ctx, ctx->d_kc_slots, nslot * 8))) return r;
+      if ((r = ensure(ctx, ctx->d_kc_ends, nslot * 8))) return r;
+      if ((r = ensure(ctx, ctx->d_kc_link, nslot * 2))) return r;
+      if ((r = ensure(ctx, ctx->d_kb_counts, tiles_c * 4))) return r;
+      if ((r = ensure(ctx, ctx->d_kb_offsets, (tiles_c + 1) * 4))) return r;
+      if ((r = ensure(ctx, ctx->d_kb_cands, nslot * 8 + 16))) return r;
+      if ((r = ensure(ctx, ctx->d_kb_fc, (n + 1) * 4))) return r;
+      if ((r = ensure(ctx, ctx->d_kb_head, 16))) return r;
+      if ((r = ensure(ctx, ctx->d_kc_fm2, (n + 1) * 4 + 8))) return r;
+      if ((r = ensure(ctx, ctx->d_markers3, ((size_t)n_mark + nslot) * 8 + 16))) return r;
+      TBZ_HIP(hipMemsetAsync(ctx->d_kc_link.p, 0, nslot * 2, ctx->stream));
+      K0bParams kc{(const u8*)d_in, (const u64*)ctx->d_str_off.p, (const u64*)ctx->d_str_len.p,
+                   (const u32*)ctx->d_kc_tf.p, (u32)n, (u32)tiles_c, (u64*)ctx->d_kc_slots.p, (u32*)ctx->d_kb_counts.p,
+                   (u32*)ctx->d_kb_offsets.p, (u64*)ctx->d_kb_cands.p, (u32*)ctx->d_kb_fc.p, (u32*)ctx->d_kb_head.p,
+                   d_markers_cur, d_first_marker, (u64*)ctx->d_markers3.p,
+                   (u32*)ctx->d_kc_fm2.p + 2, (u32*)ctx->d_kc_fm2.p, bit_off, K0C_SLOTS, (u64*)ctx->d_kc_ends.p,
+                   (u8*)ctx->d_kc_link.p};
+      TBZ_LAUNCH(tbz_k0c_scan, tiles_c, ctx->stream, kc);
+      TBZ_LAUNCH(tbz_k0c_skim, tiles_c * (size_t)(K0C_SLOTS / 64), ctx->stream, kc);
+      TBZ_LAUNCH(tbz_k0c_filter, tiles_c, ctx->stream, kc);
+      TBZ_LAUNCH(tbz_k0b_offsets, 1, ctx->stream, kc);
+      TBZ_LAUNCH(tbz_k0b_compact, tiles_c, ctx->stream, kc);
+      const size_t max_merge = (size_t)n_mark + nslot;
+      TBZ_LAUNCH(tbz_k0b_merge, (max_merge + 63) / 64, ctx->stream, kc);
+      uint32_t* h_head = (uint32_t*)ctx->h_pin;
+      TBZ_HIP(hipMemcpyAsync(h_head, ctx->d_kc_fm2.p, (n + 3) * 4, hipMemcpyDeviceToHost, ctx->stream));
+      TBZ_HIP(hipStreamSynchronize(ctx->stream));
+      const uint32_t n_merged = h_head[0];
+      ctx->tim.n_candidates += n_merged - n_mark;
+      if (n_merged != n_mark) {
+        n_mark = n_merged;
+        for (size_t s = 0; s <= n; s++) first_marker[s] = h_head[2 + s];
+        if ((r = ensure(ctx, ctx->d_items, ((size_t)n_mark + n) * sizeof(Item)))) return r;
+        K0Params k0m{};
+        k0m.str_off = (const u64*)ctx->d_str_off.p;
+        k0m.str_len = (const u64*)ctx->d_str_len.p;
+        k0m.n_streams = (u32)n;
+        k0m.markers = (u64*)ctx->d_markers3.p;
+        k0m.first_marker = (u32*)ctx->d_kc_fm2.p + 2;
+        k0m.head = (u32*)ctx->d_kc_fm2.p;
+        k0m.items = (Item*)ctx->d_items.p;
+        k0m.format = (u32)format;
+        k0m.second_pass = 1;
+        k0m.start_bit_off = bit_off;
+        TBZ_LAUNCH(tbz_k0_items, ((size_t)n_mark + n + 63) / 64, ctx->stream, k0m);
+        d_markers_cur = (const u64*)ctx->d_markers3.p;
+        d_first_marker = (const u32*)ctx->d_kc_fm2.p + 2;
         for (size_t s = 0; s < n; s++) {
           StreamPlan& S = sp[s];
           S.first_marker = first_marker[s];
@@ -1490,12 +1571,12 @@ int tbz_last_timings(const tbz_ctx* ctx, tbz_timings* out) {
 }
 
 // the pipeline over a batch, in as many passes over consecutive streams as the pool cap asks for (scratch is
-// 18 octets per input octet of a pass's extent; one stream is never split: its segments share one token pool)
+// 20 octets per input octet of a pass's extent; one stream is never split: its segments share one token pool)
 static int inflate_passes(tbz_ctx* ctx, int format, size_t n, const void* d_in, const uint64_t* in_offs,
                           const uint64_t* in_lens, void* d_out, const uint64_t* out_offs, const uint64_t* out_caps,
                           tbz_result* results, bool size_only) {
   if (!ctx || (n && (!in_offs || !in_lens))) return TBZ_E_ARG;
-  auto need = [&](uint64_t lo, uint64_t hi) { return (hi - lo) * 18; };
+  auto need = [&](uint64_t lo, uint64_t hi) { return (hi - lo) * 20; };
   uint64_t lo = ~0ull, hi = 0;
   for (size_t s = 0; s < n; s++)
     if (in_lens[s]) {

@@ -65,6 +65,23 @@ TBZ_DEV u32 wave_xor_u32(u32 v) {
 // order in which a dynamic block header lists the code-length code's lengths (constants.lisp:63-68)
 TBZ_CONSTANT u8 c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
+// RFC 1951 length / distance bases from the symbol, in ALU (no table lookups in the hot loop).
+// Same values as constants.lisp:41-61.
+TBZ_DEV void len_base_extra(u32 c /* sym-257, 0..28 */, u32& base, u32& extra) {
+  u32 e = (c >> 2) - 1;
+  u32 b = 3 + ((4 + (c & 3)) << (e & 7));
+  bool small = c < 8, top = c == 28;
+  extra = (small || top) ? 0 : e;
+  base = small ? 3 + c : (top ? 258 : b);
+}
+TBZ_DEV void dist_base_extra(u32 d /* 0..29 */, u32& base, u32& extra) {
+  u32 e = (d >> 1) - 1;
+  u32 b = 1 + ((2 + (d & 1)) << (e & 15));
+  bool small = d < 4;
+  extra = small ? 0 : e;
+  base = small ? 1 + d : b;
+}
+
 // LDS accepts any octet address for 2/4/8/16-octet accesses on gfx950
 struct __attribute__((packed, aligned(1))) K2U128 { u64 lo, hi; };
 struct __attribute__((packed, aligned(1))) K2U64 { u64 v; };
@@ -331,6 +348,9 @@ struct K0bParams {
   u32* first_merged;       //   [n_streams+1]
   u32* head_merged;        //   [2]: total, 0  (laid out as K0Params::head for tbz_k0_items)
   u32 start_bit_off;       // stream 0 begins at this bit of its first octet: nothing before it is a candidate
+  u32 slots_per_tile;      // K0B_SLOTS for the dynamic-header finder, K0C_SLOTS for the fixed-chain finder
+  u64* ends;               // K0c: [n_tiles][slots_per_tile] where the block that starts at the slot's candidate ends (0: nowhere)
+  u8* link;                // K0c: [n_tiles][slots_per_tile][2]: [0] that end is a candidate too, [1] some block ends here
 };
 TBZ_DEV u32 k0b_find_stream(const K0bParams& P, u32 tile) {
   u32 lo = 0, hi = P.n_streams;  // tile_first[lo] <= tile < tile_first[hi]; streams without tiles are skipped over
@@ -356,7 +376,7 @@ TBZ_KERNEL void tbz_k0b_scan(K0bParams P) {
   // candidate bit positions p (relative to in_base) must satisfy p_min <= p <= p_max
   const u64 p_min = (u64)(s_lo - base) * 8 + 1 + (s == 0 ? P.start_bit_off : 0u);  // (the stream's first bit belongs to the head item)
   const u64 p_end = (u64)(s_hi - base) * 8;
-  u64* slots = P.slots + (u64)tile * K0B_SLOTS;
+  u64* slots = P.slots + (u64)tile * P.slots_per_tile;
   u32 nout = 0;
   for (u32 r = 0; r < K0B_TILE / 1024; r++) {
     const uintptr_t c = t0 + r * 1024 + lane * 16;
@@ -548,7 +568,7 @@ TBZ_KERNEL void tbz_k0b_validate(K0bParams P) {
   const u32 lane = tbz_lane(), tile = tbz_block();
   const u32 s = k0b_find_stream(P, tile);
   const u64 s_lo_bit = P.str_off[s] * 8, p_end = (P.str_off[s] + P.str_len[s]) * 8;
-  u64* slots = P.slots + (u64)tile * K0B_SLOTS;
+  u64* slots = P.slots + (u64)tile * P.slots_per_tile;
   const u32 count = P.counts[tile];
   u32 nout = 0;
   for (u32 j0 = 0; j0 < count; j0 += 64) {  // wave-uniform trip count
@@ -563,6 +583,217 @@ TBZ_KERNEL void tbz_k0b_validate(K0bParams P) {
     tbz_sync();  // every lane has read its slot before the compacted ones are written (out index <= j)
     if (ok) slots[nout + tbz_popc64(okm & ((1ull << lane) - 1))] = p;
     nout += tbz_popc64(okm);
+    tbz_sync();
+  }
+  if (lane == 0) P.counts[tile] = nout;
+}
+
+// ================================================================================================
+// K0c — chains of fixed-Huffman blocks.  A fixed-Huffman block (BTYPE=1, deflate.lisp:518-528 ->
+// ht-constants.lisp:9-32) has no header to recognise, but where one FOLLOWS another the end-of-block code of the
+// fixed code (seven zero bits) is followed by BFINAL and BTYPE = 01: ten bits with nine fixed.  tbz_k0c_scan finds
+// that pattern (one position in 512 of random data: weak on its own); tbz_k0c_skim then decodes, without writing a
+// token, the ONE block that would start at every such position and sees where it ends; a candidate is kept only if
+// another candidate's block ends exactly on it (tbz_k0c_filter).
+// What survives joins the markers like K0b's candidates — and is used only if the block chain lands on it.
+// The skim is the fixed code in arithmetic (RFC 1951 3.2.6): no tables.
+// Run for streams whose items are still large after K0 and K0b (nothing was found in them).
+// ================================================================================================
+constexpr u32 K0C_SLOTS = 512;            // pattern hits kept per 16 KiB tile (random data: ~256)
+constexpr u64 K0C_MAX_BLOCK = 8u << 20;   // bits: a candidate whose block would be longer is dropped
+
+TBZ_KERNEL void tbz_k0c_scan(K0bParams P) {
+  const u32 lane = tbz_lane();
+  const u32 tile = tbz_block();
+  const u32 s = k0b_find_stream(P, tile);
+  const uintptr_t base = (uintptr_t)P.in_base;
+  const uintptr_t s_lo = base + P.str_off[s], s_hi = s_lo + P.str_len[s];
+  const uintptr_t t0 = (s_lo & ~(uintptr_t)15) + (uintptr_t)(tile - P.tile_first[s]) * K0B_TILE;
+  const u64 p_min = (u64)(s_lo - base) * 8 + 8 + (s == 0 ? P.start_bit_off : 0u);
+  const u64 p_end = (u64)(s_hi - base) * 8;
+  u64* slots = P.slots + (u64)tile * P.slots_per_tile;
+  u32 nout = 0;
+  for (u32 r = 0; r < K0B_TILE / 1024; r++) {
+    const uintptr_t c = t0 + r * 1024 + lane * 16;
+    if (t0 + r * 1024 >= s_hi) break;  // wave-uniform
+    u32 w[5];
+    uint4 v{};
+    if (c < s_hi && c + 16 > s_lo) v = *(const uint4*)c;
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    w[4] = tbz_wave_shl1(v.x);
+    if (lane == 63) {
+      const uintptr_t cn = c + 16;
+      w[4] = (cn < s_hi && cn + 16 > s_lo) ? *(const u32*)cn : 0u;
+    }
+    const u64 bit0 = (u64)(c - base) * 8;
+    u32 cnt = 0;
+    u32 m32[4];
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {
+      const u64 x = ((u64)w[k + 1] << 32) | w[k];
+      // q .. q+6 zero (the end-of-block code), q+8 set and q+9 clear (BTYPE = 01); the header is at q+7
+      const u64 z = ~x & ~(x >> 1) & ~(x >> 2) & ~(x >> 3) & ~(x >> 4) & ~(x >> 5) & ~(x >> 6);
+      u32 m = (u32)(z & (x >> 8) & ~(x >> 9));
+      // keep the positions whose header lies inside the stream with room for a block behind it
+      u32 keep = 0;
+      for (u32 t = m; t; t &= t - 1) {
+        const u32 o = (u32)__builtin_ctz(t);
+        const u64 p = bit0 + 32 * k + o + 7;
+        if ((i64)(bit0 + 32 * k + o) >= 0 && p >= p_min && p + 20 <= p_end) keep |= 1u << o;
+      }
+      m32[k] = keep;
+      cnt += (u32)__builtin_popcount(keep);
+    }
+    if (tbz_ballot(cnt != 0) == 0) continue;  // wave-uniform
+    const u32 inc = wave_incl_scan_u32(cnt);
+    u32 at = nout + inc - cnt;
+#pragma unroll
+    for (u32 k = 0; k < 4; k++)
+      for (u32 t = m32[k]; t; t &= t - 1, at++)
+        if (at < P.slots_per_tile) slots[at] = bit0 + 32 * k + (u32)__builtin_ctz(t) + 7;
+    nout += tbz_shfl(inc, 63);
+  }
+  if (lane == 0) P.counts[tile] = nout < P.slots_per_tile ? nout : P.slots_per_tile;
+}
+
+// one fixed-Huffman block from bit position p on, nothing written: the bit position after its end-of-block code,
+// or 0 if it is not a block (a symbol that may not be used, deflate.lisp:438,:481 / huffman-tree.lisp:172-177, or
+// no end within the stream / K0C_MAX_BLOCK)
+TBZ_DEV u64 k0c_skim_one(const u8* in_base, u64 p, u64 p_end) {
+  K0bBits b;
+  const uintptr_t a0 = (uintptr_t)in_base;
+  const u32 mis = (u32)(a0 & 15);
+  b.w = (const u32*)(a0 - mis);
+  const u64 a = p + mis * 8;
+  b.nwords = (mis * 8 + p_end + 31) >> 5;
+  b.wi = a >> 5;
+  b.qi = ~0ull;
+  b.q = uint4{};
+  b.buf = 0;
+  b.n = 0;
+  k0b_need(b, 32);
+  b.buf >>= (a & 31);
+  b.n -= (u32)(a & 31);
+  u64 used = 3;
+  k0b_take(b, 3);  // BFINAL, BTYPE = 01 (the scan saw them)
+  const u64 limit = p_end - p < K0C_MAX_BLOCK ? p_end - p : K0C_MAX_BLOCK;
+  for (;;) {
+    if (used + 48 > limit) return 0;
+    k0b_need(b, 32);
+    // codes are packed MSB first: the next nine stream bits as a number whose top bit came first
+    const u32 c9 = tbz_brev32((u32)b.buf) >> 23;
+    const u32 c7 = c9 >> 2, c8 = c9 >> 1;
+    u32 sym, L;
+    if (c7 <= 23) { sym = 256 + c7; L = 7; }
+    else if (c8 <= 0xBF) { sym = c8 - 0x30; L = 8; }
+    else if (c8 <= 0xC7) { sym = 280 + (c8 - 0xC0); L = 8; }
+    else { sym = 144 + (c9 - 0x190); L = 9; }
+    u32 nb = L;
+    if (sym == 256) return p + used + 7;
+    if (sym > 256) {
+      if (sym > 285) return 0;
+      u32 base_, X;
+      len_base_extra(sym - 257, base_, X);
+      const u32 ds = tbz_brev32((u32)(b.buf >> (L + X))) >> 27;  // five bits, MSB first
+      if (ds > 29) return 0;
+      u32 dbase, DX;
+      dist_base_extra(ds, dbase, DX);
+      nb = L + X + 5 + DX;  // <= 9 + 5 + 5 + 13 = 32
+    }
+    b.buf >>= nb;
+    b.n -= nb;
+    used += nb;
+  }
+}
+
+// where does the block of every candidate end, and is that end a candidate too (K0C_SLOTS / 64 workgroups per tile)
+TBZ_KERNEL void tbz_k0c_skim(K0bParams P) {
+  const u32 lane = tbz_lane(), tile = tbz_block() / (K0C_SLOTS / 64), part = tbz_block() % (K0C_SLOTS / 64);
+  const u32 s = k0b_find_stream(P, tile);
+  const uintptr_t base = (uintptr_t)P.in_base;
+  const uintptr_t s_lo = base + P.str_off[s];
+  const uintptr_t a_lo = s_lo & ~(uintptr_t)15;  // address of the stream's first tile
+  const u64 p_end = (P.str_off[s] + P.str_len[s]) * 8;
+  const u64* slots = P.slots + (u64)tile * P.slots_per_tile;
+  const u32 count = P.counts[tile];
+  for (u32 j = part * 64 + lane; j < count; j += K0C_SLOTS) {
+    const u64 p = slots[j];
+    const u64 e = k0c_skim_one(P.in_base, p, p_end);
+    P.ends[(u64)tile * P.slots_per_tile + j] = e;
+    if (!e) continue;
+    // the candidate at bit e, if there is one: it lives in the tile that holds the OCTET e / 8 - 1 + ... = the pattern's
+    // position e - 7 (slots are filed by where the pattern starts)
+    const u64 q = e - 7;
+    const uintptr_t addr = base + (q >> 3);
+    if (addr < a_lo) continue;
+    const u32 t2 = P.tile_first[s] + (u32)((addr - a_lo) / K0B_TILE);
+    if (t2 >= P.tile_first[s + 1]) continue;
+    const u64* sl2 = P.slots + (u64)t2 * P.slots_per_tile;
+    u32 lo = 0, hi = P.counts[t2];
+    while (lo < hi) {
+      const u32 mid = (lo + hi) >> 1;
+      if (sl2[mid] < e) lo = mid + 1; else hi = mid;
+    }
+    if (lo < P.counts[t2] && sl2[lo] == e) {
+      P.link[((u64)tile * P.slots_per_tile + j) * 2] = 1;        // my block ends on a candidate
+      P.link[((u64)t2 * P.slots_per_tile + lo) * 2 + 1] = 1;     // a block ends on that candidate (racing writers write the same octet)
+    }
+  }
+}
+
+// keep the candidates that are part of a chain (in place, per tile) — and that stand at least K0C_SPACING bits after
+// the candidate before them and away from every marker: an item's run table is addressed by its start position
+// (one slot per 2^RUN_SHIFT bits), so items must not start closer than that to each other; blocks of a few tokens
+// are simply decoded through by the item before them
+constexpr u64 K0C_SPACING = 128;
+TBZ_KERNEL void tbz_k0c_filter(K0bParams P) {
+  const u32 lane = tbz_lane(), tile = tbz_block();
+  const u32 s = k0b_find_stream(P, tile);
+  u64* slots = P.slots + (u64)tile * P.slots_per_tile;
+  const u8* link = P.link + (u64)tile * P.slots_per_tile * 2;
+  const u32 count = P.counts[tile];
+  // the last pattern hit of the tile before (chained or not: conservative, and no other workgroup is waited for)
+  u64 prev = P.str_off[s] * 8 + (s == 0 ? P.start_bit_off : 0u) + 1;  // (the head item starts there; + 1: never 0 = "none")
+  if (tile > P.tile_first[s]) {
+    const u32 cp = P.counts[tile - 1];
+    if (cp) prev = P.slots[(u64)(tile - 1) * P.slots_per_tile + cp - 1];
+  }
+  const u32 m_lo = P.first_marker[s], m_hi = P.first_marker[s + 1];
+  u32 nout = 0;
+  for (u32 j0 = 0; j0 < count; j0 += 64) {  // wave-uniform trip count
+    const u32 j = j0 + lane;
+    u64 p = 0;
+    bool ok = false;
+    if (j < count) {
+      p = slots[j];
+      // kept: the candidates ON WHICH a block ends.  (That a candidate's own block ends on a candidate says little: a
+      // false start inside a block falls into step with the true token sequence and ends where the block ends.)
+      ok = link[2 * j + 1] != 0;
+      if (ok && m_lo < m_hi) {  // a marker within K0C_SPACING bits on either side?
+        u32 lo = m_lo, hi = m_hi;
+        while (lo < hi) {
+          const u32 mid = (lo + hi) >> 1;
+          if (P.markers[mid] + K0C_SPACING <= p) lo = mid + 1; else hi = mid;
+        }
+        if (lo < m_hi && P.markers[lo] < p + K0C_SPACING) ok = false;
+      }
+    }
+    // the chained candidate before this one: an inclusive "latest" scan over the chunk, shifted by one lane
+    u64 last = ok ? p : 0;
+#pragma unroll
+    for (u32 d = 1; d < 64; d <<= 1) {
+      const u64 t = tbz_shfl_up64(last, d);
+      if (lane >= d && t > last) last = t;
+    }
+    const u32 b_lo = tbz_wave_shr1((u32)last), b_hi = tbz_wave_shr1((u32)(last >> 32));
+    u64 before = ((u64)b_hi << 32) | b_lo;
+    if (before < prev) before = prev;
+    const bool keep = ok && (before == 0 || p - before >= K0C_SPACING);
+    prev = tbz_shfl64(last, 63) > prev ? tbz_shfl64(last, 63) : prev;
+    const u64 km = tbz_ballot(keep);
+    tbz_sync();
+    if (keep) slots[nout + tbz_popc64(km & ((1ull << lane) - 1))] = p;
+    nout += tbz_popc64(km);
     tbz_sync();
   }
   if (lane == 0) P.counts[tile] = nout;
@@ -588,7 +819,7 @@ TBZ_KERNEL void tbz_k0b_offsets(K0bParams P) {
 TBZ_KERNEL void tbz_k0b_compact(K0bParams P) {
   const u32 lane = tbz_lane(), t = tbz_block();
   const u32 n = P.counts[t], o = P.offsets[t];
-  for (u32 j = lane; j < n; j += 64) P.cands[o + j] = P.slots[(u64)t * K0B_SLOTS + j];
+  for (u32 j = lane; j < n; j += 64) P.cands[o + j] = P.slots[(u64)t * P.slots_per_tile + j];
   if (t == 0)
     for (u32 s = lane; s <= P.n_streams; s += 64) {
       const u32 fc = P.offsets[s < P.n_streams ? P.tile_first[s] : P.n_tiles];
@@ -779,23 +1010,6 @@ TBZ_DEV void br_skip(BitReader& b, u32 n) {  // n <= 32
     b.wi += 1;
     b.nx = br_word(b, b.wi + 2);
   }
-}
-
-// RFC 1951 length / distance bases from the symbol, in ALU (no table lookups in the hot loop).
-// Same values as constants.lisp:41-61.
-TBZ_DEV void len_base_extra(u32 c /* sym-257, 0..28 */, u32& base, u32& extra) {
-  u32 e = (c >> 2) - 1;
-  u32 b = 3 + ((4 + (c & 3)) << (e & 7));
-  bool small = c < 8, top = c == 28;
-  extra = (small || top) ? 0 : e;
-  base = small ? 3 + c : (top ? 258 : b);
-}
-TBZ_DEV void dist_base_extra(u32 d /* 0..29 */, u32& base, u32& extra) {
-  u32 e = (d >> 1) - 1;
-  u32 b = 1 + ((2 + (d & 1)) << (e & 15));
-  bool small = d < 4;
-  extra = small ? 0 : e;
-  base = small ? 1 + d : b;
 }
 
 // Canonical code of one alphabet, per lane.  lim[L-1] = (first code of length L + number of codes of

@@ -76,7 +76,7 @@ struct RunRec {
   uint32_t mdef;  // max over its matches of (distance - octets the RUN produced before the match), 0 if none reaches
                   // before the run's first octet
 };
-constexpr uint32_t RUN_SHIFT = 6;
+constexpr uint32_t RUN_SHIFT = 5;  // (items start at least 40 bits apart — a flush marker is five octets — so their tables never share a slot)
 
 struct Seg {
   uint64_t tok_index;  // the item's start_bit: base of its token region and (>> RUN_SHIFT) of its run table

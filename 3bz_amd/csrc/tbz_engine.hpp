@@ -561,6 +561,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
                    (u8*)ctx->d_kc_link.p};
       TBZ_LAUNCH(tbz_k0c_scan, tiles_c, ctx->stream, kc);
       TBZ_LAUNCH(tbz_k0c_skim, tiles_c * (size_t)(K0C_SLOTS / 64), ctx->stream, kc);
+      TBZ_LAUNCH(tbz_k0c_link, tiles_c, ctx->stream, kc);
       TBZ_LAUNCH(tbz_k0c_filter, tiles_c, ctx->stream, kc);
       TBZ_LAUNCH(tbz_k0b_offsets, 1, ctx->stream, kc);
       TBZ_LAUNCH(tbz_k0b_compact, tiles_c, ctx->stream, kc);

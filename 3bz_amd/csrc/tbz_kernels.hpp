@@ -350,7 +350,8 @@ struct K0bParams {
   u32 start_bit_off;       // stream 0 begins at this bit of its first octet: nothing before it is a candidate
   u32 slots_per_tile;      // K0B_SLOTS for the dynamic-header finder, K0C_SLOTS for the fixed-chain finder
   u64* ends;               // K0c: [n_tiles][slots_per_tile] where the block that starts at the slot's candidate ends (0: nowhere)
-  u8* link;                // K0c: [n_tiles][slots_per_tile][2]: [0] that end is a candidate too, [1] some block ends here
+  u8* link;                // K0c: [n_tiles][slots_per_tile][2]: [0] some candidate's block ends here, [1] ... and on THAT
+                           //   candidate a block ends too
 };
 TBZ_DEV u32 k0b_find_stream(const K0bParams& P, u32 tile) {
   u32 lo = 0, hi = P.n_streams;  // tile_first[lo] <= tile < tile_first[hi]; streams without tiles are skipped over
@@ -594,13 +595,15 @@ TBZ_KERNEL void tbz_k0b_validate(K0bParams P) {
 // fixed code (seven zero bits) is followed by BFINAL and BTYPE = 01: ten bits with nine fixed.  tbz_k0c_scan finds
 // that pattern (one position in 512 of random data: weak on its own); tbz_k0c_skim then decodes, without writing a
 // token, the ONE block that would start at every such position and sees where it ends; a candidate is kept only if
-// another candidate's block ends exactly on it (tbz_k0c_filter).
+// it is the second link of a chain: a block ends exactly on it whose own start a block ends on (tbz_k0c_link,
+// tbz_k0c_filter).
 // What survives joins the markers like K0b's candidates — and is used only if the block chain lands on it.
 // The skim is the fixed code in arithmetic (RFC 1951 3.2.6): no tables.
 // Run for streams whose items are still large after K0 and K0b (nothing was found in them).
 // ================================================================================================
 constexpr u32 K0C_SLOTS = 512;            // pattern hits kept per 16 KiB tile (random data: ~256)
-constexpr u64 K0C_MAX_BLOCK = 8u << 20;   // bits: a candidate whose block would be longer is dropped
+constexpr u64 K0C_MAX_BLOCK = 64u << 10;  // bits: a candidate whose block would be longer is not followed (the skim is one
+                                          // lane per block: its longest block is the kernel's duration)
 
 TBZ_KERNEL void tbz_k0c_scan(K0bParams P) {
   const u32 lane = tbz_lane();
@@ -719,7 +722,7 @@ TBZ_KERNEL void tbz_k0c_skim(K0bParams P) {
   for (u32 j = part * 64 + lane; j < count; j += K0C_SLOTS) {
     const u64 p = slots[j];
     const u64 e = k0c_skim_one(P.in_base, p, p_end);
-    P.ends[(u64)tile * P.slots_per_tile + j] = e;
+    P.ends[(u64)tile * P.slots_per_tile + j] = 0;
     if (!e) continue;
     // the candidate at bit e, if there is one: it lives in the tile that holds the OCTET e / 8 - 1 + ... = the pattern's
     // position e - 7 (slots are filed by where the pattern starts)
@@ -735,9 +738,21 @@ TBZ_KERNEL void tbz_k0c_skim(K0bParams P) {
       if (sl2[mid] < e) lo = mid + 1; else hi = mid;
     }
     if (lo < P.counts[t2] && sl2[lo] == e) {
-      P.link[((u64)tile * P.slots_per_tile + j) * 2] = 1;        // my block ends on a candidate
-      P.link[((u64)t2 * P.slots_per_tile + lo) * 2 + 1] = 1;     // a block ends on that candidate (racing writers write the same octet)
+      const u64 target = (u64)t2 * P.slots_per_tile + lo;
+      P.ends[(u64)tile * P.slots_per_tile + j] = ~target;        // (the slot my block ends on, for tbz_k0c_link)
+      P.link[target * 2] = 1;                                     // a block ends on that candidate (racing writers write the same octet)
     }
+  }
+}
+
+// second link: a candidate on which a block ends passes that on to the candidate its own block ends on
+TBZ_KERNEL void tbz_k0c_link(K0bParams P) {
+  const u32 tile = tbz_block();
+  const u32 count = P.counts[tile];
+  for (u32 j = tbz_lane(); j < count; j += 64) {
+    const u64 idx = (u64)tile * P.slots_per_tile + j;
+    const u64 t = P.ends[idx];
+    if (t != 0 && P.link[idx * 2]) P.link[(~t) * 2 + 1] = 1;
   }
 }
 
@@ -766,8 +781,10 @@ TBZ_KERNEL void tbz_k0c_filter(K0bParams P) {
     bool ok = false;
     if (j < count) {
       p = slots[j];
-      // kept: the candidates ON WHICH a block ends.  (That a candidate's own block ends on a candidate says little: a
-      // false start inside a block falls into step with the true token sequence and ends where the block ends.)
+      // kept: the candidates on which a block ends whose own start is one a block ends on — two links of a chain.
+      // (One link happens by chance: one pattern hit in a few hundred is the end of SOME skimmed block; and that a
+      // candidate's own block ends on a candidate says little: a false start inside a block falls into step with the
+      // true token sequence and ends where the block ends.)
       ok = link[2 * j + 1] != 0;
       if (ok && m_lo < m_hi) {  // a marker within K0C_SPACING bits on either side?
         u32 lo = m_lo, hi = m_hi;

@@ -831,7 +831,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         k2.win_bytes = 0;
         k2.cls = h_glob->n_big < n_it ? 2 : 0;
         ctx->tim.k2_kinds |= 4u;
-        TBZ_LAUNCH(tbz_k2_lz77, n_it, ctx->stream, k2);
+        if (ctx->k2_single) TBZ_LAUNCH(tbz_k2_lz77, n_it, ctx->stream, k2);
+        else TBZ_LAUNCH_WG(tbz_k2_lz77_ring2, n_it, 128, ctx->stream, k2);
       }
       TBZ_HIP(hipGetLastError());
     }
@@ -1070,7 +1071,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       std::vector<Item> its(pv.size());
       for (size_t k = 0; k < pv.size(); k++) {
         its[k] = per_stream[pv[k].s][pv[k].seg].item;
-        its[k].flags |= (uint32_t)std::min<uint64_t>(pv[k].before, 65535) << ITEM_HIST_SHIFT;  // < 32768: the item's reach-back exceeds it
+        its[k].flags |= ITEM_PROBE | ((uint32_t)std::min<uint64_t>(pv[k].before, 65535) << ITEM_HIST_SHIFT);  // < 32768: the item's reach-back exceeds it
       }
       if ((r = upload(ctx, ctx->d_redo_items, its))) return r;
       if ((r = ensure(ctx, ctx->d_redo_res, its.size() * sizeof(SegResult)))) return r;
@@ -1289,7 +1290,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       k2.n_groups = (u32)order_big.size();
       k2.win_bytes = 0;
       ctx->tim.k2_kinds |= 4u;
-      TBZ_LAUNCH(tbz_k2_lz77, order_big.size(), ctx->stream, k2);
+      if (ctx->k2_single) TBZ_LAUNCH(tbz_k2_lz77, order_big.size(), ctx->stream, k2);
+      else TBZ_LAUNCH_WG(tbz_k2_lz77_ring2, order_big.size(), 128, ctx->stream, k2);
     }
     if (!order_h.empty()) {
       // ---- K6 work lists (see tbz_kernels.hpp): blocks = runs of consecutive H-groups of one stream, at most `bmax` long
@@ -1351,17 +1353,15 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       k2.hist = 1;
       ctx->tim.k2_kinds |= 4u | 8u;
       ctx->tim.n_hgroups = order_h.size();
-      // few groups (K2's time is one group's latency): both planes in one launch, a wavefront each; many groups
-      // (throughput): one launch per plane at four workgroups per CU
-      static const bool pair_off = getenv("TBZ_K2_HPAIR") && !strcmp(getenv("TBZ_K2_HPAIR"), "0");
-      if (order_h.size() <= 1024 && !pair_off) {
-        TBZ_LAUNCH_WG(tbz_k2_lz77_hpair, order_h.size(), 128, ctx->stream, k2, (u8*)ctx->d_mark.p + m0, (u64)mark_lo);
-      } else {
-        TBZ_LAUNCH(tbz_k2_lz77, order_h.size(), ctx->stream, k2);
-        k2.plane = 1;
-        k2.out_base = (u8*)ctx->d_mark.p + m0;
-        k2.out_bias = mark_lo;
-        TBZ_LAUNCH(tbz_k2_lz77, order_h.size(), ctx->stream, k2);
+      // two launches of the ring kernel, one per plane (octets -> out, pointer high octets -> the mark plane)
+      for (u32 plane = 0; plane < 2; plane++) {
+        if (plane) {
+          k2.plane = 1;
+          k2.out_base = (u8*)ctx->d_mark.p + m0;
+          k2.out_bias = mark_lo;
+        }
+        if (ctx->k2_single) TBZ_LAUNCH(tbz_k2_lz77, order_h.size(), ctx->stream, k2);
+        else TBZ_LAUNCH_WG(tbz_k2_lz77_ring2, order_h.size(), 128, ctx->stream, k2);
       }
       TBZ_HIP(hipEventRecord(ctx->ev[10], ctx->stream));
       const K6Range* dr = (const K6Range*)ctx->d_hg.p;

@@ -1591,7 +1591,7 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
   r.trailer_have = tr_have;
   r.land_marker = land;
   r.reserved = st.viol_out;  // (the gang kernel keeps its diagnostics here)
-  if (status == SEG_UNDERRUN && st.hist0 == 0) {
+  if (status == SEG_UNDERRUN && !(it.flags & ITEM_PROBE)) {
     // where a resumed decode would start: the block in which the input ran out, and what came out before it
     r.trailer0 = (u32)blk_pos;
     r.trailer1 = (u32)(blk_pos >> 32);
@@ -3057,15 +3057,21 @@ TBZ_DEV bool k2_pick_group(const K2Params& P, u32& gi, Group& g, Seg& sg_guess) 
 // The front end of a group: token fetch, classification, offsets, literals; every batch's matches go to
 // `emit(pend, rpos, dofs, len, dist)` — the resolve step itself in the one-wave kernels, the hand-off to the
 // resolving wave in the two-wave kernel — and `finish()` runs before the final flush.
-template <bool LINEAR, class Emit, class Finish>
+// SPAN: most octets one batch may produce in the ring kernels.  DUAL (ring, two waves): `emit` hands the batch to the
+// resolving wave and returns while it is IN FLIGHT — so the ring is flushed only up to that batch's first octet, a
+// stored run (which this wave copies into the ring itself) waits for the resolving wave to drain, and the ring must
+// hold 32 KiB of history plus TWO spans.
+template <bool LINEAR, u32 SPAN, bool DUAL, class Emit, class Finish>
 TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_guess, u8* win, u16* tks, u32* rcache,
                      Emit&& emit, Finish&& finish) {
+  static_assert(LINEAR || K2_WIN >= 32768 + (DUAL ? 2 : 1) * SPAN + 64, "ring: history + the spans in flight");
   const u32 lane = tbz_lane();
   const u64 lane_bit = 1ull << lane;
   u8* outp = P.out_base + (g.out_abs - P.out_bias);
   const u32 a0 = (u32)((uintptr_t)outp & 15);
   const u64 clip = g.out_end > g.out_abs ? g.out_end - g.out_abs : 0;
   u64 pos = 0, flushed = 0;
+  u64 bstart = 0;  // DUAL: first octet of the batch in flight (everything before it is resolved)
   u32 rpos = a0;  // window index of `pos`
   const u32 litmask = (!LINEAR && P.plane) ? 0u : 0xffu;  // plane 1: every octet this group produces itself is "known" = 0
   if (!LINEAR && P.hist) {
@@ -3194,7 +3200,7 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
         const u32 cw = (ha && !vb) ? 0u : !vb ? 1u : (hb && !hbv) ? 1u : hbv ? 3u : 2u;
         u32 nl = (n2 + 1) >> 1;  // lanes holding words
         if (!LINEAR) {           // the ring must not be overrun inside one batch
-          const u64 over = tbz_ballot(incl > K2_SPAN);
+          const u64 over = tbz_ballot(incl > SPAN);
           const u32 lok = over ? (u32)tbz_ffs64(over) - 1 : 64u;
           nl = nl < lok ? nl : lok;
         }
@@ -3210,6 +3216,7 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
         const bool hasm = (hav || hbv) && act;
         const u32 len = hav ? len_a : len_b;
         const u32 dist = ((hav ? b : na) & 0x7fffu) + 1;
+        bstart = pos;
         emit(tbz_ballot(hasm), rpos, hav ? oa : ob, hasm ? len : 0u, dist);
         pos += total;
         rpos = ring<LINEAR>(rpos + total);
@@ -3228,8 +3235,12 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
           u32 w1 = tbz_readlane(w, 1), w2 = tbz_readlane(w, 2), w3 = tbz_readlane(w, 3), w0 = tbz_readlane(w, 0);
           u64 cnt = (w0 & 0x3fff) | ((u64)(w1 & 3) << 14);
           u64 src = ((u64)(w1 >> 2) & 0x1fff) | ((u64)w2 << 13) | ((u64)w3 << 28);
+          if (DUAL) {  // an empty batch: when its hand-over returns, the batch before it is resolved
+            emit(0ull, rpos, 0u, 0u, 1u);
+            bstart = pos;
+          }
           while (cnt) {
-            u32 c = cnt < K2_SPAN ? (u32)cnt : K2_SPAN;  // (the ring holds 32 KiB of history + one span)
+            u32 c = cnt < SPAN ? (u32)cnt : SPAN;  // (the ring holds 32 KiB of history + one span)
             tbz_sync();
             for (u32 j = lane; j < c; j += 64) win[ring<LINEAR>(rpos + j)] = (u8)(P.in_base[src + j] & litmask);
             tbz_sync();
@@ -3237,6 +3248,7 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
             rpos = ring<LINEAR>(rpos + c);
             src += c;
             cnt -= c;
+            bstart = pos;
             if (!LINEAR && (pos - flushed >= K2_FLUSH || pos >= clip)) {
               u64 upto = pos >= clip ? pos : ((pos + a0) & ~15ull) - a0;
               if (upto > flushed) {
@@ -3260,7 +3272,7 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
         bool head = (mb & lane_bit) != 0, islit = (lits & lane_bit) != 0;
         u32 len = head ? (w & 0xff) + 3 : (islit ? 1u : 0u);
         u32 incl = tbz_wave_incl_scan_u32(len);
-        u64 ok = LINEAR ? cut_ok : (tbz_ballot(incl <= K2_SPAN) & cut_ok);
+        u64 ok = LINEAR ? cut_ok : (tbz_ballot(incl <= SPAN) & cut_ok);
         if (ok == 0) break;  // malformed token stream (never produced by K1)
         u32 m = 64 - (u32)__builtin_clzll(ok);
         u32 total = tbz_readlane(incl, m - 1);
@@ -3268,13 +3280,15 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
         u32 dofs = incl - len;  // octet offset of this token inside the batch
         u32 dist = (tbz_wave_shl1(w) & 0x7fffu) + 1;
         if (islit && (act & lane_bit)) win[ring<LINEAR>(rpos + dofs)] = (u8)(w & litmask);
+        bstart = pos;
         emit(mb & act, rpos, dofs, len, dist);
         pos += total;
         rpos = ring<LINEAR>(rpos + total);
         p += m;
       }
       if (!LINEAR && pos - flushed >= K2_FLUSH) {
-        u64 upto = ((pos + a0) & ~15ull) - a0;  // keep the unaligned tail in the ring
+        const u64 lim = DUAL ? bstart : pos;
+        u64 upto = ((lim + a0) & ~15ull) - a0;  // keep the unaligned tail in the ring
         if (upto > flushed) {
           k2_flush<LINEAR>(win, outp, flushed, upto, clip, a0);
           flushed = upto;
@@ -3294,35 +3308,9 @@ TBZ_KERNEL void tbz_k2_lz77(K2Params P) {
   Group g;
   Seg sg;
   if (!k2_pick_group(P, gi, g, sg)) return;
-  k2_body<false>(
+  k2_body<false, K2_SPAN, false>(
       P, gi, g, sg, win, tks, rcache,
       [&](u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) { k2_resolve<false>(win, pend, rpos, dofs, len, dist); },
-      [](u64, u32) {});
-}
-
-// H-groups: both planes in ONE launch, one wavefront per plane, each over a ring of its own (the planes do not
-// interact: the copies are the same, the octets differ).  Two workgroups per CU; for calls with fewer groups than the
-// chip has slots — where K2's time is one group's latency — this halves it.
-TBZ_KERNEL_WG(128, 1) void tbz_k2_lz77_hpair(K2Params P, u8* mark_base, u64 mark_bias) {
-  TBZ_SHARED __attribute__((aligned(16))) u8 win[2][K2_WIN];
-  TBZ_SHARED __attribute__((aligned(16))) u16 tks[2][K2_TOKBUF];
-  TBZ_SHARED u32 rcache[2][128];
-  u32 gi;
-  Group g;
-  Seg sg;
-  if (!k2_pick_group(P, gi, g, sg)) return;
-  const u32 w = tbz_wave();
-  K2Params Q = P;
-  Q.hist = 1;
-  Q.plane = w;
-  if (w) {
-    Q.out_base = mark_base;
-    Q.out_bias = mark_bias;
-  }
-  u8* mywin = win[w];
-  k2_body<false>(
-      Q, gi, g, sg, mywin, tks[w], rcache[w],
-      [&](u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) { k2_resolve<false>(mywin, pend, rpos, dofs, len, dist); },
       [](u64, u32) {});
 }
 
@@ -3334,7 +3322,7 @@ TBZ_KERNEL void tbz_k2_lz77_small(K2Params P) {
   Seg sg;
   if (!k2_pick_group(P, gi, g, sg)) return;
   u8* win = dyn;
-  k2_body<true>(
+  k2_body<true, K2_SPAN, false>(
       P, gi, g, sg, win, (u16*)(dyn + P.win_bytes), (u32*)(dyn + P.win_bytes + 2 * K2_TOKBUF),
       [&](u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) { k2_resolve<true>(win, pend, rpos, dofs, len, dist); },
       [](u64, u32) {});
@@ -3363,7 +3351,7 @@ TBZ_KERNEL_WG(128, 2) void tbz_k2_lz77_dual(K2Params P) {
   K2Hand* H = (K2Hand*)(dyn + P.win_bytes + 2 * K2_TOKBUF + 512);
   if (tbz_wave() == 0) {
     u32 k = 0;
-    k2_body<true>(
+    k2_body<true, K2_SPAN, false>(
         P, gi, g, sg, win, (u16*)(dyn + P.win_bytes), (u32*)(dyn + P.win_bytes + 2 * K2_TOKBUF),
         [&](u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) {
           K2Hand& h = H[k & 1];
@@ -3438,6 +3426,53 @@ TBZ_KERNEL_WG(128, 2) void tbz_k2_lz77_dual(K2Params P) {
         }
         break;
       }
+    }
+  }
+}
+
+// The ring kernel on TWO wavefronts (front end || resolve, as tbz_k2_lz77_dual does for the linear window): groups
+// larger than a linear window, and H-groups.  The same 36 KB ring serves: a batch produces at most K2_SPAN / 2 octets
+// here, so that the batch in flight and the one the front end is writing both fit beside 32 KiB of history
+// (k2_body, DUAL).  Four workgroups per CU, eight waves.
+constexpr u32 K2_SPAN_DUAL = K2_SPAN / 2;
+TBZ_KERNEL_WG(128, 1) void tbz_k2_lz77_ring2(K2Params P) {
+  TBZ_SHARED __attribute__((aligned(16))) u8 win[K2_WIN];
+  TBZ_SHARED __attribute__((aligned(16))) u16 tks[K2_TOKBUF];
+  TBZ_SHARED u32 rcache[128];
+  TBZ_SHARED K2Hand H[2];
+  u32 gi;
+  Group g;
+  Seg sg;
+  if (!k2_pick_group(P, gi, g, sg)) return;  // both waves take the same decision
+  const u32 lane = tbz_lane();
+  if (tbz_wave() == 0) {
+    u32 k = 0;
+    k2_body<false, K2_SPAN_DUAL, true>(
+        P, gi, g, sg, win, tks, rcache,
+        [&](u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) {
+          K2Hand& h = H[k & 1];
+          h.desc[lane] = (u64)dofs | ((u64)len << 16) | ((u64)dist << 32);
+          if (lane == 0) {
+            h.pend = pend;
+            h.rpos = rpos;
+            h.end = 0;
+          }
+          tbz_wg_barrier();
+          k += 1;
+        },
+        [&](u64, u32) {
+          if (lane == 0) H[k & 1].end = 1;
+          tbz_wg_barrier();  // the last batch is resolved when this returns: the final flush may read the window
+        });
+  } else {
+    for (u32 k = 0;; k++) {
+      if (k > 0) {
+        const K2Hand& h = H[(k - 1) & 1];
+        const u64 d = h.desc[lane];
+        k2_resolve<false>(win, h.pend, h.rpos, (u32)(d & 0xffffu), (u32)((d >> 16) & 0xffffu), (u32)(d >> 32));
+      }
+      tbz_wg_barrier();
+      if (H[k & 1].end) break;
     }
   }
 }

@@ -22,6 +22,7 @@ namespace tbz {
 enum : uint32_t {
   ITEM_HEAD = 1u,    // starts at the stream's first byte: parse the zlib/gzip container header first
   ITEM_FIXUP = 2u,   // chain repair: ignore `limit_bit`, land on ANY marker (binary search)
+  ITEM_PROBE = 4u,   // re-decode by the one-lane kernel to locate a distance error: SegResult.reserved = its place
   ITEM_FMT_SHIFT = 8, // format in bits 8..9
   ITEM_HIST_SHIFT = 16 // bits 16..31: octets of the stream before the item (saturated at 65535), for the exact
                        // location of a distance-before-start error (one-lane re-decode of the offending item)

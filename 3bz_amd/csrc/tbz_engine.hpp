@@ -481,6 +481,14 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
                    (u32*)ctx->d_kb_fm2.p + 2, (u32*)ctx->d_kb_fm2.p, bit_off, K0B_SLOTS, nullptr, nullptr};
       TBZ_LAUNCH(tbz_k0b_scan, tiles_b, ctx->stream, kb);
       TBZ_LAUNCH(tbz_k0b_validate, tiles_b, ctx->stream, kb);
+#ifdef TBZ_WAVE_TRACE
+      if (const char* vp = getenv("TBZ_VAL_TRACE")) {
+        std::vector<u64> h(8192 * 8);
+        hipStreamSynchronize(ctx->stream);
+        hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(tbz_dbg), h.size() * 8);
+        if (FILE* f = fopen(vp, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+      }
+#endif
       TBZ_LAUNCH(tbz_k0b_offsets, 1, ctx->stream, kb);
       TBZ_LAUNCH(tbz_k0b_compact, tiles_b, ctx->stream, kb);
       const size_t max_merge = (size_t)n_mark + tiles_b * (size_t)K0B_SLOTS;
@@ -490,6 +498,14 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       TBZ_HIP(hipStreamSynchronize(ctx->stream));
       const uint32_t n_merged = h_head[0];
       ctx->tim.n_candidates = n_merged - n_mark;
+      if (const char* dp = getenv("TBZ_DEBUG_CANDS")) {  // the merged list of bit positions, for tools/ that compare it with the true block starts
+        std::vector<uint64_t> hm(n_merged);
+        TBZ_HIP(hipMemcpy(hm.data(), ctx->d_markers2.p, hm.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(dp, "wb")) {
+          fwrite(hm.data(), 8, hm.size(), f);
+          fclose(f);
+        }
+      }
       if (n_merged != n_mark) {
         n_mark = n_merged;
         for (size_t s = 0; s <= n; s++) first_marker[s] = h_head[2 + s];
@@ -534,7 +550,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       const uint64_t items_s = 1 + (first_marker[s + 1] - first_marker[s]);
       const bool search = ctx->find_mode == 2 ? sp[s].in_len >= 64
                                               : (!enough && sp[s].in_len * 8 / items_s >= FIXED_MIN_ITEM_BITS);
-      if (search) tiles_c += ((((uintptr_t)d_in + in_offs[s]) & 15) + in_lens[s] + K0B_TILE - 1) / K0B_TILE;
+      if (search) tiles_c += ((((uintptr_t)d_in + in_offs[s]) & 15) + in_lens[s] + K0C_TILE - 1) / K0C_TILE;
       if (tiles_c > 0x7fffffffu) return TBZ_E_ARG;
     }
     tfc[n] = (uint32_t)tiles_c;
@@ -681,6 +697,10 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     ctx->tim.huff_launches++;
     return 0;
   };
+  auto sub_min_for = [&](int) -> u32 {
+    if (const char* m = getenv("TBZ_SUB_MIN")) return (u32)std::max(64, atoi(m) & ~63);
+    return KG_SUB_MIN;
+  };
   auto ovl_for = [&](int G) -> u32 {
     if (const char* m = getenv("TBZ_OVL")) return (u32)std::max(64, atoi(m));
     // measured (profiles/README.md): a gang of 64 commits 29 lanes per round at 512 bits of run-up, 59 at 1024 (K1 on
@@ -701,7 +721,33 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if (ctx->k1h) TBZ_LAUNCH(tbz_k1h_headers, (n_it + 63) / 64, ctx->stream, kh);
     K1gParams kg{(const u8*)d_in, pool_tok(fix), pool_runs(fix), d_items, d_res,
                  d_markers_cur, d_first_marker, ctx->k1h ? (const HdrRec*)ctx->d_hdr.p : nullptr,
-                 (const u8*)ctx->d_scratch.p, (u32)n_mark, (u32)n_it, ovl_for(G)};
+                 (const u8*)ctx->d_scratch.p, (u32)n_mark, (u32)n_it, ovl_for(G), sub_min_for(G)};
+#ifdef TBZ_WAVE_TRACE
+    {
+      static int n_launch = 0;
+      u32 ef = (n_launch++ >= 1 && getenv("TBZ_EXP")) ? (u32)atoi(getenv("TBZ_EXP")) : 0u;
+      hipMemcpyToSymbolAsync(HIP_SYMBOL(tbz_exp_flags), &ef, 4, 0, hipMemcpyHostToDevice, ctx->stream);
+      hipStreamSynchronize(ctx->stream);
+    }
+    static u64* d_trace = nullptr;
+    static size_t trace_wg = 0;
+    if (const char* tp = getenv("TBZ_WAVE_TRACE")) {
+      if (d_trace && trace_wg) {  // the previous launch's records
+        std::vector<u64> h(trace_wg * 16);
+        hipStreamSynchronize(ctx->stream);
+        hipMemcpy(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(tp, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+        hipFree(d_trace);
+      }
+      hipMalloc((void**)&d_trace, nwg * 128);
+      hipMemsetAsync(d_trace, 0, nwg * 128, ctx->stream);
+      trace_wg = nwg;
+      kg.trace = d_trace;
+
+    } else {
+      kg.trace = nullptr;
+    }
+#endif
     switch (G) {
       case 8: TBZ_LAUNCH(tbz_k1g8_huff_decode, nwg, ctx->stream, kg); break;
       case 16: TBZ_LAUNCH(tbz_k1g16_huff_decode, nwg, ctx->stream, kg); break;
@@ -1274,7 +1320,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if ((r = upload(ctx, ctx->d_order, order))) return r;
     K2Params k2{pool_tok(false), pool_runs(false), pool_tok(true), pool_runs(true),
                 (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, (const u32*)ctx->d_order.p, (const u8*)d_in, (u8*)d_out, 0, 0, 0, nullptr, nullptr,
-                0, 0, 0};
+                0, 0, 0, 0, 0, nullptr, 0};
     if (!order_small.empty()) {
       k2.n_groups = (u32)order_small.size();
       k2.win_bytes = (u32)((max_small + K2_SLACK + 63) & ~63ull);
@@ -1285,7 +1331,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         TBZ_LAUNCH_DYN_WG(tbz_k2_lz77_dual, order_small.size(), 128,
                           k2.win_bytes + 2 * K2_TOKBUF + 512 + 2 * sizeof(K2Hand), ctx->stream, k2);
     }
-    if (!order_big.empty()) {
+    if (!order_big.empty() && order_h.empty()) {
       k2.order = (const u32*)ctx->d_order.p + order_small.size();
       k2.n_groups = (u32)order_big.size();
       k2.win_bytes = 0;
@@ -1347,21 +1393,23 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       if ((r = ensure(ctx, ctx->d_mark, (mark_hi - mark_lo) + 64))) return r;
       if ((r = upload(ctx, ctx->d_hg, ranges))) return r;
       if ((r = upload(ctx, ctx->d_k6s, lists))) return r;
-      k2.order = (const u32*)ctx->d_order.p + order_small.size() + order_big.size();
-      k2.n_groups = (u32)order_h.size();
+      // ONE launch of the ring kernel: the plain large groups, and both planes of every H-group (octets -> out, pointer
+      // high octets -> the mark plane) as neighbouring workgroups, which read the same tokens (measured on the 64 MiB
+      // no-flush stream: three launches of 1 + 1304 + 1304 workgroups took 0.29 + 0.37 + 0.37 ms, four workgroups
+      // fit a CU)
+      k2.order = (const u32*)ctx->d_order.p + order_small.size();
+      k2.n_groups = (u32)(order_big.size() + order_h.size());
       k2.win_bytes = 0;
-      k2.hist = 1;
+      k2.mixed = 1;
+      k2.n_plain = (u32)order_big.size();
+      k2.mark_base = (u8*)ctx->d_mark.p + m0;
+      k2.mark_bias = mark_lo;
       ctx->tim.k2_kinds |= 4u | 8u;
       ctx->tim.n_hgroups = order_h.size();
-      // two launches of the ring kernel, one per plane (octets -> out, pointer high octets -> the mark plane)
-      for (u32 plane = 0; plane < 2; plane++) {
-        if (plane) {
-          k2.plane = 1;
-          k2.out_base = (u8*)ctx->d_mark.p + m0;
-          k2.out_bias = mark_lo;
-        }
-        if (ctx->k2_single) TBZ_LAUNCH(tbz_k2_lz77, order_h.size(), ctx->stream, k2);
-        else TBZ_LAUNCH_WG(tbz_k2_lz77_ring2, order_h.size(), 128, ctx->stream, k2);
+      {
+        const size_t nwg = order_big.size() + 2 * order_h.size();
+        if (ctx->k2_single) TBZ_LAUNCH(tbz_k2_lz77, nwg, ctx->stream, k2);
+        else TBZ_LAUNCH_WG(tbz_k2_lz77_ring2, nwg, 128, ctx->stream, k2);
       }
       TBZ_HIP(hipEventRecord(ctx->ev[10], ctx->stream));
       const K6Range* dr = (const K6Range*)ctx->d_hg.p;

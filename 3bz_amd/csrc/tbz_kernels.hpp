@@ -315,7 +315,7 @@ TBZ_KERNEL void tbz_k0_scan_emit(K0Params P) {
 // and unmarked: 3bz finds the next block only by finishing the previous one (:block-end -> :start-of-block,
 // deflate.lisp:719-722).  But the header of a dynamic-Huffman block (deflate.lisp:577-669) is heavily
 // redundant, so plausible headers can be FOUND: every bit position is tested for
-//     BFINAL=0, BTYPE=2 | HLIT <= 29, HDIST <= 29 | the code-length code is complete (Kraft sum exactly 1)
+//     BFINAL=0 (1 near the stream's end), BTYPE=2 | HLIT <= 29, HDIST <= 29 | the code-length code is complete (Kraft sum exactly 1)
 // by tbz_k0b_scan (bit-parallel masks over 32 positions at a time, then one LDS lookup per four code
 // lengths: ~1 position in 2300 survives on compressed data), and the survivors are parsed in full by
 // tbz_k0b_validate, one lane each: the HLIT+HDIST code lengths must decode without a repeat error, the
@@ -326,9 +326,17 @@ TBZ_KERNEL void tbz_k0_scan_emit(K0Params P) {
 // Fixed-Huffman and stored blocks carry no such redundancy and are not looked for: the item before them
 // decodes through them.
 // ================================================================================================
-constexpr u32 K0B_TILE = 16u << 10;  // octets of memory per finder workgroup (16 rows of 1 KiB)
-constexpr u32 K0B_SLOTS = 128;       // survivors kept per tile (expected ~56 on compressed data; more are dropped)
+#ifdef TBZ_WAVE_TRACE
+__device__ u32 tbz_exp_flags;  // experiment builds (tools/exp): switches parts of kernels off to see what they cost
+__device__ u64 tbz_dbg[8192 * 8];
+__device__ u32 tbz_dbg_cnt[4];
+#endif
+constexpr u32 K0B_TILE = 8u << 10;   // octets of memory per finder workgroup (8 rows of 1 KiB)
+constexpr u32 K0B_SLOTS = 128;       // survivors kept per tile (expected ~28 on compressed data, twice that near a stream's end,
+                                     // where BFINAL = 1 passes too; more are dropped): ONE pass of tbz_k0b_validate nearly always
 constexpr u32 K0B_TAIL_BITS = 80;    // a candidate must have this much stream left (3+14+up to 57 header bits)
+constexpr u32 K0B_PRE_WORDS = 32;    // words of a candidate's header staged in LDS up front (128 octets)
+constexpr u32 K0B_FINAL_WINDOW = 128u << 10;  // octets before a stream's end in which a header with BFINAL = 1 is a candidate
 struct K0bParams {
   const u8* in_base;
   const u64* str_off;
@@ -379,6 +387,9 @@ TBZ_KERNEL void tbz_k0b_scan(K0bParams P) {
   const u64 p_end = (u64)(s_hi - base) * 8;
   u64* slots = P.slots + (u64)tile * P.slots_per_tile;
   u32 nout = 0;
+  // BFINAL = 1 is accepted near the stream's end only (the final block starts within one block's length of it; everywhere
+  // else the extra bit halves the survivors)
+  const u64 final_ok = t0 + K0B_FINAL_WINDOW >= s_hi ? ~0ull : 0ull;
   for (u32 r = 0; r < K0B_TILE / 1024; r++) {
     const uintptr_t c = t0 + r * 1024 + lane * 16;
     if (t0 + r * 1024 >= s_hi) break;  // wave-uniform: the rest of the tile lies past the stream
@@ -400,7 +411,7 @@ TBZ_KERNEL void tbz_k0b_scan(K0bParams P) {
 #pragma unroll
     for (u32 k = 0; k < 4; k++) {
       const u64 x = ((u64)w[k + 1] << 32) | w[k];
-      const u64 m = ~x & ~(x >> 1) & (x >> 2);                               // BFINAL 0, BTYPE 2 (bits 0,0,1)
+      const u64 m = (~x | final_ok) & ~(x >> 1) & (x >> 2);                  // BFINAL 0, BTYPE 2 (bits 0,0,1)
       const u64 hl = (x >> 4) & (x >> 5) & (x >> 6) & (x >> 7);              // HLIT >= 30
       const u64 hd = (x >> 9) & (x >> 10) & (x >> 11) & (x >> 12);           // HDIST >= 30
       u32 m32 = (u32)(m & ~hl & ~hd);
@@ -408,8 +419,9 @@ TBZ_KERNEL void tbz_k0b_scan(K0bParams P) {
         const u32 o = (u32)__builtin_ctz(m32);
         m32 &= m32 - 1;
         const u64 p = bit0 + 32 * k + o;
-        // HCLEN and the code-length code's lengths: 61 bits from o+13 on
-        const u64 f = (x >> (o + 13)) | ((u64)w[k + 2] << (51 - o));
+        // HCLEN and the code-length code's lengths: 61 bits from o+13 on (x holds 51 - o of them, the next word 32)
+        u64 f = (x >> (o + 13)) | ((u64)w[k + 2] << (51 - o));
+        if (o > 19) f |= (u64)w[k + 3] << (83 - o);
         const u32 n = (u32)(f & 15) + 4;
         u64 L = f >> 4;
         L &= (1ull << (3 * n)) - 1;  // 3n <= 57
@@ -442,9 +454,13 @@ struct K0bBits {
   u32 n;          // valid bits in buf
   uint4 q;        // the aligned four words that hold word wi (fetched 16 octets at a time: a header is a serial
   u64 qi;         //   read of 60-150 octets, and every fetch is a memory round trip for the whole wave)
+  const u32* pre; // LDS [K0B_PRE_WORDS][64]: the candidate's first octets, loaded in one go (nullptr: none).  The lanes of
+  u64 pre0;       //   a wave are out of step, so on-demand fetches put one memory round trip into nearly EVERY trip of
+                  //   the symbol loop (measured: 346 us for 110 000 candidates, most of them rejected within 40 octets)
 };
 TBZ_DEV u32 k0b_word(K0bBits& b) {
   const u64 i = b.wi++;
+  if (b.pre && i - b.pre0 < K0B_PRE_WORDS) return b.pre[(i - b.pre0) * 64 + tbz_lane()];  // (already masked at the stream's end)
   if ((i & ~3ull) != b.qi) {
     b.qi = i & ~3ull;
     b.q = b.qi < b.nwords ? *(const uint4*)(b.w + b.qi) : uint4{};  // (an aligned 16-octet chunk that holds a stream octet is mapped)
@@ -466,7 +482,7 @@ TBZ_DEV u32 k0b_take(K0bBits& b, u32 k) {  // k <= 16
   b.n -= k;
   return v;
 }
-TBZ_DEV bool k0b_validate_one(const u8* in_base, u64 p, u64 s_lo_bit, u64 p_end, u8 (*tab)[64]) {
+TBZ_DEV bool k0b_validate_one(const u8* in_base, u64 p, u64 s_lo_bit, u64 p_end, u32* pre) {
   const u32 lane = tbz_lane();
   // the block that follows a flush marker is K0's: no duplicates
   if ((p & 7) == 0 && p >= s_lo_bit + 32) {
@@ -484,6 +500,22 @@ TBZ_DEV bool k0b_validate_one(const u8* in_base, u64 p, u64 s_lo_bit, u64 p_end,
   b.q = uint4{};
   b.buf = 0;
   b.n = 0;
+  b.pre = pre;
+  b.pre0 = b.wi & ~3ull;
+  if (pre) {  // eight independent 16-octet loads: one round trip
+#pragma unroll
+    for (u32 k = 0; k < K0B_PRE_WORDS; k += 4) {
+      const u64 wq = b.pre0 + k;
+      const uint4 v = wq < b.nwords ? *(const uint4*)(b.w + wq) : uint4{};
+      pre[(k + 0) * 64 + lane] = wq + 0 < b.nwords ? v.x : 0u;
+      pre[(k + 1) * 64 + lane] = wq + 1 < b.nwords ? v.y : 0u;
+      pre[(k + 2) * 64 + lane] = wq + 2 < b.nwords ? v.z : 0u;
+      pre[(k + 3) * 64 + lane] = wq + 3 < b.nwords ? v.w : 0u;
+    }
+  }
+#ifdef TBZ_WAVE_TRACE
+  if (tbz_exp_flags & 4) return false;
+#endif
   k0b_need(b, 32);
   b.buf >>= (a & 31);
   b.n -= (u32)(a & 31);
@@ -499,34 +531,50 @@ TBZ_DEV bool k0b_validate_one(const u8* in_base, u64 p, u64 s_lo_bit, u64 p_end,
     if (l) cnt += 1u << (4 * l);
   }
   used += 3 * hclen;
-  u32 next[8];
+  // The code-length code is decoded out of REGISTERS (canonical compare-count; no table: building a 128-entry table
+  // per lane cost 70 us of LDS stores per pass, and every lookup was an LDS round trip in a serial chain):
+  //   lim[l]  (8 bits each)  left-aligned 7-bit limit of the codes of length <= l
+  //   dlt[l]  (8 bits each)  canonical slot of a code c of length l = (c + dlt[l]) & 31
+  //   sorted  (5 bits each)  symbols in canonical order: by length, then by symbol
+  u64 limv = 0, dltv = 0, s0 = 0, s1 = 0;
   {
-    u32 code = 0, prev = 0;
+    u32 code = 0, prev = 0, off = 0;
+    u64 posv = 0;  // first slot of each length, 5 bits each
     for (u32 l = 1; l < 8; l++) {
       code = (code + prev) << 1;
       prev = (cnt >> (4 * l)) & 15;
-      next[l] = code;
+      limv |= (u64)(((code + prev) << (7 - l)) & 0xffu) << (8 * l);  // 128 (a complete code's last limit) is stored as 0x80
+      dltv |= (u64)((off - code) & 0xffu) << (8 * l);
+      posv |= (u64)off << (5 * l);
+      off += prev;
+    }
+    for (u32 sym = 0; sym < 19; sym++) {
+      const u32 l = (u32)(pl >> (3 * sym)) & 7;
+      if (!l) continue;
+      const u32 at = (u32)(posv >> (5 * l)) & 31;
+      posv += 1ull << (5 * l);
+      if (at < 12) s0 |= (u64)sym << (5 * at);
+      else s1 |= (u64)sym << (5 * (at - 12));
     }
   }
-  for (u32 j = 0; j < 128; j++) tab[j][lane] = 0;
-  for (u32 sym = 0; sym < 19; sym++) {
-    const u32 l = (u32)(pl >> (3 * sym)) & 7;
-    if (!l) continue;
-    u32 cd = 0;
-#pragma unroll
-    for (u32 q = 1; q < 8; q++)
-      if (q == l) cd = next[q]++;
-    const u32 rev = tbz_brev32(cd) >> (32 - l);
-    for (u32 j = rev; j < 128; j += 1u << l) tab[j][lane] = (u8)(l | (sym << 3));
-  }
+#ifdef TBZ_WAVE_TRACE
+  if (tbz_exp_flags & 8) return false;
+#endif
   const u32 n = hlit + hdist;
   u32 i = 0, last = 0xff, kl = 0, kd = 0, nl_used = 0, nd_used = 0;
   bool eob = false;
   while (i < n) {
+#ifdef TBZ_WAVE_TRACE
+    if (lane == (u32)__builtin_ctzll(tbz_ballot(true))) atomicAdd(&pre[K0B_PRE_WORDS * 64], 1u);
+#endif
     k0b_need(b, 16);
-    const u32 e = tab[(u32)b.buf & 127][lane];
-    const u32 l = e & 7, sym = e >> 3;
-    if (l == 0) return false;
+    const u32 r7 = tbz_brev32((u32)b.buf) >> 25;
+    u32 l = 1;
+#pragma unroll
+    for (u32 k = 1; k < 7; k++) l += r7 >= ((u32)(limv >> (8 * k)) & 0xffu) ? 1u : 0u;
+    if (l == 7 && r7 >= ((u32)(limv >> 56) & 0xffu) && ((u32)(limv >> 56) & 0xffu) != 0x80u) return false;  // (not reached: the scan kept complete codes only)
+    const u32 slot = ((r7 >> (7 - l)) + ((u32)(dltv >> (8 * l)) & 0xffu)) & 31;
+    const u32 sym = slot < 12 ? (u32)(s0 >> (5 * slot)) & 31 : (u32)(s1 >> (5 * (slot - 12))) & 31;
     const u32 xb = sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u;
     const u32 x = ((u32)(b.buf >> l)) & ((1u << xb) - 1);
     b.buf >>= l + xb;
@@ -565,7 +613,14 @@ TBZ_DEV bool k0b_validate_one(const u8* in_base, u64 p, u64 s_lo_bit, u64 p_end,
 }
 
 TBZ_KERNEL void tbz_k0b_validate(K0bParams P) {
-  TBZ_SHARED u8 tab[128][64];  // per lane: the code-length code's 7-bit lookup table (length | symbol << 3)
+#ifdef TBZ_WAVE_TRACE
+  TBZ_SHARED u32 pre[K0B_PRE_WORDS * 64 + 4];
+  const u64 tr0 = wall_clock64();
+  if (tbz_lane() == 0) pre[K0B_PRE_WORDS * 64] = 0;
+  tbz_sync();
+#else
+  TBZ_SHARED u32 pre[K0B_PRE_WORDS * 64];  // per lane: the first 128 octets of its candidate
+#endif
   const u32 lane = tbz_lane(), tile = tbz_block();
   const u32 s = k0b_find_stream(P, tile);
   const u64 s_lo_bit = P.str_off[s] * 8, p_end = (P.str_off[s] + P.str_len[s]) * 8;
@@ -578,7 +633,7 @@ TBZ_KERNEL void tbz_k0b_validate(K0bParams P) {
     bool ok = false;
     if (j < count) {
       p = slots[j];
-      ok = k0b_validate_one(P.in_base, p, s_lo_bit, p_end, tab);
+      ok = k0b_validate_one(P.in_base, p, s_lo_bit, p_end, pre);
     }
     const u64 okm = tbz_ballot(ok);
     tbz_sync();  // every lane has read its slot before the compacted ones are written (out index <= j)
@@ -587,6 +642,16 @@ TBZ_KERNEL void tbz_k0b_validate(K0bParams P) {
     tbz_sync();
   }
   if (lane == 0) P.counts[tile] = nout;
+#ifdef TBZ_WAVE_TRACE
+  tbz_sync();
+  if (lane == 0 && tile < 8192) {
+    tbz_dbg[tile * 8 + 0] = tr0;
+    tbz_dbg[tile * 8 + 1] = wall_clock64();
+    tbz_dbg[tile * 8 + 2] = pre[K0B_PRE_WORDS * 64];
+    tbz_dbg[tile * 8 + 3] = count;
+    tbz_dbg[tile * 8 + 4] = nout;
+  }
+#endif
 }
 
 // ================================================================================================
@@ -601,6 +666,7 @@ TBZ_KERNEL void tbz_k0b_validate(K0bParams P) {
 // The skim is the fixed code in arithmetic (RFC 1951 3.2.6): no tables.
 // Run for streams whose items are still large after K0 and K0b (nothing was found in them).
 // ================================================================================================
+constexpr u32 K0C_TILE = 16u << 10;       // octets of memory per workgroup of the scan
 constexpr u32 K0C_SLOTS = 512;            // pattern hits kept per 16 KiB tile (random data: ~256)
 constexpr u64 K0C_MAX_BLOCK = 64u << 10;  // bits: a candidate whose block would be longer is not followed (the skim is one
                                           // lane per block: its longest block is the kernel's duration)
@@ -611,12 +677,12 @@ TBZ_KERNEL void tbz_k0c_scan(K0bParams P) {
   const u32 s = k0b_find_stream(P, tile);
   const uintptr_t base = (uintptr_t)P.in_base;
   const uintptr_t s_lo = base + P.str_off[s], s_hi = s_lo + P.str_len[s];
-  const uintptr_t t0 = (s_lo & ~(uintptr_t)15) + (uintptr_t)(tile - P.tile_first[s]) * K0B_TILE;
+  const uintptr_t t0 = (s_lo & ~(uintptr_t)15) + (uintptr_t)(tile - P.tile_first[s]) * K0C_TILE;
   const u64 p_min = (u64)(s_lo - base) * 8 + 8 + (s == 0 ? P.start_bit_off : 0u);
   const u64 p_end = (u64)(s_hi - base) * 8;
   u64* slots = P.slots + (u64)tile * P.slots_per_tile;
   u32 nout = 0;
-  for (u32 r = 0; r < K0B_TILE / 1024; r++) {
+  for (u32 r = 0; r < K0C_TILE / 1024; r++) {
     const uintptr_t c = t0 + r * 1024 + lane * 16;
     if (t0 + r * 1024 >= s_hi) break;  // wave-uniform
     u32 w[5];
@@ -674,6 +740,8 @@ TBZ_DEV u64 k0c_skim_one(const u8* in_base, u64 p, u64 p_end) {
   b.q = uint4{};
   b.buf = 0;
   b.n = 0;
+  b.pre = nullptr;
+  b.pre0 = 0;
   k0b_need(b, 32);
   b.buf >>= (a & 31);
   b.n -= (u32)(a & 31);
@@ -729,7 +797,7 @@ TBZ_KERNEL void tbz_k0c_skim(K0bParams P) {
     const u64 q = e - 7;
     const uintptr_t addr = base + (q >> 3);
     if (addr < a_lo) continue;
-    const u32 t2 = P.tile_first[s] + (u32)((addr - a_lo) / K0B_TILE);
+    const u32 t2 = P.tile_first[s] + (u32)((addr - a_lo) / K0C_TILE);
     if (t2 >= P.tile_first[s + 1]) continue;
     const u64* sl2 = P.slots + (u64)t2 * P.slots_per_tile;
     u32 lo = 0, hi = P.counts[t2];
@@ -1737,6 +1805,9 @@ struct KgLds {
   GangState gs[64 / G];
   u32 inbuf[K1_INBUF][64];
   u8 tokring[64 * KG_RING_STRIDE];  // per lane: 16 token words on their way to memory (see TokOut)
+#ifdef TBZ_WAVE_TRACE
+  u32 tr_cnt[4];
+#endif
 };
 
 struct K1gParams {
@@ -1753,7 +1824,16 @@ struct K1gParams {
   u32 n_items;
   u32 ovl;                  // run-up bits before a lane's sub-range (KG_OVL; wider gangs need longer chains of lanes
                             // in sync and take a longer run-up)
+  u32 sub_min;              // least sub-range per lane (bits, multiple of 64): what the rounds after the first one run at
+#ifdef TBZ_WAVE_TRACE
+  u64* trace;               // experiment builds only: 8 words per workgroup (tools/exp/wave_trace.py)
+#endif
 };
+#ifdef TBZ_WAVE_TRACE
+#define TBZ_TR_NOW() wall_clock64()
+#else
+#define TBZ_TR_NOW() 0ull
+#endif
 
 struct __attribute__((packed, aligned(2))) U16x8 {  // eight token words at 2-octet alignment
   uint4 v;
@@ -2131,6 +2211,9 @@ struct RoundOut {
   u32 nhdr;     //   … this many block headers
   u32 assumed;  //   … an end-of-block code without knowing whether that block was the final one (it took it not to be)
   i32 bf_end;   // BFINAL of the block the lane was in when it stopped, -1 = the block it started in (no header passed)
+#ifdef TBZ_WAVE_TRACE
+  u32 li;
+#endif
 };
 // Decoding through block boundaries inside a lane's sub-range.  With the fixed code loaded (deflate.lisp:518-528 ->
 // ht-constants.lisp:9-32) the tables do not change from block to block, so "end-of-block, BFINAL, BTYPE=1" is consumed
@@ -2150,6 +2233,10 @@ struct TokOut {
   u16* stage;  // where the run goes in the token pool (16-octet aligned)
   u32 n;       // words produced
   u32 nf;      // words already stored (multiple of 8)
+#ifdef TBZ_WAVE_TRACE
+  u32 li;    // this lane's iterations
+  u32* cnt;  // LDS: wave trips of the token loop, phases
+#endif
 };
 TBZ_DEV void tok_put(TokOut& t, u32 w) { *(u16*)(t.ring + ((t.n & 15) << 1)) = (u16)w; }
 TBZ_DEV void tok_put2(TokOut& t, u32 w) {  // words n and n+1 from the halves of w
@@ -2157,6 +2244,17 @@ TBZ_DEV void tok_put2(TokOut& t, u32 w) {  // words n and n+1 from the halves of
   *(u16*)(t.ring + (((t.n + 1) & 15) << 1)) = (u16)(w >> 16);
 }
 TBZ_DEV void tok_flush_piece(TokOut& t) {  // the oldest 8 words
+#ifdef TBZ_WAVE_TRACE
+  if (tbz_exp_flags & 1) {
+    t.nf += 8;
+    return;
+  }
+  if (tbz_exp_flags & 2) {
+    *(uint4*)(t.stage + (t.nf & 63)) = *(const uint4*)(t.ring + ((t.nf & 15) << 1));
+    t.nf += 8;
+    return;
+  }
+#endif
   *(uint4*)(t.stage + t.nf) = *(const uint4*)(t.ring + ((t.nf & 15) << 1));
   t.nf += 8;
 }
@@ -2191,7 +2289,14 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, T
     // NOTE: conditions are combined with & and | on purpose — && / || / ?: on side-effect-free terms
     // become exec-mask branches here, and every branch costs the whole wave scalar work
     bool go = (K1_INBUF >= 5) & (rel < tgt);
+#ifdef TBZ_WAVE_TRACE
+    if (lane == (u32)__builtin_ctzll(tbz_ballot(true))) atomicAdd(&to.cnt[1], 1u);
+#endif
     while (go) {
+#ifdef TBZ_WAVE_TRACE
+      if (lane == (u32)__builtin_ctzll(tbz_ballot(true))) atomicAdd(&to.cnt[0], 1u);
+      to.li++;
+#endif
       const u32 x1 = wp[0], x2 = wp[64];
       const u32 pk = tbz_alignbit(hi, lo, o);
       u32 e = gt.lfast[pk & ((1u << KG_TBL) - 1)];
@@ -2378,6 +2483,10 @@ TBZ_DEV void kg_lane_round(const GangTables& gt, BitReader& B, u64 start, u64 re
   to.ring = ring;
   to.stage = stage;
   to.n = to.nf = 0;
+#ifdef TBZ_WAVE_TRACE
+  to.li = 0;
+  to.cnt = (u32*)(ring - tbz_lane() * KG_RING_STRIDE + 64 * KG_RING_STRIDE);
+#endif
   u32 out = 0;
   i32 mdef = -(1 << 30);
   br_seek_fill(B, start);
@@ -2393,6 +2502,9 @@ TBZ_DEV void kg_lane_round(const GangTables& gt, BitReader& B, u64 start, u64 re
   ro.n = 0;
   ro.out = 0;
   ro.mdef = mdef;
+#ifdef TBZ_WAVE_TRACE
+  ro.li = to.li;
+#endif
   if (junk) {
     ro.flag = RF_JUNK;
     return;
@@ -2414,6 +2526,9 @@ TBZ_DEV void kg_lane_round(const GangTables& gt, BitReader& B, u64 start, u64 re
   while (to.nf < n8 * 8) tok_flush_piece(to);
   ro.out = out;
   ro.mdef = mdef;
+#ifdef TBZ_WAVE_TRACE
+  ro.li = to.li;
+#endif
 }
 
 // run-table slots an item may use once it has consumed the bitstream up to `upto`: the table is
@@ -2599,6 +2714,8 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
   st.tok = tok0;
   st.fail_pos = it.start_bit;
   const u64 lim64 = st.end_bit < st.limit_bit ? st.end_bit : st.limit_bit;
+  [[maybe_unused]] const u64 tr_t0 = TBZ_TR_NOW();
+  [[maybe_unused]] u64 tr_hdr = 0, tr_build = 0, tr_round = 0, tr_commit = 0, tr_n = 0, tr_a = 0, tr_b = 0, tr_first = 0, tr_wt1 = 0, tr_li1 = 0, tr_ph1 = 0, tr_wt2 = 0, tr_li2 = 0;
 
   if (leader) {
     gs.P = it.start_bit;
@@ -2640,8 +2757,11 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     tbz_sync();
     if (tbz_ballot(gs.mode != GM_DONE) == 0) break;
     // ---- H: leaders whose gang is between blocks parse the next header
+    tr_a = TBZ_TR_NOW();
     if (leader && gs.mode == GM_HEADER) kg_leader_header(gt, gs, st, it, P, tok0, fmt, fixup, idx);
     tbz_sync();
+    tr_b = TBZ_TR_NOW();
+    tr_hdr += tr_b - tr_a;
     // ---- B: gangs with a new code build it together (wave-uniform branch: collectives inside)
     const bool building = gs.mode == GM_BUILD;
     if (tbz_ballot(building) != 0) {
@@ -2669,6 +2789,8 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
       tbz_sync();
     }
     // ---- R: one round for the gangs that are inside a Huffman block
+    tr_a = TBZ_TR_NOW();
+    tr_build += tr_a - tr_b;
     const bool inblk = gs.mode == GM_BLOCK;
     const u64 Pb = gs.P;
     RoundOut ro;
@@ -2683,6 +2805,11 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     ro.nhdr = 0;
     ro.assumed = 0;
     ro.bf_end = -1;
+#ifdef TBZ_WAVE_TRACE
+    ro.li = 0;
+    if (lane == 0) S.tr_cnt[0] = S.tr_cnt[1] = 0;
+    tbz_sync();
+#endif
     // consecutive fixed-Huffman blocks are decoded through (not by repair items: they land on a marker after EVERY block)
     const bool inl_on = inblk && gs.tables == 1 && !fixup && !gs.noinline;
     u16* stage = P.tok;
@@ -2693,7 +2820,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
       const u64 per = (remb + G - 1) / G;
       u32 sub = per >= KG_SUB_MAX ? KG_SUB_MAX : (u32)per;
       sub = (sub + 63) & ~63u;
-      sub = sub < KG_SUB_MIN ? KG_SUB_MIN : sub;
+      sub = sub < P.sub_min ? P.sub_min : sub;
       const u64 s_g = Pb + (u64)g * sub;
       const u64 start = g == 0 ? Pb : s_g - P.ovl;
       s_lo = s_g & ~7ull;
@@ -2703,6 +2830,18 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
       il.cur_bf = g == 0 ? (i32)gs.bfinal : -1;
       kg_lane_round(gt, st.br, start, s_g, s_g + sub, lim64, stage, S.tokring + lane * KG_RING_STRIDE, sub - 16, ro, il);
     }
+    tr_b = TBZ_TR_NOW();
+    tr_round += tr_b - tr_a;
+    if (tr_n == 0) tr_first = tr_b - tr_a;
+#ifdef TBZ_WAVE_TRACE
+    {
+      tbz_sync();
+      u32 mx = S.tr_cnt[0], sm = ro.li, pm = S.tr_cnt[1];
+      for (int m = 1; m < 64; m <<= 1) sm += tbz_shfl_xor(sm, m);
+      if (tr_n == 0) { tr_wt1 = mx; tr_li1 = sm; tr_ph1 = pm; } else { tr_wt2 += mx; tr_li2 += sm; }
+    }
+#endif
+    tr_n++;
     // ---- chain validation: lane g counts iff it began recording exactly where lane g-1 stopped
     const u32 pe_lo = tbz_wave_shr1((u32)ro.e), pe_hi = tbz_wave_shr1((u32)(ro.e >> 32));
     const u64 prev_e = ((u64)pe_hi << 32) | pe_lo;
@@ -2827,7 +2966,25 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
         gs.mode = GM_DONE;
       }
     }
+    tr_commit += TBZ_TR_NOW() - tr_b;
   }
+#ifdef TBZ_WAVE_TRACE
+  if (P.trace && lane == 0) {
+    u64* t = P.trace + (u64)tbz_block() * 16;
+    u32 xcc = 0, hwid = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    t[0] = tr_t0;
+    t[1] = TBZ_TR_NOW();
+    t[2] = ((u64)xcc << 32) | hwid;
+    t[3] = tr_hdr + tr_commit;
+    t[4] = tr_build;
+    t[5] = tr_round;
+    t[6] = tr_first;
+    t[7] = tr_n;
+    t[8] = tr_wt1; t[9] = tr_li1; t[10] = tr_ph1; t[11] = tr_wt2; t[12] = tr_li2;
+  }
+#endif
 
   if (leader && have) {
     SegResult r;
@@ -2918,6 +3075,12 @@ struct K2Params {
   u32 plane;          // 0: octets (a pointer's low octet where the source is symbolic) -> out_base
                       // 1: 0 for a known octet, 0x80 | pointer >> 8 for a symbolic one    -> out_base = the mark plane
   u64 out_bias;       // octet x of the output lives at out_base[x - out_bias] (the mark plane covers the streams' extent only)
+  // ---- ring launches that take plain groups and both planes of the H-groups together (k2_ring_select): workgroups
+  // [0, n_plain) handle order[0 .. n_plain), workgroup n_plain + 2k + q handles plane q of order[n_plain + k]
+  u32 mixed;          // 1: that mapping (hist / plane / out_base / out_bias above are then per workgroup, taken from below)
+  u32 n_plain;
+  u8* mark_base;
+  u64 mark_bias;
 };
 
 // A group whose whole output fits the LDS window needs no ring: LINEAR = true keeps every octet of
@@ -3042,9 +3205,10 @@ TBZ_DEV void k2_resolve(u8* win, u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist
 }
 
 // which group this workgroup handles; false: none (beyond the list, or filtered out by size class)
-TBZ_DEV bool k2_pick_group(const K2Params& P, u32& gi, Group& g, Seg& sg_guess) {
-  if (tbz_block() >= P.n_groups) return false;
-  gi = P.order ? P.order[tbz_block()] : tbz_block();
+TBZ_DEV bool k2_pick_group(const K2Params& P, u32& gi, Group& g, Seg& sg_guess, u32 at = ~0u) {
+  if (at == ~0u) at = tbz_block();
+  if (at >= P.n_groups) return false;
+  gi = P.order ? P.order[at] : at;
   sg_guess = P.segs[gi];  // device-built tables (K3) have segment i in group i: fetched along with the group
   g = P.groups[gi];
   if (!P.order && P.cls) {  // device-built tables (K3): one segment per group, sorted into launches by size here
@@ -3052,6 +3216,26 @@ TBZ_DEV bool k2_pick_group(const K2Params& P, u32& gi, Group& g, Seg& sg_guess) 
     if ((P.cls == 1) != small) return false;
   }
   return true;
+}
+
+// ring launches: which group, and which plane of it, this workgroup decodes (Q = the launch parameters as k2_body wants
+// them for that group)
+TBZ_DEV bool k2_ring_select(const K2Params& P, K2Params& Q, u32& gi, Group& g, Seg& sg_guess) {
+  Q = P;
+  if (!P.mixed) return k2_pick_group(P, gi, g, sg_guess);
+  const u32 b = tbz_block();
+  u32 at = b;
+  if (b >= P.n_plain) {
+    const u32 h = b - P.n_plain;
+    at = P.n_plain + (h >> 1);
+    Q.hist = 1;
+    Q.plane = h & 1;
+    if (h & 1) {
+      Q.out_base = P.mark_base;
+      Q.out_bias = P.mark_bias;
+    }
+  }
+  return k2_pick_group(P, gi, g, sg_guess, at);
 }
 
 // The front end of a group: token fetch, classification, offsets, literals; every batch's matches go to
@@ -3307,9 +3491,10 @@ TBZ_KERNEL void tbz_k2_lz77(K2Params P) {
   u32 gi;
   Group g;
   Seg sg;
-  if (!k2_pick_group(P, gi, g, sg)) return;
+  K2Params Q;
+  if (!k2_ring_select(P, Q, gi, g, sg)) return;
   k2_body<false, K2_SPAN, false>(
-      P, gi, g, sg, win, tks, rcache,
+      Q, gi, g, sg, win, tks, rcache,
       [&](u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) { k2_resolve<false>(win, pend, rpos, dofs, len, dist); },
       [](u64, u32) {});
 }
@@ -3443,12 +3628,13 @@ TBZ_KERNEL_WG(128, 1) void tbz_k2_lz77_ring2(K2Params P) {
   u32 gi;
   Group g;
   Seg sg;
-  if (!k2_pick_group(P, gi, g, sg)) return;  // both waves take the same decision
+  K2Params Q;
+  if (!k2_ring_select(P, Q, gi, g, sg)) return;  // both waves take the same decision
   const u32 lane = tbz_lane();
   if (tbz_wave() == 0) {
     u32 k = 0;
     k2_body<false, K2_SPAN_DUAL, true>(
-        P, gi, g, sg, win, tks, rcache,
+        Q, gi, g, sg, win, tks, rcache,
         [&](u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) {
           K2Hand& h = H[k & 1];
           h.desc[lane] = (u64)dofs | ((u64)len << 16) | ((u64)dist << 32);

@@ -873,6 +873,14 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
           TBZ_LAUNCH_DYN_WG(tbz_k2_lz77_dual, n_it, 128, k2.win_bytes + 2 * K2_TOKBUF + 512 + 2 * sizeof(K2Hand),
                             ctx->stream, k2);
       }
+#ifdef TBZ_WAVE_TRACE
+      if (const char* vp = getenv("TBZ_K2_TRACE")) {
+        std::vector<u64> h(8192 * 8);
+        hipStreamSynchronize(ctx->stream);
+        hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(tbz_dbg), h.size() * 8);
+        if (FILE* f = fopen(vp, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+      }
+#endif
       if (h_glob->n_big) {
         k2.win_bytes = 0;
         k2.cls = h_glob->n_big < n_it ? 2 : 0;
@@ -1330,6 +1338,14 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       else
         TBZ_LAUNCH_DYN_WG(tbz_k2_lz77_dual, order_small.size(), 128,
                           k2.win_bytes + 2 * K2_TOKBUF + 512 + 2 * sizeof(K2Hand), ctx->stream, k2);
+#ifdef TBZ_WAVE_TRACE
+      if (const char* vp = getenv("TBZ_K2_TRACE")) {
+        std::vector<u64> h(8192 * 8);
+        hipStreamSynchronize(ctx->stream);
+        hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(tbz_dbg), h.size() * 8);
+        if (FILE* f = fopen(vp, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+      }
+#endif
     }
     if (!order_big.empty() && order_h.empty()) {
       k2.order = (const u32*)ctx->d_order.p + order_small.size();

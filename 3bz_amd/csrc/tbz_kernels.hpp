@@ -327,6 +327,11 @@ TBZ_KERNEL void tbz_k0_scan_emit(K0Params P) {
 // decodes through them.
 // ================================================================================================
 #ifdef TBZ_WAVE_TRACE
+#define TBZ_TR_NOW() wall_clock64()
+#else
+#define TBZ_TR_NOW() 0ull
+#endif
+#ifdef TBZ_WAVE_TRACE
 __device__ u32 tbz_exp_flags;  // experiment builds (tools/exp): switches parts of kernels off to see what they cost
 __device__ u64 tbz_dbg[8192 * 8];
 __device__ u32 tbz_dbg_cnt[4];
@@ -1829,11 +1834,7 @@ struct K1gParams {
   u64* trace;               // experiment builds only: 8 words per workgroup (tools/exp/wave_trace.py)
 #endif
 };
-#ifdef TBZ_WAVE_TRACE
-#define TBZ_TR_NOW() wall_clock64()
-#else
-#define TBZ_TR_NOW() 0ull
-#endif
+
 
 struct __attribute__((packed, aligned(2))) U16x8 {  // eight token words at 2-octet alignment
   uint4 v;
@@ -3534,6 +3535,8 @@ TBZ_KERNEL_WG(128, 2) void tbz_k2_lz77_dual(K2Params P) {
   const u32 lane = tbz_lane();
   u8* win = dyn;
   K2Hand* H = (K2Hand*)(dyn + P.win_bytes + 2 * K2_TOKBUF + 512);
+  [[maybe_unused]] const u64 tr0 = TBZ_TR_NOW();
+  [[maybe_unused]] u64 tr_wait = 0, tr_x = 0;
   if (tbz_wave() == 0) {
     u32 k = 0;
     k2_body<true, K2_SPAN, false>(
@@ -3546,7 +3549,9 @@ TBZ_KERNEL_WG(128, 2) void tbz_k2_lz77_dual(K2Params P) {
             h.rpos = rpos;
             h.end = 0;
           }
+          tr_x = TBZ_TR_NOW();
           tbz_wg_barrier();
+          tr_wait += TBZ_TR_NOW() - tr_x;
           k += 1;
         },
         [&](u64 n_out, u32 a0) {
@@ -3556,8 +3561,21 @@ TBZ_KERNEL_WG(128, 2) void tbz_k2_lz77_dual(K2Params P) {
             h.pend = n_out;  // what wave 1 needs for the checksum: octets of the group, window index of the first
             h.rpos = a0;
           }
+          tr_x = TBZ_TR_NOW();
           tbz_wg_barrier();
+          tr_wait += TBZ_TR_NOW() - tr_x;
+#ifdef TBZ_WAVE_TRACE
+          if (lane == 0 && tbz_block() < 8192) {
+            tbz_dbg[tbz_block() * 8 + 0] = tr0;
+            tbz_dbg[tbz_block() * 8 + 2] = tr_wait;
+            tbz_dbg[tbz_block() * 8 + 3] = k;
+            tbz_dbg[tbz_block() * 8 + 6] = TBZ_TR_NOW();
+          }
+#endif
         });
+#ifdef TBZ_WAVE_TRACE
+    if (lane == 0 && tbz_block() < 8192) tbz_dbg[tbz_block() * 8 + 1] = TBZ_TR_NOW();
+#endif
   } else {
     for (u32 k = 0;; k++) {
       if (k > 0) {
@@ -3565,7 +3583,9 @@ TBZ_KERNEL_WG(128, 2) void tbz_k2_lz77_dual(K2Params P) {
         const u64 d = h.desc[lane];
         k2_resolve<true>(win, h.pend, h.rpos, (u32)(d & 0xffffu), (u32)((d >> 16) & 0xffffu), (u32)(d >> 32));
       }
+      tr_x = TBZ_TR_NOW();
       tbz_wg_barrier();
+      tr_wait += TBZ_TR_NOW() - tr_x;
       if (H[k & 1].end) {
         // every match is resolved: while wave 0 flushes the window, this wave takes the group's adler32
         // partial from it (A = sum b_i, B = sum (n - i) b_i; checksums.lisp:18-62 split for the combine)
@@ -3612,6 +3632,12 @@ TBZ_KERNEL_WG(128, 2) void tbz_k2_lz77_dual(K2Params P) {
         break;
       }
     }
+#ifdef TBZ_WAVE_TRACE
+    if (lane == 0 && tbz_block() < 8192) {
+      tbz_dbg[tbz_block() * 8 + 4] = tr_wait;
+      tbz_dbg[tbz_block() * 8 + 5] = TBZ_TR_NOW();
+    }
+#endif
   }
 }
 

@@ -1158,12 +1158,14 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   uint32_t n_recs = 0;
   // K2's parallelism is its number of groups: segments much larger than a fair share of the call's output are cut
   // into slices at run boundaries on the device (tbz_k3_slice); every slice becomes a group
-  uint64_t slice_target = 64u << 10;
+  uint64_t slice_target = 64u << 10, h_join_below = 48u << 10;
   {
     uint64_t tot = 0;
     for (size_t s = 0; s < n; s++) tot += std::min(sp[s].total_out, sp[s].out_cap);
     slice_target = std::max<uint64_t>(slice_target, tot / 4096);
     if (const char* m = getenv("TBZ_SLICE")) slice_target = std::max(1024, atoi(m));  // (tests force small slices)
+    h_join_below = std::min<uint64_t>(std::max<uint64_t>(48u << 10, tot / 2048), 256u << 10);
+    if (const char* m = getenv("TBZ_H_JOIN")) h_join_below = std::max(1024, atoi(m));
   }
   for (size_t s = 0; s < n; s++) {
     StreamPlan& S = sp[s];
@@ -1191,7 +1193,9 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     uint64_t o = 0;
     S.seg_first = (uint32_t)h_segs.size();
     const size_t g0 = h_groups.size();  // this stream's first group
-    constexpr uint64_t H_JOIN_BELOW = 48u << 10;  // a group keeps taking in history-needing segments below this size
+    // a group keeps taking in history-needing segments below this size: K6's chain is 2 * sqrt(H-groups) steps, so
+    // groups grow with the call's output while the ring kernel still gets some 2048 of them (x 2 planes; 1024 fit the chip)
+    const uint64_t H_JOIN_BELOW = h_join_below;
     bool after_big = false;
     for (size_t i = 0; i < v.size(); i++) {
       if (o >= R.out_len) break;

@@ -124,13 +124,19 @@ class Engine:
         self._check(self.lib.tbz_inflate_device(self._ctx, fmt, d_in, in_len, d_out, out_cap, C.byref(res)))
         return res
 
-    def inflate_batch_device(self, d_in, in_offs, in_lens, d_out, out_offs, out_caps, fmt):
+    @staticmethod
+    def u64_array(v):
+        """the C ABI's offset / length arrays; a caller that decodes the same batch shape again keeps them"""
+        return v if isinstance(v, C.Array) else (C.c_uint64 * len(v))(*v)
+
+    def inflate_batch_device(self, d_in, in_offs, in_lens, d_out, out_offs, out_caps, fmt, raw=False):
+        """raw=True: the tbz_result records as the ctypes array the library filled (indexable, not copied)"""
         n = len(in_offs)
-        a = lambda v: (C.c_uint64 * n)(*v)
+        a = self.u64_array
         res = (_lib.Result * n)()
         self._check(self.lib.tbz_inflate_batch_device(self._ctx, fmt, n, d_in, a(in_offs), a(in_lens), d_out,
                                                       a(out_offs), a(out_caps), res))
-        return list(res)
+        return res if raw else list(res)
 
     def adler32_device(self, d_buf, n, s1=1, s2=0):
         o1, o2 = C.c_uint32(), C.c_uint32()

@@ -452,13 +452,14 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     constexpr uint64_t FIND_MIN_ITEM_BITS = 8ull * (48u << 10);  // mean compressed octets per item below which it does not pay
     // ... nor when the call already has enough items to fill the chip (a batch of thousands of streams: measured on
     // config 3, 4096 gzip members, splitting them cost more in K2's second plane than it gained in K1)
-    const bool enough = (size_t)n_mark + n >= 2048;
+    const bool enough = (size_t)n_mark + n >= (getenv("TBZ_FIND_ENOUGH") ? (size_t)atol(getenv("TBZ_FIND_ENOUGH")) : (size_t)2048);
+    const uint64_t find_min_len = getenv("TBZ_FIND_MIN_LEN") ? (uint64_t)atol(getenv("TBZ_FIND_MIN_LEN")) : (uint64_t)(128u << 10);
     std::vector<uint32_t> tfb(n + 1);
     uint64_t tiles_b = 0;
     for (size_t s = 0; s < n; s++) {
       tfb[s] = (uint32_t)tiles_b;
       const uint64_t items_s = 1 + (first_marker[s + 1] - first_marker[s]);
-      const bool search = ctx->find_mode == 2 ? sp[s].in_len >= 64 : (!enough && sp[s].in_len >= (128u << 10) && sp[s].in_len * 8 / items_s >= FIND_MIN_ITEM_BITS);
+      const bool search = ctx->find_mode == 2 ? sp[s].in_len >= 64 : (!enough && sp[s].in_len >= find_min_len && sp[s].in_len * 8 / items_s >= FIND_MIN_ITEM_BITS);
       if (search) tiles_b += ((((uintptr_t)d_in + in_offs[s]) & 15) + in_lens[s] + K0B_TILE - 1) / K0B_TILE;
       if (tiles_b > 0x7fffffffu) return TBZ_E_ARG;
     }

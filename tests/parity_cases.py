@@ -270,6 +270,42 @@ def _fixed_chain(seed, nblk, maxtok, final_at=None):
     return w.getvalue(), bytes(out[:fin])
 
 
+def case_block_starts_found(eng, n_blocks=30, chunk=40_000):
+    """K0b finds EVERY dynamic-block header, wherever in a 32-bit word of memory it starts: a stream of `n_blocks`
+    blocks whose count is known by construction (deflate's Z_BLOCK flush ends a block and adds nothing — no marker for
+    K0), at all four octet alignments of the input, one K1 item per block.  (A first version of the scan read too few
+    bits for headers starting in the last three bits of a word: 9 % of the blocks were missed, their items spanned two
+    blocks and K1 was as slow as its stragglers.)  The final block (BFINAL = 1) is a candidate too."""
+    text = K.enwik_like(n_blocks * chunk, 0x3B8)
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    parts = []
+    for k in range(n_blocks):
+        parts.append(c.compress(text[k * chunk:(k + 1) * chunk]))
+        parts.append(c.flush(zlib.Z_BLOCK if k + 1 < n_blocks else zlib.Z_FINISH))
+    s = b"".join(parts)
+    assert_same(eng, s, "deflate", len(text), what="%d Z_BLOCK-delimited blocks" % n_blocks)
+    searched = len(s) >= 128 << 10 or os.environ.get("TBZ_FIND") == "always"
+    d_in, d_out = eng.malloc(len(s) + 80), eng.malloc(len(text) + 64)
+    counts = []
+    try:
+        for shift in range(4):
+            eng.h2d(d_in + shift, s)
+            res = eng.inflate_device(d_in + shift, len(s), d_out, len(text), T.FORMATS["deflate"])
+            t = eng.timings()
+            out = bytearray(len(text))
+            eng.d2h(out, d_out)
+            assert res.status == 0 and bytes(out) == text, shift
+            if searched:  # every block but the first (the head item's) is a candidate
+                assert t.n_candidates >= n_blocks - 1 and t.n_segments >= n_blocks, (shift, t.n_candidates, t.n_segments)
+            counts.append(t.n_candidates)
+        # the number of blocks does not depend on where the stream lies in memory (zlib may have split a chunk: the
+        # exact count is not known here, its independence of the alignment is)
+        assert len(set(counts)) == 1, counts
+    finally:
+        eng.free(d_in)
+        eng.free(d_out)
+
+
 def case_fixed_block_chains(eng):
     """Consecutive fixed-Huffman blocks are decoded THROUGH by the gang kernel (end-of-block + header consumed like a
     token; a lane that starts inside a block assumes it is not the final one): blocks of one to three tokens, blocks
@@ -934,7 +970,7 @@ def case_pointer_contexts(eng, n=60_000):
 
 
 ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_reference_chunk_patterns, case_containers_and_levels, case_flush_streams,
-             case_noflush_streams, case_fixed_block_chains, case_history_across_groups,
+             case_noflush_streams, case_block_starts_found, case_fixed_block_chains, case_history_across_groups,
              case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_device_buffers,
              case_checksum_kernels, case_deep_codes, case_chunked_resume, case_gzip_members,
              case_pointer_contexts, case_container_headers, case_gzip_metadata, case_scratch_bounds, case_fuzz]

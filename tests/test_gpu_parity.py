@@ -57,6 +57,7 @@ def test_gpu_reference_chunk_patterns_in_full(eng, request):
 def test_gpu_larger_sizes(eng):
     P.case_flush_streams(eng, n=8 << 20)
     P.case_noflush_streams(eng, n=6 << 20)
+    P.case_block_starts_found(eng, n_blocks=160)
     P.case_chunked_resume(eng, n=600_000)
     P.case_containers_and_levels(eng, n=2_000_000)
     P.case_configs_1_3_5(eng, adv_total=8 << 20)

@@ -1194,7 +1194,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     uint64_t o = 0;
     S.seg_first = (uint32_t)h_segs.size();
     const size_t g0 = h_groups.size();  // this stream's first group
-    // a group keeps taking in history-needing segments below this size: K6's chain is 2 * sqrt(H-groups) steps, so
+    // a group keeps taking in history-needing segments below this size: K6's chain grows with the cube root of their number, so
     // groups grow with the call's output while the ring kernel still gets some 2048 of them (x 2 planes; 1024 fit the chip)
     const uint64_t H_JOIN_BELOW = h_join_below;
     bool after_big = false;
@@ -1367,47 +1367,79 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         for (j = i; j < hgs.size() && hgs[j].stream == hgs[i].stream; j++) {}
         max_per_stream = std::max(max_per_stream, j - i);
       }
+      // three levels: groups -> blocks of at most bmax groups -> superblocks of at most bmax blocks, bmax = N^(1/3): the
+      // dependent chain is 3 * bmax steps (two levels: 2 * sqrt(N))
       size_t bmax = 1;
-      while (bmax * bmax < max_per_stream) bmax++;
+      while (bmax * bmax * bmax < max_per_stream) bmax++;
       if (const char* m = getenv("TBZ_K6_BLOCK")) bmax = std::max(1, atoi(m));
+      const bool three = !getenv("TBZ_K6_TWO_LEVELS");
+      if (!three) {
+        bmax = 1;
+        while (bmax * bmax < max_per_stream) bmax++;
+        if (const char* m = getenv("TBZ_K6_BLOCK")) bmax = std::max(1, atoi(m));
+      }
       std::vector<K6Range> ranges;
       std::vector<K6List> lists;
-      // section 1: tails of the groups of multi-group blocks (tbz_k6_chain_sym); section 2: one range per block, one
-      // list per stream (tbz_k6_chain); sections 3a / 3b: tbz_k6_resolve
-      std::vector<K6Range> r1, r2, r3a, r3b;
-      std::vector<K6List> l1, l2;
-      for (size_t i = 0, j; i < hgs.size(); i = j) {
-        K6List ls{(u32)r2.size(), 0};
-        for (j = i; j < hgs.size() && hgs[j].stream == hgs[i].stream;) {
-          size_t e = j + 1;  // block [j, e)
-          while (e < hgs.size() && e - j < bmax && hgs[e].stream == hgs[j].stream && hgs[e].start == hgs[e - 1].end) e++;
-          const uint64_t B0 = hgs[j].start, E = hgs[e - 1].end, fl = hgs[j].floor;
+      // section 1: tails of the groups of multi-group blocks (tbz_k6_chain_sym, relative to the block afterwards);
+      // section 1b: the last 32 KiB of the blocks of multi-block superblocks (tbz_k6_chain_sym again, relative to the
+      // superblock afterwards); section 2: one range per superblock, one list per stream (tbz_k6_chain: final);
+      // sections 3s / 3a / 3b: tbz_k6_resolve, in this order (what each refers to is final by then)
+      std::vector<K6Range> r1, r1b, r2, r3s, r3a, r3b;
+      std::vector<K6List> l1, l1b, l2;
+      struct Blk { size_t j, e; uint64_t B0, E, last_lo, fl; };
+      for (size_t i = 0, jj; i < hgs.size(); i = jj) {
+        // ---- this stream's blocks
+        std::vector<Blk> blks;
+        for (jj = i; jj < hgs.size() && hgs[jj].stream == hgs[i].stream;) {
+          size_t e = jj + 1;  // block [jj, e)
+          while (e < hgs.size() && e - jj < bmax && hgs[e].stream == hgs[jj].stream && hgs[e].start == hgs[e - 1].end) e++;
+          const uint64_t B0 = hgs[jj].start, E = hgs[e - 1].end, fl = hgs[jj].floor;
           const uint64_t last_lo = E - B0 > K6_W ? E - K6_W : B0;
-          if (e - j > 1) {
-            l1.push_back(K6List{(u32)r1.size(), (u32)(e - j)});
-            for (size_t k = j; k < e; k++) {
+          blks.push_back(Blk{jj, e, B0, E, last_lo, fl});
+          if (e - jj > 1) {
+            l1.push_back(K6List{(u32)r1.size(), (u32)(e - jj)});
+            for (size_t k = jj; k < e; k++) {
               const uint64_t t_lo = hgs[k].end - hgs[k].start > K6_W ? hgs[k].end - K6_W : hgs[k].start;
               r1.push_back(K6Range{hgs[k].start, t_lo, hgs[k].end, fl});
               if (t_lo < std::min(hgs[k].end, last_lo)) r3a.push_back(K6Range{B0, t_lo, std::min(hgs[k].end, last_lo), fl});
             }
           }
-          r2.push_back(K6Range{B0, last_lo, E, fl});
-          ls.count++;
-          for (size_t k = j; k < e; k++)  // a group's octets before its tail, in sub-ranges of at most 64 KiB
+          for (size_t k = jj; k < e; k++)  // a group's octets before its tail, in sub-ranges of at most 64 KiB
             if (hgs[k].end - hgs[k].start > K6_W)
               for (uint64_t x = hgs[k].start; x < hgs[k].end - K6_W; x += 65536)
                 r3b.push_back(K6Range{hgs[k].start, x, std::min(x + 65536, hgs[k].end - K6_W), fl});
-          j = e;
+          jj = e;
+        }
+        // ---- its superblocks: runs of adjacent blocks
+        K6List ls{(u32)r2.size(), 0};
+        for (size_t q = 0, qe; q < blks.size(); q = qe) {
+          qe = q + 1;
+          while (three && qe < blks.size() && qe - q < bmax && blks[qe].B0 == blks[qe - 1].E) qe++;
+          const uint64_t S0 = blks[q].B0, SE = blks[qe - 1].E, fl = blks[q].fl;
+          const uint64_t s_last_lo = SE - S0 > K6_W ? SE - K6_W : S0;
+          if (qe - q > 1) {
+            l1b.push_back(K6List{(u32)r1b.size(), (u32)(qe - q)});
+            for (size_t k = q; k < qe; k++) {
+              r1b.push_back(K6Range{blks[k].B0, blks[k].last_lo, blks[k].E, fl});
+              if (blks[k].last_lo < std::min(blks[k].E, s_last_lo)) r3s.push_back(K6Range{S0, blks[k].last_lo, std::min(blks[k].E, s_last_lo), fl});
+            }
+          }
+          r2.push_back(K6Range{S0, s_last_lo, SE, fl});
+          ls.count++;
         }
         l2.push_back(ls);
       }
-      for (auto& l : l2) l.first += (u32)r1.size();
-      const size_t o2 = r1.size(), o3a = o2 + r2.size(), o3b = o3a + r3a.size();
+      const size_t o1b = r1.size(), o2 = o1b + r1b.size(), o3s = o2 + r2.size(), o3a = o3s + r3s.size(), o3b = o3a + r3a.size();
+      for (auto& l : l1b) l.first += (u32)o1b;
+      for (auto& l : l2) l.first += (u32)o2;
       ranges = r1;
+      ranges.insert(ranges.end(), r1b.begin(), r1b.end());
       ranges.insert(ranges.end(), r2.begin(), r2.end());
+      ranges.insert(ranges.end(), r3s.begin(), r3s.end());
       ranges.insert(ranges.end(), r3a.begin(), r3a.end());
       ranges.insert(ranges.end(), r3b.begin(), r3b.end());
       lists = l1;
+      lists.insert(lists.end(), l1b.begin(), l1b.end());
       lists.insert(lists.end(), l2.begin(), l2.end());
       // the mark plane covers [mark_lo, mark_hi) of the output, at the same alignment (mod 16) as the output itself
       const uint32_t m0 = (uint32_t)(((uintptr_t)d_out + mark_lo) & 15);
@@ -1440,7 +1472,12 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         k6.n_lists = (u32)l1.size();
         TBZ_LAUNCH_WG(tbz_k6_chain_sym, l1.size(), K6_THREADS, ctx->stream, k6);
       }
-      k6.lists = dl + l1.size();
+      if (!l1b.empty()) {
+        k6.lists = dl + l1.size();
+        k6.n_lists = (u32)l1b.size();
+        TBZ_LAUNCH_WG(tbz_k6_chain_sym, l1b.size(), K6_THREADS, ctx->stream, k6);
+      }
+      k6.lists = dl + l1.size() + l1b.size();
       k6.n_lists = (u32)l2.size();
       TBZ_LAUNCH_WG(tbz_k6_chain, l2.size(), K6_THREADS, ctx->stream, k6);
       auto resolve = [&](size_t first, size_t count, uint64_t maxlen) {
@@ -1451,6 +1488,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         q.pieces = (u32)((maxlen + 15 + K6_PIECE - 1) / K6_PIECE);
         TBZ_LAUNCH(tbz_k6_resolve, count * (size_t)q.pieces, ctx->stream, q);
       };
+      resolve(o3s, r3s.size(), K6_W);
       resolve(o3a, r3a.size(), K6_W);
       resolve(o3b, r3b.size(), 65536);
       TBZ_HIP(hipEventRecord(ctx->ev[11], ctx->stream));

@@ -3723,12 +3723,15 @@ TBZ_KERNEL_WG(128, 1) void tbz_k2_lz77_ring2(K2Params P) {
 //   1. tbz_k6_chain_sym   blocks of consecutive H-groups, all blocks in parallel: one workgroup walks its block's
 //                         tails in order through a 32 KiB ring of SYMBOLS and rewrites them relative to the 32 KiB
 //                         before the BLOCK (pointers of pointers collapse);
-//   2. tbz_k6_chain       one workgroup per stream walks the blocks in order and makes each block's last 32 KiB
+//   1b. tbz_k6_chain_sym  again, one level up: superblocks of consecutive blocks; a workgroup walks the last 32 KiB of
+//                         its superblock's blocks and rewrites them relative to the 32 KiB before the SUPERBLOCK;
+//   2. tbz_k6_chain       one workgroup per stream walks the superblocks in order and makes each one's last 32 KiB
 //                         final out of a ring of final octets;
-//   3. tbz_k6_resolve     everything else in parallel, its sources being final by then: first the other tail octets
-//                         (relative to their block), then every H-group's octets before its tail (relative to itself).
-// The chain is (groups per block) + (blocks per stream) steps instead of one step per group; a step is one LDS gather
-// round, two workgroup barriers and the stores.
+//   3. tbz_k6_resolve     everything else in parallel, its sources being final by then: the blocks' last 32 KiB
+//                         (relative to their superblock), then the other tail octets (relative to their block), then
+//                         every H-group's octets before its tail (relative to itself).
+// The chain is three times the cube root of the number of H-groups instead of one step per group (the host sizes
+// blocks and superblocks: tbz_engine.hpp); a step is one LDS gather round, workgroup barriers and the stores.
 // ================================================================================================
 struct K6Range {   // the symbolic octets of [lo, hi): pointer i stands for the octet at absolute offset base - 32768 + i
   u64 base, lo, hi;

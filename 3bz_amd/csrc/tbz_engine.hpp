@@ -674,9 +674,61 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     TBZ_LAUNCH(tbz_k1_huff_decode, (n_it + k1.items_per_wg - 1) / k1.items_per_wg, ctx->stream, k1);
     return 0;
   };
+  auto sub_min_for = [&](int) -> u32 {
+    if (const char* m = getenv("TBZ_SUB_MIN")) return (u32)std::max(64, atoi(m) & ~63);
+    return KG_SUB_MIN;
+  };
+  // a gang narrower than 64 lanes declines items it would need more than eight full rounds for (the width follows the
+  // launch's mean item size: a batch of many small streams and one large one); the host decodes those with gangs of
+  // 64 (`redo`).  Not lower: where lanes do not fall into step (periodic bitstreams: config 5's 294 Kbit block, 1.8 lanes
+  // committed per round) a wider gang means shorter sub-ranges and MORE rounds — handing that block over cost 2.5 ms.
+  // Forced flavours (tests) keep everything.
+  auto wide_for = [&](int G, bool fix) -> u64 {
+    if (const char* m = getenv("TBZ_WIDE_BITS")) return (u64)atol(m);
+    if (ctx->k1_mode || fix || G >= 64) return 0;
+    return (u64)G * KG_SUB_MAX * 8;
+  };
+  auto ovl_for = [&](int G) -> u32 {
+    if (const char* m = getenv("TBZ_OVL")) return (u32)std::max(64, atoi(m));
+    // measured (profiles/README.md): a gang of 64 commits 29 lanes per round at 512 bits of run-up, 59 at 1024 (K1 on
+    // the 64 MiB no-flush stream 2.78 -> 1.56 ms, on config 3 8.96 -> 6.05 ms); gangs of 32 are flat from 512 to 768
+    return G >= 64 ? 1024u : KG_OVL;
+  };
   // items the gang kernel declined (SEG_REDO: token stream as dense as the bitstream, run table full) are
   // decoded again by the one-lane kernel, which writes one contiguous run
   auto redo = [&](const std::vector<Item>& its, std::vector<SegResult>& rs, bool fix) -> int {
+    {  // items a narrow gang handed back (SEG_WIDE): gangs of 64, the leader parsing the first header itself
+      std::vector<Item> wide;
+      std::vector<size_t> widx;
+      for (size_t i = 0; i < rs.size(); i++)
+        if (rs[i].status == SEG_WIDE) {
+          wide.push_back(its[i]);
+          widx.push_back(i);
+        }
+      if (!wide.empty()) {
+        if (getenv("TBZ_DEBUG")) {
+          uint64_t mx = 0;
+          for (const Item& q : wide) mx = std::max<uint64_t>(mx, std::min(q.limit_bit, q.end_byte * 8) - q.start_bit);
+          fprintf(stderr, "tbz: %zu large item(s) handed to gangs of 64 (the largest: %llu bits)\n", wide.size(), (unsigned long long)mx);
+        }
+        int rr;
+        if ((rr = upload(ctx, ctx->d_redo_items, wide))) return rr;
+        if ((rr = ensure(ctx, ctx->d_redo_res, wide.size() * sizeof(SegResult)))) return rr;
+        K1gParams kg{(const u8*)d_in, pool_tok(fix), pool_runs(fix), (const Item*)ctx->d_redo_items.p,
+                     (SegResult*)ctx->d_redo_res.p, d_markers_cur, d_first_marker, nullptr, nullptr, (u32)n_mark,
+                     (u32)wide.size(), ovl_for(64), sub_min_for(64), 0};
+#ifdef TBZ_WAVE_TRACE
+        kg.trace = nullptr;
+#endif
+        TBZ_LAUNCH(tbz_k1g64_huff_decode, wide.size(), ctx->stream, kg);
+        std::vector<SegResult> tmp(wide.size());
+        TBZ_HIP(hipMemcpyAsync(tmp.data(), ctx->d_redo_res.p, tmp.size() * sizeof(SegResult), hipMemcpyDeviceToHost,
+                               ctx->stream));
+        TBZ_HIP(hipStreamSynchronize(ctx->stream));
+        for (size_t k = 0; k < widx.size(); k++) rs[widx[k]] = tmp[k];
+        ctx->tim.huff_launches++;
+      }
+    }
     std::vector<Item> sub;
     std::vector<size_t> idx;
     for (size_t i = 0; i < rs.size(); i++)
@@ -698,16 +750,6 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     ctx->tim.huff_launches++;
     return 0;
   };
-  auto sub_min_for = [&](int) -> u32 {
-    if (const char* m = getenv("TBZ_SUB_MIN")) return (u32)std::max(64, atoi(m) & ~63);
-    return KG_SUB_MIN;
-  };
-  auto ovl_for = [&](int G) -> u32 {
-    if (const char* m = getenv("TBZ_OVL")) return (u32)std::max(64, atoi(m));
-    // measured (profiles/README.md): a gang of 64 commits 29 lanes per round at 512 bits of run-up, 59 at 1024 (K1 on
-    // the 64 MiB no-flush stream 2.78 -> 1.56 ms, on config 3 8.96 -> 6.05 ms); gangs of 32 are flat from 512 to 768
-    return G >= 64 ? 1024u : KG_OVL;
-  };
   auto launch_k1 = [&](const Item* d_items, SegResult* d_res, size_t n_it, bool fix) -> int {
     int G = k1_gang(n_it);
     if (!fix) ctx->tim.k1_gang = (uint32_t)G;
@@ -722,7 +764,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if (ctx->k1h) TBZ_LAUNCH(tbz_k1h_headers, (n_it + 63) / 64, ctx->stream, kh);
     K1gParams kg{(const u8*)d_in, pool_tok(fix), pool_runs(fix), d_items, d_res,
                  d_markers_cur, d_first_marker, ctx->k1h ? (const HdrRec*)ctx->d_hdr.p : nullptr,
-                 (const u8*)ctx->d_scratch.p, (u32)n_mark, (u32)n_it, ovl_for(G), sub_min_for(G)};
+                 (const u8*)ctx->d_scratch.p, (u32)n_mark, (u32)n_it, ovl_for(G), sub_min_for(G), wide_for(G, fix)};
 #ifdef TBZ_WAVE_TRACE
     {
       static int n_launch = 0;

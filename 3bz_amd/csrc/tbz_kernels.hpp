@@ -1836,6 +1836,7 @@ struct K1gParams {
   u32 ovl;                  // run-up bits before a lane's sub-range (KG_OVL; wider gangs need longer chains of lanes
                             // in sync and take a longer run-up)
   u32 sub_min;              // least sub-range per lane (bits, multiple of 64): what the rounds after the first one run at
+  u64 wide_bits;            // gangs narrower than 64 decline items longer than this (SEG_WIDE; 0: never)
 #ifdef TBZ_WAVE_TRACE
   u64* trace;               // experiment builds only: 8 words per workgroup (tools/exp/wave_trace.py)
 #endif
@@ -2745,6 +2746,10 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     gs.inl = gs.noinline = 0;
     // (an item far larger than any block an encoder emits holds several: a first guess, replaced after the first block)
     gs.est = (have && !fixup && lim64 > it.start_bit && lim64 - it.start_bit >= KG_MULTI_BLOCK_BITS) ? KG_BLOCK_GUESS_BITS : 0u;
+    if (G < 64 && have && !fixup && P.wide_bits && lim64 > it.start_bit && lim64 - it.start_bit > P.wide_bits) {
+      gs.status = SEG_WIDE;  // the gang width follows the launch's MEAN item: this one would be the kernel's straggler
+      gs.mode = GM_DONE;
+    } else
     if (have && (it.flags & ITEM_HEAD)) {
       br_seek_fill(st.br, it.start_bit);
       i32 e = k1_container_header(st, fmt);

@@ -34,8 +34,10 @@ enum : int32_t {
   SEG_FINAL = 2,      // decoded the BFINAL block (trailer fields valid)
   SEG_OVERSHOOT = 3,  // crossed limit_bit mid-block: resume from end_bit (= start of that block)
   SEG_UNDERRUN = 4,   // input ended (deflate.lisp:114-120); out_bytes/tok_words cover complete tokens
-  SEG_REDO = 5        // the gang kernel declined the item (token stream as dense as the bitstream, run table
+  SEG_REDO = 5,       // the gang kernel declined the item (token stream as dense as the bitstream, run table
                       // full): decode it again with one lane
+  SEG_WIDE = 6        // a narrow gang declined an item far larger than the launch's mean (K1gParams::wide_bits): the
+                      // host hands it to gangs of 64
   // <0: TBZ_E_* error codes of include/tbz_amd.h
 };
 

@@ -48,6 +48,30 @@ def test_emu_case(eng, case, request):
     case(eng)
 
 
+def test_emu_large_items_handed_to_wide_gangs():
+    """a gang narrower than 64 lanes declines items far larger than the launch's mean (SEG_WIDE) and the host decodes
+    them with gangs of 64: forced here with gangs of 8 and a 20 Kbit threshold (TBZ_WIDE_BITS is read per call)"""
+    T = importlib.import_module("3bz_amd")
+    os.environ["TBZ_K1_MODE"] = "gang8"
+    e = T.Engine(0, lib_path=os.path.join(EMU_DIR, "libtbz_emu.so"))
+    os.environ.pop("TBZ_K1_MODE", None)
+    os.environ["TBZ_WIDE_BITS"] = "20000"
+    try:
+        import zlib
+        from tools import corpus as K
+        p = K.enwik_like(300_000, 5)
+        out = bytearray(len(p))
+        r = e.inflate(zlib.compress(p, 6), T.FORMATS["zlib"], out)
+        t = e.timings()
+        assert r.status == 0 and bytes(out) == p
+        assert t.k1_gang == 8 and t.huff_launches >= 2, (t.k1_gang, t.huff_launches)  # the second launch: gangs of 64
+        P.case_flush_streams(e)
+        P.case_overflow_and_underrun(e)
+    finally:
+        os.environ.pop("TBZ_WIDE_BITS", None)
+        e.close()
+
+
 def test_emu_sanitized():
     """ASan/UBSan are CPU-only on this pool: the kernel + engine sources, compiled with both, run the cases
     that stress addressing (known-answer vectors; false markers incl. crowded tiles and fix-up rounds).  The

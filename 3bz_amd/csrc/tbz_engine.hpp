@@ -920,6 +920,10 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       if (const char* vp = getenv("TBZ_K2_TRACE")) {
         std::vector<u64> h(8192 * 8);
         hipStreamSynchronize(ctx->stream);
+        u32 cn[4] = {0, 0, 0, 0};
+        hipMemcpyFromSymbol(cn, HIP_SYMBOL(tbz_dbg_cnt), 16);
+        fprintf(stderr, "tbz: K2 resolve since the start: %u batches with matches, %.2f rounds and %.1f matches per batch\n", cn[0],
+                cn[0] ? (double)cn[1] / cn[0] : 0.0, cn[0] ? (double)cn[2] / cn[0] : 0.0);
         hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(tbz_dbg), h.size() * 8);
         if (FILE* f = fopen(vp, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
       }
@@ -1389,6 +1393,10 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       if (const char* vp = getenv("TBZ_K2_TRACE")) {
         std::vector<u64> h(8192 * 8);
         hipStreamSynchronize(ctx->stream);
+        u32 cn[4] = {0, 0, 0, 0};
+        hipMemcpyFromSymbol(cn, HIP_SYMBOL(tbz_dbg_cnt), 16);
+        fprintf(stderr, "tbz: K2 resolve since the start: %u batches with matches, %.2f rounds and %.1f matches per batch\n", cn[0],
+                cn[0] ? (double)cn[1] / cn[0] : 0.0, cn[0] ? (double)cn[2] / cn[0] : 0.0);
         hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(tbz_dbg), h.size() * 8);
         if (FILE* f = fopen(vp, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
       }

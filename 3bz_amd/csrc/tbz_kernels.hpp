@@ -3184,7 +3184,14 @@ TBZ_DEV void k2_resolve(u8* win, u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist
   // writes that cover exactly [rd, rd + len)
   const bool fastable = len <= K2_SHORT && dist >= len && (LINEAR || (rs + 32 <= K2_WIN && rd + 32 <= K2_WIN));
   tbz_sync();
+#ifdef TBZ_WAVE_TRACE
+  u32 tr_rounds = 0;
+  const u32 tr_matches = (u32)tbz_popc64(pend);
+#endif
   while (pend) {
+#ifdef TBZ_WAVE_TRACE
+    tr_rounds += 1;
+#endif
     const u32 first = (u32)tbz_ffs64(pend) - 1;
     const i32 hwm = (i32)tbz_readlane(dofs, first);
     const bool ready = (pend & lane_bit) && need <= hwm;
@@ -3228,7 +3235,15 @@ TBZ_DEV void k2_resolve(u8* win, u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist
     pend &= ~rdy;
     tbz_sync();
   }
+#ifdef TBZ_WAVE_TRACE
+  if (lane == 0 && tr_matches) {
+    atomicAdd(&tbz_dbg_cnt[0], 1u);          // batches with matches
+    atomicAdd(&tbz_dbg_cnt[1], tr_rounds);   // rounds
+    atomicAdd(&tbz_dbg_cnt[2], tr_matches);  // matches
+  }
+#endif
 }
+
 
 // which group this workgroup handles; false: none (beyond the list, or filtered out by size class)
 TBZ_DEV bool k2_pick_group(const K2Params& P, u32& gi, Group& g, Seg& sg_guess, u32 at = ~0u) {

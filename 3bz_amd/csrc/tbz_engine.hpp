@@ -490,7 +490,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         if (FILE* f = fopen(vp, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
       }
 #endif
-      TBZ_LAUNCH(tbz_k0b_offsets, 1, ctx->stream, kb);
+      TBZ_LAUNCH_WG(tbz_k0b_offsets, 1, K0B_SCAN_THREADS, ctx->stream, kb);
       TBZ_LAUNCH(tbz_k0b_compact, tiles_b, ctx->stream, kb);
       const size_t max_merge = (size_t)n_mark + tiles_b * (size_t)K0B_SLOTS;
       TBZ_LAUNCH(tbz_k0b_merge, (max_merge + 63) / 64, ctx->stream, kb);
@@ -580,7 +580,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       TBZ_LAUNCH(tbz_k0c_skim, tiles_c * (size_t)(K0C_SLOTS / 64), ctx->stream, kc);
       TBZ_LAUNCH(tbz_k0c_link, tiles_c, ctx->stream, kc);
       TBZ_LAUNCH(tbz_k0c_filter, tiles_c, ctx->stream, kc);
-      TBZ_LAUNCH(tbz_k0b_offsets, 1, ctx->stream, kc);
+      TBZ_LAUNCH_WG(tbz_k0b_offsets, 1, K0B_SCAN_THREADS, ctx->stream, kc);
       TBZ_LAUNCH(tbz_k0b_compact, tiles_c, ctx->stream, kc);
       const size_t max_merge = (size_t)n_mark + nslot;
       TBZ_LAUNCH(tbz_k0b_merge, (max_merge + 63) / 64, ctx->stream, kc);

@@ -890,16 +890,31 @@ TBZ_KERNEL void tbz_k0c_filter(K0bParams P) {
 }
 
 // single wave: exclusive scan of the per-tile counts
-TBZ_KERNEL void tbz_k0b_offsets(K0bParams P) {
-  const u32 lane = tbz_lane();
+// exclusive scan of the tiles' counts: ONE workgroup of 1024 threads, 1024 tiles per step (a single wave took 0.31 ms
+// for the 63 000 tiles of a 1 GiB stream: one memory round trip per 64 tiles)
+constexpr u32 K0B_SCAN_THREADS = 1024;
+TBZ_KERNEL_WG(1024, 1) void tbz_k0b_offsets(K0bParams P) {
+  TBZ_SHARED u32 wsum[16];
+  const u32 lane = tbz_lane(), wave = tbz_wave(), tid = wave * 64 + lane;
   u32 carry = 0;
-  for (u32 i = 0; i < P.n_tiles; i += 64) {
-    const u32 v = (i + lane) < P.n_tiles ? P.counts[i + lane] : 0;
+  for (u32 i = 0; i < P.n_tiles; i += K0B_SCAN_THREADS) {  // uniform over the workgroup
+    const bool in = i + tid < P.n_tiles;
+    const u32 v = in ? P.counts[i + tid] : 0;
     const u32 inc = wave_incl_scan_u32(v);
-    if ((i + lane) < P.n_tiles) P.offsets[i + lane] = carry + inc - v;
-    carry += tbz_shfl(inc, 63);
+    if (lane == 63) wsum[wave] = inc;
+    tbz_wg_barrier();
+    u32 before = 0, total = 0;
+#pragma unroll
+    for (u32 k = 0; k < 16; k++) {
+      const u32 x = wsum[k];
+      before += k < wave ? x : 0u;
+      total += x;
+    }
+    if (in) P.offsets[i + tid] = carry + before + inc - v;
+    carry += total;
+    tbz_wg_barrier();  // wsum is rewritten in the next step
   }
-  if (lane == 0) {
+  if (tid == 0) {
     P.offsets[P.n_tiles] = carry;
     P.head[0] = carry;
   }

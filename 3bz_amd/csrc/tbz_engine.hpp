@@ -479,9 +479,12 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
                    (const u32*)ctx->d_kb_tf.p, (u32)n, (u32)tiles_b, (u64*)ctx->d_kb_slots.p, (u32*)ctx->d_kb_counts.p,
                    (u32*)ctx->d_kb_offsets.p, (u64*)ctx->d_kb_cands.p, (u32*)ctx->d_kb_fc.p, (u32*)ctx->d_kb_head.p,
                    (const u64*)ctx->d_markers.p, (const u32*)ctx->d_k0_fm.p + 2, (u64*)ctx->d_markers2.p,
-                   (u32*)ctx->d_kb_fm2.p + 2, (u32*)ctx->d_kb_fm2.p, bit_off, K0B_SLOTS, nullptr, nullptr};
+                   (u32*)ctx->d_kb_fm2.p + 2, (u32*)ctx->d_kb_fm2.p, bit_off, K0B_SLOTS,
+                   getenv("TBZ_K0B_PAIR") ? (u32)(atoi(getenv("TBZ_K0B_PAIR")) != 0) : (tiles_b >= 8192 ? 1u : 0u), nullptr, nullptr};
       TBZ_LAUNCH(tbz_k0b_scan, tiles_b, ctx->stream, kb);
-      TBZ_LAUNCH(tbz_k0b_validate, tiles_b, ctx->stream, kb);
+      // (a launch that fits the chip at once — 64 MiB of input — is as long as its slowest wave: a tile per wave; beyond
+      // that it is throughput that counts: two tiles per wave, 32 lanes each)
+      TBZ_LAUNCH(tbz_k0b_validate, kb.pair ? (tiles_b + 1) / 2 : tiles_b, ctx->stream, kb);
 #ifdef TBZ_WAVE_TRACE
       if (const char* vp = getenv("TBZ_VAL_TRACE")) {
         std::vector<u64> h(8192 * 8);
@@ -574,7 +577,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
                    (const u32*)ctx->d_kc_tf.p, (u32)n, (u32)tiles_c, (u64*)ctx->d_kc_slots.p, (u32*)ctx->d_kb_counts.p,
                    (u32*)ctx->d_kb_offsets.p, (u64*)ctx->d_kb_cands.p, (u32*)ctx->d_kb_fc.p, (u32*)ctx->d_kb_head.p,
                    d_markers_cur, d_first_marker, (u64*)ctx->d_markers3.p,
-                   (u32*)ctx->d_kc_fm2.p + 2, (u32*)ctx->d_kc_fm2.p, bit_off, K0C_SLOTS, (u64*)ctx->d_kc_ends.p,
+                   (u32*)ctx->d_kc_fm2.p + 2, (u32*)ctx->d_kc_fm2.p, bit_off, K0C_SLOTS, 0, (u64*)ctx->d_kc_ends.p,
                    (u8*)ctx->d_kc_link.p};
       TBZ_LAUNCH(tbz_k0c_scan, tiles_c, ctx->stream, kc);
       TBZ_LAUNCH(tbz_k0c_skim, tiles_c * (size_t)(K0C_SLOTS / 64), ctx->stream, kc);

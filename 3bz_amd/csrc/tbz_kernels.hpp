@@ -362,6 +362,7 @@ struct K0bParams {
   u32* head_merged;        //   [2]: total, 0  (laid out as K0Params::head for tbz_k0_items)
   u32 start_bit_off;       // stream 0 begins at this bit of its first octet: nothing before it is a candidate
   u32 slots_per_tile;      // K0B_SLOTS for the dynamic-header finder, K0C_SLOTS for the fixed-chain finder
+  u32 pair;                // tbz_k0b_validate: 1 = two tiles per wave (32 lanes each), for launches of many waves
   u64* ends;               // K0c: [n_tiles][slots_per_tile] where the block that starts at the slot's candidate ends (0: nowhere)
   u8* link;                // K0c: [n_tiles][slots_per_tile][2]: [0] some candidate's block ends here, [1] ... and on THAT
                            //   candidate a block ends too
@@ -617,6 +618,9 @@ TBZ_DEV bool k0b_validate_one(const u8* in_base, u64 p, u64 s_lo_bit, u64 p_end,
   return true;
 }
 
+// One wave serves TWO tiles, 32 lanes each: a tile holds ~28 survivors, and nearly every tile holds one that parses for
+// 150+ symbols (a true header, or a false one whose lengths stay far below a complete code), so a wave per tile ran a
+// median of 165 trips of the symbol loop with 28 of 64 lanes occupied at the start.
 TBZ_KERNEL void tbz_k0b_validate(K0bParams P) {
 #ifdef TBZ_WAVE_TRACE
   TBZ_SHARED u32 pre[K0B_PRE_WORDS * 64 + 4];
@@ -626,27 +630,33 @@ TBZ_KERNEL void tbz_k0b_validate(K0bParams P) {
 #else
   TBZ_SHARED u32 pre[K0B_PRE_WORDS * 64];  // per lane: the first 128 octets of its candidate
 #endif
-  const u32 lane = tbz_lane(), tile = tbz_block();
-  const u32 s = k0b_find_stream(P, tile);
+  // (P.pair = 0: one tile per wave — fewer trips per wave, better where the launch fits the chip at once)
+  const u32 lane = tbz_lane(), half = P.pair ? lane >> 5 : 0u, hl = P.pair ? lane & 31 : lane, W = P.pair ? 32u : 64u;
+  const u32 tile = P.pair ? 2 * tbz_block() + half : tbz_block();
+  const bool have = tile < P.n_tiles;
+  const u32 s = have ? k0b_find_stream(P, tile) : 0;
   const u64 s_lo_bit = P.str_off[s] * 8, p_end = (P.str_off[s] + P.str_len[s]) * 8;
-  u64* slots = P.slots + (u64)tile * P.slots_per_tile;
-  const u32 count = P.counts[tile];
+  u64* slots = P.slots + (u64)(have ? tile : 0) * P.slots_per_tile;
+  const u32 count = have ? P.counts[tile] : 0;
+  const u32 c0 = tbz_shfl(count, 0), c1 = tbz_shfl(count, 32);
+  const u32 cmax = c0 > c1 ? c0 : c1;
   u32 nout = 0;
-  for (u32 j0 = 0; j0 < count; j0 += 64) {  // wave-uniform trip count
-    const u32 j = j0 + lane;
+  for (u32 j0 = 0; j0 < cmax; j0 += W) {  // wave-uniform trip count
+    const u32 j = j0 + hl;
     u64 p = 0;
     bool ok = false;
     if (j < count) {
       p = slots[j];
       ok = k0b_validate_one(P.in_base, p, s_lo_bit, p_end, pre);
     }
-    const u64 okm = tbz_ballot(ok);
+    u64 okm = tbz_ballot(ok);
+    if (P.pair) okm = (okm >> (32 * half)) & 0xffffffffull;  // my tile's half of the wave
     tbz_sync();  // every lane has read its slot before the compacted ones are written (out index <= j)
-    if (ok) slots[nout + tbz_popc64(okm & ((1ull << lane) - 1))] = p;
+    if (ok) slots[nout + tbz_popc64(okm & ((1ull << hl) - 1))] = p;
     nout += tbz_popc64(okm);
     tbz_sync();
   }
-  if (lane == 0) P.counts[tile] = nout;
+  if (hl == 0 && have) P.counts[tile] = nout;
 #ifdef TBZ_WAVE_TRACE
   tbz_sync();
   if (lane == 0 && tile < 8192) {

@@ -72,6 +72,27 @@ def test_emu_large_items_handed_to_wide_gangs():
         e.close()
 
 
+def test_emu_k0b_two_tiles_per_wave():
+    """large launches of the K0b validation put two tiles on a wave (32 lanes each): forced here at a small size"""
+    T = importlib.import_module("3bz_amd")
+    e = T.Engine(0, lib_path=os.path.join(EMU_DIR, "libtbz_emu.so"))
+    os.environ["TBZ_K0B_PAIR"] = "1"
+    try:
+        P.case_block_starts_found(e)
+        os.environ["TBZ_FIND"] = "always"
+        e2 = T.Engine(0, lib_path=os.path.join(EMU_DIR, "libtbz_emu.so"))
+        os.environ.pop("TBZ_FIND", None)
+        try:
+            P.case_known_answer_vectors(e2)
+            P.case_false_markers(e2)
+        finally:
+            e2.close()
+    finally:
+        os.environ.pop("TBZ_K0B_PAIR", None)
+        os.environ.pop("TBZ_FIND", None)
+        e.close()
+
+
 def test_emu_sanitized():
     """ASan/UBSan are CPU-only on this pool: the kernel + engine sources, compiled with both, run the cases
     that stress addressing (known-answer vectors; false markers incl. crowded tiles and fix-up rounds).  The

@@ -393,7 +393,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
                 (u32*)ctx->d_k0_fm.p + 2, (u32*)ctx->d_k0_fm.p, (Item*)ctx->d_items.p, (u32)format, 0, bit_off};
     const size_t max_items = tiles * (size_t)K0_SLOTS + n;
     TBZ_LAUNCH(tbz_k0_scan_tiles, tiles, ctx->stream, k0);
-    TBZ_LAUNCH(tbz_k0_scan_offsets, 1, ctx->stream, k0);
+    TBZ_LAUNCH_WG(tbz_k0_scan_offsets, 1, K0_SCAN_THREADS, ctx->stream, k0);
     TBZ_LAUNCH(tbz_k0_compact, tiles, ctx->stream, k0);
     TBZ_LAUNCH(tbz_k0_items, (max_items + 63) / 64, ctx->stream, k0);
     uint32_t* h_head = (uint32_t*)ctx->h_pin;

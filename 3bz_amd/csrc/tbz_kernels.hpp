@@ -233,27 +233,40 @@ TBZ_KERNEL void tbz_k0_scan_tiles(K0Params P) {
 }
 
 // single-wave exclusive scan over tile counts
-TBZ_KERNEL void tbz_k0_scan_offsets(K0Params P) {
-  const u32 lane = tbz_lane();
-  u32 carry = 0;
-  for (u32 i = 0; i < P.n_tiles; i += 256) {  // four rows per trip: their loads go out together
-    u32 v[4];
+// (ONE workgroup of 1024 threads, 1024 tiles per step: a single wave took 30 us for config 2's 16 384 tiles)
+constexpr u32 K0_SCAN_THREADS = 1024;
+TBZ_KERNEL_WG(1024, 1) void tbz_k0_scan_offsets(K0Params P) {
+  TBZ_SHARED u32 wsum[16];
+  TBZ_SHARED u32 wover[16];
+  const u32 lane = tbz_lane(), wave = tbz_wave(), tid = wave * 64 + lane;
+  u32 carry = 0, over = 0;
+  for (u32 i = 0; i < P.n_tiles; i += K0_SCAN_THREADS) {  // uniform over the workgroup
+    const bool in = i + tid < P.n_tiles;
+    const u32 v = in ? P.tile_counts[i + tid] : 0;
+    over += v > K0_SLOTS ? 1u : 0u;
+    const u32 inc = wave_incl_scan_u32(v);
+    if (lane == 63) wsum[wave] = inc;
+    tbz_wg_barrier();
+    u32 before = 0, total = 0;
 #pragma unroll
-    for (u32 q = 0; q < 4; q++) v[q] = (i + q * 64 + lane) < P.n_tiles ? P.tile_counts[i + q * 64 + lane] : 0;
-#pragma unroll
-    for (u32 q = 0; q < 4; q++) {
-      const u32 inc = wave_incl_scan_u32(v[q]);
-      if ((i + q * 64 + lane) < P.n_tiles) P.tile_offsets[i + q * 64 + lane] = carry + inc - v[q];
-      carry += tbz_shfl(inc, 63);
+    for (u32 k = 0; k < 16; k++) {
+      const u32 x = wsum[k];
+      before += k < wave ? x : 0u;
+      total += x;
     }
+    if (in) P.tile_offsets[i + tid] = carry + before + inc - v;
+    carry += total;
+    tbz_wg_barrier();  // wsum is rewritten in the next step
   }
-  u32 over = 0;
-  for (u32 i = lane; i < P.n_tiles; i += 64) over += P.tile_counts[i] > K0_SLOTS ? 1u : 0u;
   over = (u32)wave_sum_u64(over);
-  if (lane == 0) {
+  if (lane == 0) wover[wave] = over;
+  tbz_wg_barrier();
+  if (tid == 0) {
+    u32 ov = 0;
+    for (u32 k = 0; k < 16; k++) ov += wover[k];
     P.tile_offsets[P.n_tiles] = carry;
     P.head[0] = carry;
-    P.head[1] = over;
+    P.head[1] = ov;
   }
 }
 

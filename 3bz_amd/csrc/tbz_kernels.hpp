@@ -3921,9 +3921,11 @@ TBZ_DEV void k6_chain(const K6Params& P, u8* W0, u8* W1) {
     if (g.hi > g.lo) {
       // 1. the window [need_lo, base): whatever of it the ring does not hold comes from memory, where it is final
       //    (octets of groups that needed no history, or octets this loop stored in an earlier step)
+      bool dirty = gi == 0;  // the ring has been written since the last barrier: its initialisation, or the reload below
       if (!SYM) {
         const u64 need_lo = g.base - g.floor > K6_W ? g.base - K6_W : g.floor;
         if (!(w_hi == g.base && w_lo <= need_lo)) {
+          dirty = true;
           const bool older = w_hi == g.base && w_lo < g.base;  // contiguous but short: the older part only
           const u64 upto = older ? w_lo : g.base;
           tbz_device_fence();  // (octets this workgroup stored in earlier steps must come back from L2, not a stale L1 line)
@@ -3933,7 +3935,7 @@ TBZ_DEV void k6_chain(const K6Params& P, u8* W0, u8* W1) {
           if (!older) w_hi = g.base;
         }
       }
-      tbz_wg_barrier();
+      if (dirty) tbz_wg_barrier();  // (workgroup-uniform; the step before ended in a barrier)
       // 2. gather first (a destination's ring slot is the slot of the source 32 KiB before it), then store.  Threads own
       //    16-octet chunks that are aligned in address space.
       const u32 rbase = (u32)(ob + g.base);

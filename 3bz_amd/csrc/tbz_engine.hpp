@@ -56,13 +56,23 @@ struct tbz_ctx {
                          // they join their predecessors' group instead, one workgroup per chain, as in round 1)
   uint64_t pool_cap = 96ull << 30;  // octets of token pool + run tables one pass may hold (env TBZ_POOL_CAP_MIB): a batch
                                     // whose streams need more is decoded in several passes over consecutive streams
+  // thresholds and diagnostics switches (tests force the rare paths at small sizes): read ONCE, when the context is created
+  struct Tun {
+    long find_enough = 2048, find_min_len = 128 << 10;
+    int k0b_pair = -1;        // -1: by launch size
+    int sub_min = 0, ovl = 0; // 0: the defaults
+    long wide_bits = -1;      // -1: by gang width
+    int slice = 0, h_join = 0, k6_block = 0;
+    bool k6_two_levels = false, no_fused_adler = false, debug = false, debug2 = false;
+    std::string debug_cands;
+  } tun;
   int find_mode = 1;  // K0b block-start finder: 0 never, 1 for streams whose items are large (default), 2 for every stream
                       // of at least one finder tile (env TBZ_FIND=off|auto|always; tests force it at small sizes)
   // device pools (grow-only)
   tbz::DevBuf d_str_off, d_str_len, d_tile_first, d_tile_counts, d_tile_offsets, d_markers, d_items, d_res,
       d_tok, d_scratch, d_runs, d_segs, d_groups, d_order, d_k3_fi, d_k3_ni, d_k3_oo, d_k3_oc, d_k3_sums, d_k3_flags,
       d_k3_gscan, d_k3_gne, d_k3_streams, d_k3_glob, d_redo_items, d_redo_res, d_k0_slots, d_k0_fm, d_hdr, d_gck, d_gchunks, d_ck_l1, d_tok2, d_runs2, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
-      d_out_stage, d_kb_tf, d_kb_slots, d_kb_counts, d_kb_offsets, d_kb_cands, d_kb_fc, d_kb_head, d_markers2, d_kb_fm2, d_mark, d_hg, d_k6s, d_bigs, d_recs, d_kc_tf, d_kc_slots, d_kc_ends, d_kc_link, d_kc_fm2, d_markers3;
+      d_out_stage, d_kb_tf, d_kb_slots, d_kb_counts, d_kb_offsets, d_kb_cands, d_kb_fc, d_kb_head, d_markers2, d_kb_fm2, d_mark, d_hg, d_k6s, d_bigs, d_recs, d_kc_tf, d_kc_slots, d_kc_ends, d_kc_link, d_kc_fm2, d_markers3, d_kb_keep, d_kb_kcounts;
 };
 
 namespace tbz {
@@ -78,7 +88,8 @@ static std::vector<DevBuf*> all_pools(tbz_ctx* ctx) {
           &ctx->d_gck, &ctx->d_gchunks, &ctx->d_ck_l1, &ctx->d_tok2, &ctx->d_runs2, &ctx->d_kb_tf, &ctx->d_kb_slots,
           &ctx->d_kb_counts, &ctx->d_kb_offsets, &ctx->d_kb_cands, &ctx->d_kb_fc, &ctx->d_kb_head, &ctx->d_markers2,
           &ctx->d_kb_fm2, &ctx->d_mark, &ctx->d_hg, &ctx->d_k6s, &ctx->d_bigs, &ctx->d_recs, &ctx->d_kc_tf,
-          &ctx->d_kc_slots, &ctx->d_kc_ends, &ctx->d_kc_link, &ctx->d_kc_fm2, &ctx->d_markers3};
+          &ctx->d_kc_slots, &ctx->d_kc_ends, &ctx->d_kc_link, &ctx->d_kc_fm2, &ctx->d_markers3, &ctx->d_kb_keep,
+          &ctx->d_kb_kcounts};
 }
 static uint64_t scratch_total(tbz_ctx* ctx) {
   uint64_t t = 0;
@@ -452,8 +463,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     constexpr uint64_t FIND_MIN_ITEM_BITS = 8ull * (48u << 10);  // mean compressed octets per item below which it does not pay
     // ... nor when the call already has enough items to fill the chip (a batch of thousands of streams: measured on
     // config 3, 4096 gzip members, splitting them cost more in K2's second plane than it gained in K1)
-    const bool enough = (size_t)n_mark + n >= (getenv("TBZ_FIND_ENOUGH") ? (size_t)atol(getenv("TBZ_FIND_ENOUGH")) : (size_t)2048);
-    const uint64_t find_min_len = getenv("TBZ_FIND_MIN_LEN") ? (uint64_t)atol(getenv("TBZ_FIND_MIN_LEN")) : (uint64_t)(128u << 10);
+    const bool enough = (size_t)n_mark + n >= (size_t)ctx->tun.find_enough;
+    const uint64_t find_min_len = (uint64_t)ctx->tun.find_min_len;
     std::vector<uint32_t> tfb(n + 1);
     uint64_t tiles_b = 0;
     for (size_t s = 0; s < n; s++) {
@@ -469,6 +480,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       if ((r = upload(ctx, ctx->d_kb_tf, tfb))) return r;
       if ((r = ensure(ctx, ctx->d_kb_slots, tiles_b * (size_t)K0B_SLOTS * 8))) return r;
       if ((r = ensure(ctx, ctx->d_kb_counts, tiles_b * 4))) return r;
+      if ((r = ensure(ctx, ctx->d_kb_kcounts, tiles_b * 4))) return r;
+      if ((r = ensure(ctx, ctx->d_kb_keep, tiles_b * (size_t)(K0B_SLOTS / 64) * 8))) return r;
       if ((r = ensure(ctx, ctx->d_kb_offsets, (tiles_b + 1) * 4))) return r;
       if ((r = ensure(ctx, ctx->d_kb_cands, tiles_b * (size_t)K0B_SLOTS * 8 + 16))) return r;
       if ((r = ensure(ctx, ctx->d_kb_fc, (n + 1) * 4))) return r;
@@ -480,7 +493,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
                    (u32*)ctx->d_kb_offsets.p, (u64*)ctx->d_kb_cands.p, (u32*)ctx->d_kb_fc.p, (u32*)ctx->d_kb_head.p,
                    (const u64*)ctx->d_markers.p, (const u32*)ctx->d_k0_fm.p + 2, (u64*)ctx->d_markers2.p,
                    (u32*)ctx->d_kb_fm2.p + 2, (u32*)ctx->d_kb_fm2.p, bit_off, K0B_SLOTS,
-                   getenv("TBZ_K0B_PAIR") ? (u32)(atoi(getenv("TBZ_K0B_PAIR")) != 0) : (tiles_b >= 8192 ? 1u : 0u), nullptr, nullptr};
+                   ctx->tun.k0b_pair >= 0 ? (u32)(ctx->tun.k0b_pair != 0) : (tiles_b >= 8192 ? 1u : 0u), nullptr, nullptr,
+                   (u64*)ctx->d_kb_keep.p, (u32*)ctx->d_kb_kcounts.p};
       TBZ_LAUNCH(tbz_k0b_scan, tiles_b, ctx->stream, kb);
       // (a launch that fits the chip at once — 64 MiB of input — is as long as its slowest wave: a tile per wave; beyond
       // that it is throughput that counts: two tiles per wave, 32 lanes each)
@@ -493,6 +507,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         if (FILE* f = fopen(vp, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
       }
 #endif
+      TBZ_LAUNCH(tbz_k0b_space, tiles_b, ctx->stream, kb);  // (candidates too close to a marker, the head or each other: dropped)
       TBZ_LAUNCH_WG(tbz_k0b_offsets, 1, K0B_SCAN_THREADS, ctx->stream, kb);
       TBZ_LAUNCH(tbz_k0b_compact, tiles_b, ctx->stream, kb);
       const size_t max_merge = (size_t)n_mark + tiles_b * (size_t)K0B_SLOTS;
@@ -502,7 +517,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       TBZ_HIP(hipStreamSynchronize(ctx->stream));
       const uint32_t n_merged = h_head[0];
       ctx->tim.n_candidates = n_merged - n_mark;
-      if (const char* dp = getenv("TBZ_DEBUG_CANDS")) {  // the merged list of bit positions, for tools/ that compare it with the true block starts
+      if (const char* dp = ctx->tun.debug_cands.empty() ? nullptr : ctx->tun.debug_cands.c_str()) {  // the merged list of bit positions, for tools/ that compare it with the true block starts
         std::vector<uint64_t> hm(n_merged);
         TBZ_HIP(hipMemcpy(hm.data(), ctx->d_markers2.p, hm.size() * 8, hipMemcpyDeviceToHost));
         if (FILE* f = fopen(dp, "wb")) {
@@ -566,6 +581,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       if ((r = ensure(ctx, ctx->d_kc_ends, nslot * 8))) return r;
       if ((r = ensure(ctx, ctx->d_kc_link, nslot * 2))) return r;
       if ((r = ensure(ctx, ctx->d_kb_counts, tiles_c * 4))) return r;
+      if ((r = ensure(ctx, ctx->d_kb_kcounts, tiles_c * 4))) return r;
+      if ((r = ensure(ctx, ctx->d_kb_keep, tiles_c * (size_t)(K0C_SLOTS / 64) * 8))) return r;
       if ((r = ensure(ctx, ctx->d_kb_offsets, (tiles_c + 1) * 4))) return r;
       if ((r = ensure(ctx, ctx->d_kb_cands, nslot * 8 + 16))) return r;
       if ((r = ensure(ctx, ctx->d_kb_fc, (n + 1) * 4))) return r;
@@ -578,7 +595,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
                    (u32*)ctx->d_kb_offsets.p, (u64*)ctx->d_kb_cands.p, (u32*)ctx->d_kb_fc.p, (u32*)ctx->d_kb_head.p,
                    d_markers_cur, d_first_marker, (u64*)ctx->d_markers3.p,
                    (u32*)ctx->d_kc_fm2.p + 2, (u32*)ctx->d_kc_fm2.p, bit_off, K0C_SLOTS, 0, (u64*)ctx->d_kc_ends.p,
-                   (u8*)ctx->d_kc_link.p};
+                   (u8*)ctx->d_kc_link.p, (u64*)ctx->d_kb_keep.p, (u32*)ctx->d_kb_kcounts.p};
       TBZ_LAUNCH(tbz_k0c_scan, tiles_c, ctx->stream, kc);
       TBZ_LAUNCH(tbz_k0c_skim, tiles_c * (size_t)(K0C_SLOTS / 64), ctx->stream, kc);
       TBZ_LAUNCH(tbz_k0c_link, tiles_c, ctx->stream, kc);
@@ -678,7 +695,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     return 0;
   };
   auto sub_min_for = [&](int) -> u32 {
-    if (const char* m = getenv("TBZ_SUB_MIN")) return (u32)std::max(64, atoi(m) & ~63);
+    if (ctx->tun.sub_min) return (u32)std::max(64, ctx->tun.sub_min & ~63);
     return KG_SUB_MIN;
   };
   // a gang narrower than 64 lanes declines items it would need more than eight full rounds for (the width follows the
@@ -687,12 +704,12 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   // committed per round) a wider gang means shorter sub-ranges and MORE rounds — handing that block over cost 2.5 ms.
   // Forced flavours (tests) keep everything.
   auto wide_for = [&](int G, bool fix) -> u64 {
-    if (const char* m = getenv("TBZ_WIDE_BITS")) return (u64)atol(m);
+    if (ctx->tun.wide_bits >= 0) return (u64)ctx->tun.wide_bits;
     if (ctx->k1_mode || fix || G >= 64) return 0;
     return (u64)G * KG_SUB_MAX * 8;
   };
   auto ovl_for = [&](int G) -> u32 {
-    if (const char* m = getenv("TBZ_OVL")) return (u32)std::max(64, atoi(m));
+    if (ctx->tun.ovl) return (u32)std::max(64, ctx->tun.ovl);
     // measured (profiles/README.md): a gang of 64 commits 29 lanes per round at 512 bits of run-up, 59 at 1024 (K1 on
     // the 64 MiB no-flush stream 2.78 -> 1.56 ms, on config 3 8.96 -> 6.05 ms); gangs of 32 are flat from 512 to 768
     return G >= 64 ? 1024u : KG_OVL;
@@ -709,7 +726,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
           widx.push_back(i);
         }
       if (!wide.empty()) {
-        if (getenv("TBZ_DEBUG")) {
+        if (ctx->tun.debug) {
           uint64_t mx = 0;
           for (const Item& q : wide) mx = std::max<uint64_t>(mx, std::min(q.limit_bit, q.end_byte * 8) - q.start_bit);
           fprintf(stderr, "tbz: %zu large item(s) handed to gangs of 64 (the largest: %llu bits)\n", wide.size(), (unsigned long long)mx);
@@ -740,7 +757,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         idx.push_back(i);
       }
     if (sub.empty()) return 0;
-    if (getenv("TBZ_DEBUG")) fprintf(stderr, "tbz: %zu item(s) redone by the one-lane kernel\n", sub.size());
+    if (ctx->tun.debug) fprintf(stderr, "tbz: %zu item(s) redone by the one-lane kernel\n", sub.size());
     int rr;
     if ((rr = upload(ctx, ctx->d_redo_items, sub))) return rr;
     if ((rr = ensure(ctx, ctx->d_redo_res, sub.size() * sizeof(SegResult)))) return rr;
@@ -853,7 +870,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     // an item far larger than a fair share of the output is sliced (tbz_k3_slice): the general path lays that out
     if (simple && ctx->sym_hist && !size_only) {
       uint64_t target = std::max<uint64_t>(64u << 10, h_glob->total_out / 4096);
-      if (const char* m = getenv("TBZ_SLICE")) target = std::max(1024, atoi(m));
+      if (ctx->tun.slice) target = std::max(1024, ctx->tun.slice);
       if (h_glob->max_out >= 2 * target) simple = false;
     }
   }
@@ -900,7 +917,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if (!size_only) {
       if (!d_out) return TBZ_E_ARG;
       const u32 n_it = (u32)n_items;
-      fused_adler = format == TBZ_FORMAT_ZLIB && !ctx->k2_single && h_glob->n_big == 0 && !getenv("TBZ_NO_FUSED_ADLER");
+      fused_adler = format == TBZ_FORMAT_ZLIB && !ctx->k2_single && h_glob->n_big == 0 && !ctx->tun.no_fused_adler;
       K2Params k2{pool_tok(false), pool_runs(false), nullptr, nullptr, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, nullptr,
                   (const u8*)d_in, (u8*)d_out, n_it, 0, 0, nullptr, nullptr, 0, 0, 0};
       if (h_glob->n_big < n_it) {
@@ -1003,7 +1020,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     h.deficit = q.max_deficit;
     h.continues = S.next_continues;
     S.next_continues = false;
-    if (getenv("TBZ_DEBUG2")) fprintf(stderr, "consume: start_bit %llu status %d end_bit %llu out %llu tok %llu runs %u deficit %u fixup %d\n", (unsigned long long)it.start_bit, q.status, (unsigned long long)q.end_bit, (unsigned long long)q.out_bytes, (unsigned long long)q.tok_words, q.n_runs, q.max_deficit, (int)is_fixup);
+    if (ctx->tun.debug2) fprintf(stderr, "consume: start_bit %llu status %d end_bit %llu out %llu tok %llu runs %u deficit %u fixup %d\n", (unsigned long long)it.start_bit, q.status, (unsigned long long)q.end_bit, (unsigned long long)q.out_bytes, (unsigned long long)q.tok_words, q.n_runs, q.max_deficit, (int)is_fixup);
     if (q.tok_words || q.out_bytes) per_stream[s].push_back(h);
     else if (h.continues) S.next_continues = true;  // nothing emitted: carry the flag forward
     S.total_out += q.out_bytes;
@@ -1138,7 +1155,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     }
   }
   ctx->tim.huff_ms = huff_ms;
-  if (getenv("TBZ_DEBUG")) fprintf(stderr, "tbz: gang rounds %llu, committed lanes %llu (%.2f per round)\n", (unsigned long long)ctx->gang_rounds, (unsigned long long)ctx->gang_valid, ctx->gang_rounds ? (double)ctx->gang_valid / ctx->gang_rounds : 0.0);
+  if (ctx->tun.debug) fprintf(stderr, "tbz: gang rounds %llu, committed lanes %llu (%.2f per round)\n", (unsigned long long)ctx->gang_rounds, (unsigned long long)ctx->gang_valid, ctx->gang_rounds ? (double)ctx->gang_valid / ctx->gang_rounds : 0.0);
 
   // ---------------------------------------------------------------- distance errors vs output overflow
   // history check (deflate.lisp:343-345): a match may not reach before the stream's first octet.  Every segment
@@ -1213,9 +1230,9 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     uint64_t tot = 0;
     for (size_t s = 0; s < n; s++) tot += std::min(sp[s].total_out, sp[s].out_cap);
     slice_target = std::max<uint64_t>(slice_target, tot / 4096);
-    if (const char* m = getenv("TBZ_SLICE")) slice_target = std::max(1024, atoi(m));  // (tests force small slices)
+    if (ctx->tun.slice) slice_target = std::max(1024, ctx->tun.slice);  // (tests force small slices)
     h_join_below = std::min<uint64_t>(std::max<uint64_t>(48u << 10, tot / 2048), 256u << 10);
-    if (const char* m = getenv("TBZ_H_JOIN")) h_join_below = std::max(1024, atoi(m));
+    if (ctx->tun.h_join) h_join_below = std::max(1024, ctx->tun.h_join);
   }
   for (size_t s = 0; s < n; s++) {
     StreamPlan& S = sp[s];
@@ -1424,12 +1441,12 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       // dependent chain is 3 * bmax steps (two levels: 2 * sqrt(N))
       size_t bmax = 1;
       while (bmax * bmax * bmax < max_per_stream) bmax++;
-      if (const char* m = getenv("TBZ_K6_BLOCK")) bmax = std::max(1, atoi(m));
-      const bool three = !getenv("TBZ_K6_TWO_LEVELS");
+      if (ctx->tun.k6_block) bmax = std::max(1, ctx->tun.k6_block);
+      const bool three = !ctx->tun.k6_two_levels;
       if (!three) {
         bmax = 1;
         while (bmax * bmax < max_per_stream) bmax++;
-        if (const char* m = getenv("TBZ_K6_BLOCK")) bmax = std::max(1, atoi(m));
+        if (ctx->tun.k6_block) bmax = std::max(1, ctx->tun.k6_block);
       }
       std::vector<K6Range> ranges;
       std::vector<K6List> lists;
@@ -1614,7 +1631,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   ctx->tim.cksum_ms = elapsed(ctx, 5, 6);
   ctx->tim.total_ms = elapsed(ctx, 0, 6);
   ctx->tim.scratch_bytes = scratch_total(ctx);
-  if (getenv("TBZ_DEBUG") && !ctx->tim.fixup_rounds)
+  if (ctx->tun.debug && !ctx->tim.fixup_rounds)
     fprintf(stderr, "tbz: ms scan %.3f | items+upload %.3f | huff %.3f | results+walk+layout %.3f | lz %.3f | cksum %.3f\n",
             elapsed(ctx, 0, 1), elapsed(ctx, 1, 2), elapsed(ctx, 2, 3), elapsed(ctx, 3, 4), elapsed(ctx, 4, 5),
             elapsed(ctx, 5, 6));
@@ -1693,6 +1710,23 @@ int tbz_ctx_create(int device_id, tbz_ctx** out_ctx) {
   }
   if ((e = hipMemcpy(ctx->d_crc_tab.p, t.data(), t.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
     return fail(e, "hipMemcpy");
+  {
+    tbz_ctx::Tun& t = ctx->tun;
+    if (const char* m = getenv("TBZ_FIND_ENOUGH")) t.find_enough = atol(m);
+    if (const char* m = getenv("TBZ_FIND_MIN_LEN")) t.find_min_len = atol(m);
+    if (const char* m = getenv("TBZ_K0B_PAIR")) t.k0b_pair = atoi(m) != 0;
+    if (const char* m = getenv("TBZ_SUB_MIN")) t.sub_min = atoi(m);
+    if (const char* m = getenv("TBZ_OVL")) t.ovl = atoi(m);
+    if (const char* m = getenv("TBZ_WIDE_BITS")) t.wide_bits = atol(m);
+    if (const char* m = getenv("TBZ_SLICE")) t.slice = atoi(m);
+    if (const char* m = getenv("TBZ_H_JOIN")) t.h_join = atoi(m);
+    if (const char* m = getenv("TBZ_K6_BLOCK")) t.k6_block = atoi(m);
+    t.k6_two_levels = getenv("TBZ_K6_TWO_LEVELS") != nullptr;
+    t.no_fused_adler = getenv("TBZ_NO_FUSED_ADLER") != nullptr;
+    t.debug = getenv("TBZ_DEBUG") != nullptr;
+    t.debug2 = getenv("TBZ_DEBUG2") != nullptr;
+    if (const char* m = getenv("TBZ_DEBUG_CANDS")) t.debug_cands = m;
+  }
   if (const char* m = getenv("TBZ_HOST_LAYOUT")) ctx->host_layout = m[0] == '1';
   if (const char* m = getenv("TBZ_K2_MODE")) ctx->k2_single = !strcmp(m, "single");
   if (const char* m = getenv("TBZ_K1H")) ctx->k1h = m[0] != '0';

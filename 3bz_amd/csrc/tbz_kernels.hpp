@@ -379,6 +379,8 @@ struct K0bParams {
   u64* ends;               // K0c: [n_tiles][slots_per_tile] where the block that starts at the slot's candidate ends (0: nowhere)
   u8* link;                // K0c: [n_tiles][slots_per_tile][2]: [0] some candidate's block ends here, [1] ... and on THAT
                            //   candidate a block ends too
+  u64* keep;               // [n_tiles][slots_per_tile / 64]: which of a tile's `counts` slots survive the spacing rule
+  u32* kcounts;            // [n_tiles]: how many (what tbz_k0b_offsets scans)
 };
 TBZ_DEV u32 k0b_find_stream(const K0bParams& P, u32 tile) {
   u32 lo = 0, hi = P.n_streams;  // tile_first[lo] <= tile < tile_first[hi]; streams without tiles are skipped over
@@ -682,6 +684,61 @@ TBZ_KERNEL void tbz_k0b_validate(K0bParams P) {
 #endif
 }
 
+// Items must start at least 2^RUN_SHIFT bits apart: an item's run table is addressed by its start position (one slot per
+// 2^RUN_SHIFT bits, and every item owns at least one slot), so two starts inside one slot's span would share it.  Flush
+// markers keep that distance among themselves (a marker is five octets); candidates do not — a Z_BLOCK-flushed fixed
+// block of one or two literals is 17-28 bits long, and the dynamic block after it is a candidate right behind a
+// marker, the stream's head or another candidate.  Rule (K0C_SPACING bits, for K0b's and K0c's candidates alike): a
+// candidate is dropped when a marker or the stream's head lies within the spacing on either side, or another candidate
+// of the (immutable) list before it does — dropped or not, so the decision needs no order among workgroups.  The item
+// before a dropped candidate simply decodes through it.  The verdict is a bit mask per tile; tbz_k0b_compact applies it.
+constexpr u64 K0C_SPACING = 128;
+static_assert(K0C_SPACING >= (1ull << RUN_SHIFT), "item starts must not share a run-table slot");
+TBZ_DEV bool k0x_marker_near(const K0bParams& P, u32 s, u64 p) {
+  u32 lo = P.first_marker[s];
+  const u32 m_hi = P.first_marker[s + 1];
+  u32 hi = m_hi;
+  while (lo < hi) {
+    const u32 mid = (lo + hi) >> 1;
+    if (P.markers[mid] + K0C_SPACING <= p) lo = mid + 1; else hi = mid;
+  }
+  return lo < m_hi && P.markers[lo] < p + K0C_SPACING;
+}
+// the last slot of the tile before (same stream), or 0: whatever lies further back is a tile away
+TBZ_DEV u64 k0x_prev_tile_last(const K0bParams& P, u32 s, u32 tile) {
+  if (tile <= P.tile_first[s]) return 0;
+  const u32 cp = P.counts[tile - 1];
+  return cp ? P.slots[(u64)(tile - 1) * P.slots_per_tile + cp - 1] : 0;
+}
+// `ok`: the lane's slot j0 + lane passes every other test; `p` its position.  Returns the keep verdict: ok, no
+// marker / head near, no slot of the list within the spacing before it (`carry`: the last slot before this chunk).
+TBZ_DEV bool k0x_spaced(const K0bParams& P, u32 s, u64 head, u64 p, bool have, bool ok, u64& carry) {
+  const u32 lane = tbz_lane();
+  if (ok) ok = p >= head + K0C_SPACING && !k0x_marker_near(P, s, p);
+  const u32 b_lo = tbz_wave_shr1((u32)p), b_hi = tbz_wave_shr1((u32)(p >> 32));
+  const u64 before = lane == 0 ? carry : (((u64)b_hi << 32) | b_lo);
+  const u64 hm = tbz_ballot(have);
+  if (hm) carry = tbz_shfl64(p, 63 - (int)__builtin_clzll(hm));
+  return ok && (before == 0 || p - before >= K0C_SPACING);
+}
+TBZ_KERNEL void tbz_k0b_space(K0bParams P) {
+  const u32 lane = tbz_lane(), tile = tbz_block();
+  const u32 s = k0b_find_stream(P, tile);
+  const u64* slots = P.slots + (u64)tile * P.slots_per_tile;
+  const u32 count = P.counts[tile];
+  const u64 head = P.str_off[s] * 8 + (s == 0 ? P.start_bit_off : 0u);
+  u64 carry = k0x_prev_tile_last(P, s, tile);
+  u32 kept = 0;
+  for (u32 j0 = 0; j0 < P.slots_per_tile; j0 += 64) {  // wave-uniform trip count; every mask word is written
+    const bool have = j0 + lane < count;
+    const u64 p = have ? slots[j0 + lane] : 0;
+    const u64 km = tbz_ballot(k0x_spaced(P, s, head, p, have, have, carry));
+    if (lane == 0) P.keep[(u64)tile * (P.slots_per_tile / 64) + j0 / 64] = km;
+    kept += tbz_popc64(km);
+  }
+  if (lane == 0) P.kcounts[tile] = kept;
+}
+
 // ================================================================================================
 // K0c — chains of fixed-Huffman blocks.  A fixed-Huffman block (BTYPE=1, deflate.lisp:518-528 ->
 // ht-constants.lisp:9-32) has no header to recognise, but where one FOLLOWS another the end-of-block code of the
@@ -852,64 +909,32 @@ TBZ_KERNEL void tbz_k0c_link(K0bParams P) {
   }
 }
 
-// keep the candidates that are part of a chain (in place, per tile) — and that stand at least K0C_SPACING bits after
-// the candidate before them and away from every marker: an item's run table is addressed by its start position
-// (one slot per 2^RUN_SHIFT bits), so items must not start closer than that to each other; blocks of a few tokens
-// are simply decoded through by the item before them
-constexpr u64 K0C_SPACING = 128;
+// keep the candidates that are part of a chain — and that satisfy the spacing rule (tbz_k0b_space: blocks of a few
+// tokens are simply decoded through by the item before them).  "Slots of the list before it" are all pattern hits,
+// chained or not: conservative, and immutable while this kernel runs.
 TBZ_KERNEL void tbz_k0c_filter(K0bParams P) {
   const u32 lane = tbz_lane(), tile = tbz_block();
   const u32 s = k0b_find_stream(P, tile);
-  u64* slots = P.slots + (u64)tile * P.slots_per_tile;
+  const u64* slots = P.slots + (u64)tile * P.slots_per_tile;
   const u8* link = P.link + (u64)tile * P.slots_per_tile * 2;
   const u32 count = P.counts[tile];
-  // the last pattern hit of the tile before (chained or not: conservative, and no other workgroup is waited for)
-  u64 prev = P.str_off[s] * 8 + (s == 0 ? P.start_bit_off : 0u) + 1;  // (the head item starts there; + 1: never 0 = "none")
-  if (tile > P.tile_first[s]) {
-    const u32 cp = P.counts[tile - 1];
-    if (cp) prev = P.slots[(u64)(tile - 1) * P.slots_per_tile + cp - 1];
-  }
-  const u32 m_lo = P.first_marker[s], m_hi = P.first_marker[s + 1];
-  u32 nout = 0;
-  for (u32 j0 = 0; j0 < count; j0 += 64) {  // wave-uniform trip count
+  const u64 head = P.str_off[s] * 8 + (s == 0 ? P.start_bit_off : 0u);
+  u64 carry = k0x_prev_tile_last(P, s, tile);
+  u32 kept = 0;
+  for (u32 j0 = 0; j0 < P.slots_per_tile; j0 += 64) {  // wave-uniform trip count; every mask word is written
     const u32 j = j0 + lane;
-    u64 p = 0;
-    bool ok = false;
-    if (j < count) {
-      p = slots[j];
-      // kept: the candidates on which a block ends whose own start is one a block ends on — two links of a chain.
-      // (One link happens by chance: one pattern hit in a few hundred is the end of SOME skimmed block; and that a
-      // candidate's own block ends on a candidate says little: a false start inside a block falls into step with the
-      // true token sequence and ends where the block ends.)
-      ok = link[2 * j + 1] != 0;
-      if (ok && m_lo < m_hi) {  // a marker within K0C_SPACING bits on either side?
-        u32 lo = m_lo, hi = m_hi;
-        while (lo < hi) {
-          const u32 mid = (lo + hi) >> 1;
-          if (P.markers[mid] + K0C_SPACING <= p) lo = mid + 1; else hi = mid;
-        }
-        if (lo < m_hi && P.markers[lo] < p + K0C_SPACING) ok = false;
-      }
-    }
-    // the chained candidate before this one: an inclusive "latest" scan over the chunk, shifted by one lane
-    u64 last = ok ? p : 0;
-#pragma unroll
-    for (u32 d = 1; d < 64; d <<= 1) {
-      const u64 t = tbz_shfl_up64(last, d);
-      if (lane >= d && t > last) last = t;
-    }
-    const u32 b_lo = tbz_wave_shr1((u32)last), b_hi = tbz_wave_shr1((u32)(last >> 32));
-    u64 before = ((u64)b_hi << 32) | b_lo;
-    if (before < prev) before = prev;
-    const bool keep = ok && (before == 0 || p - before >= K0C_SPACING);
-    prev = tbz_shfl64(last, 63) > prev ? tbz_shfl64(last, 63) : prev;
-    const u64 km = tbz_ballot(keep);
-    tbz_sync();
-    if (keep) slots[nout + tbz_popc64(km & ((1ull << lane) - 1))] = p;
-    nout += tbz_popc64(km);
-    tbz_sync();
+    const bool have = j < count;
+    const u64 p = have ? slots[j] : 0;
+    // kept: the candidates on which a block ends whose own start is one a block ends on — two links of a chain.
+    // (One link happens by chance: one pattern hit in a few hundred is the end of SOME skimmed block; and that a
+    // candidate's own block ends on a candidate says little: a false start inside a block falls into step with the
+    // true token sequence and ends where the block ends.)
+    const bool ok = have && link[2 * j + 1] != 0;
+    const u64 km = tbz_ballot(k0x_spaced(P, s, head, p, have, ok, carry));
+    if (lane == 0) P.keep[(u64)tile * (P.slots_per_tile / 64) + j0 / 64] = km;
+    kept += tbz_popc64(km);
   }
-  if (lane == 0) P.counts[tile] = nout;
+  if (lane == 0) P.kcounts[tile] = kept;
 }
 
 // single wave: exclusive scan of the per-tile counts
@@ -922,7 +947,7 @@ TBZ_KERNEL_WG(1024, 1) void tbz_k0b_offsets(K0bParams P) {
   u32 carry = 0;
   for (u32 i = 0; i < P.n_tiles; i += K0B_SCAN_THREADS) {  // uniform over the workgroup
     const bool in = i + tid < P.n_tiles;
-    const u32 v = in ? P.counts[i + tid] : 0;
+    const u32 v = in ? P.kcounts[i + tid] : 0;
     const u32 inc = wave_incl_scan_u32(v);
     if (lane == 63) wsum[wave] = inc;
     tbz_wg_barrier();
@@ -946,8 +971,13 @@ TBZ_KERNEL_WG(1024, 1) void tbz_k0b_offsets(K0bParams P) {
 // tile slots -> the compact candidate list; workgroup 0 writes the per-stream index
 TBZ_KERNEL void tbz_k0b_compact(K0bParams P) {
   const u32 lane = tbz_lane(), t = tbz_block();
-  const u32 n = P.counts[t], o = P.offsets[t];
-  for (u32 j = lane; j < n; j += 64) P.cands[o + j] = P.slots[(u64)t * P.slots_per_tile + j];
+  const u32 n = P.counts[t];
+  u32 o = P.offsets[t];
+  for (u32 j0 = 0; j0 < n; j0 += 64) {  // the slots that passed the spacing rule (tbz_k0b_space / tbz_k0c_filter)
+    const u64 km = P.keep[(u64)t * (P.slots_per_tile / 64) + j0 / 64];
+    if ((km >> lane) & 1) P.cands[o + tbz_popc64(km & ((1ull << lane) - 1))] = P.slots[(u64)t * P.slots_per_tile + j0 + lane];
+    o += tbz_popc64(km);
+  }
   if (t == 0)
     for (u32 s = lane; s <= P.n_streams; s += 64) {
       const u32 fc = P.offsets[s < P.n_streams ? P.tile_first[s] : P.n_tiles];
@@ -3235,8 +3265,46 @@ TBZ_DEV void k2_resolve(u8* win, u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist
     const bool ready = (pend & lane_bit) && need <= hwm;
     const u64 rdy = tbz_ballot(ready);
     u64 longs = rdy & longm;
+#ifdef TBZ_EXP_K2_HOIST
+    // every class's reads go out before any class's writes: one LDS round trip per round instead of one per class (no
+    // ready match writes below the high-water mark, where all their sources lie)
+    const bool fa = ready && fastable;
+    const bool k17 = fa && len >= 17, k9 = fa && len >= 9, k4 = fa && len >= 4;
+    u64 A0 = 0, A1 = 0, B0 = 0, B1 = 0;
+    if (fa) A0 = k2_ld64(win + rs);  // (len 3: the window is K2_SLACK longer than the output, the ring checked for 32)
+    if (k9) B1 = k2_ld64(win + rs + len - 8);
+    if (k17) {
+      A1 = k2_ld64(win + rs + 8);
+      B0 = k2_ld64(win + rs + len - 16);
+    }
+    if (k17) {
+      k2_st64(win + rd, A0);
+      k2_st64(win + rd + 8, A1);
+      k2_st64(win + rd + len - 16, B0);
+      k2_st64(win + rd + len - 8, B1);
+    } else if (k9) {
+      k2_st64(win + rd, A0);
+      k2_st64(win + rd + len - 8, B1);
+    } else if (k4) {
+      k2_st32(win + rd, (u32)A0);
+      k2_st32(win + rd + len - 4, (u32)(A0 >> ((len - 4) * 8)));
+    } else if (fa) {
+      k2_st16(win + rd, (u32)A0);
+      win[rd + 2] = (u8)(A0 >> 16);
+    }
+    if (ready && !fastable && len <= K2_SHORT) {
+      u32 jj = 0;
+      for (u32 j = 0; j < len; j++) {
+        win[ring<LINEAR>(rd + j)] = win[ring<LINEAR>(rs + jj)];
+        jj = jj + 1 == dist ? 0 : jj + 1;
+      }
+    }
+    if (false) {
+      if (false) {
+#else
     if (ready && fastable) {
       if (len >= 17) {
+#endif
         // (four 8-octet accesses each way: a 16-octet struct copy took a round trip through scratch memory here)
         const u64 a0 = k2_ld64(win + rs), a1 = k2_ld64(win + rs + 8);
         const u64 b0 = k2_ld64(win + rs + len - 16), b1 = k2_ld64(win + rs + len - 8);
@@ -3910,6 +3978,7 @@ TBZ_DEV void k6_chain(const K6Params& P, u8* W0, u8* W1) {
   fetch(g, 1, o1, m1);
   if (tid == 0) fetch(g, 2, o2, m2);
   K6R gn = count > 1 ? k6_range(P, first + 1) : g;
+  bool dirty = true;  // the ring has been written since the last barrier: its initialisation, or a reload below
   for (u32 gi = 0; gi < count; gi++) {
     const K6R gnn = gi + 2 < count ? k6_range(P, first + gi + 2) : gn;
     uint4 p0{}, p1{}, p2{}, q0{}, q1{}, q2{};
@@ -3921,7 +3990,6 @@ TBZ_DEV void k6_chain(const K6Params& P, u8* W0, u8* W1) {
     if (g.hi > g.lo) {
       // 1. the window [need_lo, base): whatever of it the ring does not hold comes from memory, where it is final
       //    (octets of groups that needed no history, or octets this loop stored in an earlier step)
-      bool dirty = gi == 0;  // the ring has been written since the last barrier: its initialisation, or the reload below
       if (!SYM) {
         const u64 need_lo = g.base - g.floor > K6_W ? g.base - K6_W : g.floor;
         if (!(w_hi == g.base && w_lo <= need_lo)) {
@@ -3936,6 +4004,7 @@ TBZ_DEV void k6_chain(const K6Params& P, u8* W0, u8* W1) {
         }
       }
       if (dirty) tbz_wg_barrier();  // (workgroup-uniform; the step before ended in a barrier)
+      dirty = false;
       // 2. gather first (a destination's ring slot is the slot of the source 32 KiB before it), then store.  Threads own
       //    16-octet chunks that are aligned in address space.
       const u32 rbase = (u32)(ob + g.base);

@@ -79,7 +79,8 @@ struct RunRec {
   uint32_t mdef;  // max over its matches of (distance - octets the RUN produced before the match), 0 if none reaches
                   // before the run's first octet
 };
-constexpr uint32_t RUN_SHIFT = 5;  // (items start at least 40 bits apart — a flush marker is five octets — so their tables never share a slot)
+constexpr uint32_t RUN_SHIFT = 5;  // items start at least 2^RUN_SHIFT bits apart, so that their tables never share a slot: flush markers
+                                   // are five octets long, and candidates closer than K0C_SPACING to anything are dropped (tbz_k0b_space)
 
 struct Seg {
   uint64_t tok_index;  // the item's start_bit: base of its token region and (>> RUN_SHIFT) of its run table

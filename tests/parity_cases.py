@@ -306,6 +306,47 @@ def case_block_starts_found(eng, n_blocks=30, chunk=40_000):
         eng.free(d_out)
 
 
+def case_close_block_starts(eng):
+    """Item starts closer than one run-table slot (2^RUN_SHIFT = 32 bits): a Z_BLOCK-flushed fixed block of one or two
+    literals is 18-27 bits long, so the dynamic block behind it is a K0b candidate right after a flush marker, the
+    stream's head or another candidate.  Such candidates are dropped (tbz_k0b_space) and the item before decodes
+    through them; before that rule two items shared a run-table slot and valid streams decoded to wrong octets.
+    Every position of the marker in a 32-bit word, raw deflate and zlib, plus a mixed-flush fuzz."""
+    always = os.environ.get("TBZ_FIND") == "always"
+    big = 24_000 if always else 300 << 10   # (the default finder searches streams of at least 128 KiB with large items)
+    text = K.enwik_like(big, 7)
+
+    def stream(parts, wbits=-15):
+        c = zlib.compressobj(6, zlib.DEFLATED, wbits)
+        out = b"".join(c.compress(d) + (c.flush(fl) if fl is not None else b"") for d, fl in parts)
+        return out + c.flush()
+
+    for lits in (b"a", b"ab"):
+        s = stream([(lits, zlib.Z_BLOCK), (text, None)])
+        assert_same(eng, s, "deflate", len(lits) + len(text), what="head + %d-literal fixed block + dynamic block" % len(lits))
+    n_var = 32 if always else 3
+    for pad in range(n_var):
+        t2 = K.enwik_like(big + pad * 7, 11 + pad)
+        lits = b"a" if pad & 1 else b"ab"
+        for fmt, wb in (("deflate", -15), ("zlib", 15)):
+            s = stream([(t2, zlib.Z_SYNC_FLUSH), (lits, zlib.Z_BLOCK), (text, None)], wb)
+            assert_same(eng, s, fmt, len(t2) + len(lits) + len(text), what="marker + short fixed block + dynamic block, variant %d %s" % (pad, fmt))
+    # two candidates a few bits apart: dynamic block, one-literal fixed blocks, dynamic block
+    s = stream([(text, zlib.Z_BLOCK), (b"x", zlib.Z_BLOCK), (b"y", zlib.Z_BLOCK), (text, zlib.Z_BLOCK), (b"z", zlib.Z_PARTIAL_FLUSH), (text, None)])
+    assert_same(eng, s, "deflate", 3 * len(text) + 3, what="candidates a few bits apart")
+    rng = random.Random(0xB10C)
+    flushes = [zlib.Z_BLOCK, zlib.Z_PARTIAL_FLUSH, zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, None]
+    for k in range(10 if always else 2):
+        parts, plain = [], b""
+        for _ in range(rng.randrange(3, 9)):
+            n = rng.choice((1, 2, 3, 5, 40, big // 3, big))
+            d = K.enwik_like(n, rng.randrange(1 << 20))
+            parts.append((d, rng.choice(flushes)))
+            plain += d
+        fmt, wb = rng.choice((("deflate", -15), ("zlib", 15)))
+        assert_same(eng, stream(parts, wb), fmt, len(plain), what="mixed-flush fuzz %d" % k)
+
+
 def case_fixed_block_chains(eng):
     """Consecutive fixed-Huffman blocks are decoded THROUGH by the gang kernel (end-of-block + header consumed like a
     token; a lane that starts inside a block assumes it is not the final one): blocks of one to three tokens, blocks
@@ -970,7 +1011,7 @@ def case_pointer_contexts(eng, n=60_000):
 
 
 ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_reference_chunk_patterns, case_containers_and_levels, case_flush_streams,
-             case_noflush_streams, case_block_starts_found, case_fixed_block_chains, case_history_across_groups,
+             case_noflush_streams, case_block_starts_found, case_close_block_starts, case_fixed_block_chains, case_history_across_groups,
              case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_device_buffers,
              case_checksum_kernels, case_deep_codes, case_chunked_resume, case_gzip_members,
              case_pointer_contexts, case_container_headers, case_gzip_metadata, case_scratch_bounds, case_fuzz]
@@ -979,7 +1020,7 @@ ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_reference_chunk
 FLAVOUR_CASES = {
     # K0b on every stream, however small: candidates, chains through false ones, symbolic history everywhere
     "findalways": ["case_known_answer_vectors", "case_containers_and_levels", "case_noflush_streams",
-                   "case_fixed_block_chains", "case_overflow_and_underrun", "case_false_markers", "case_errors", "case_fuzz"],
+                   "case_close_block_starts", "case_fixed_block_chains", "case_overflow_and_underrun", "case_false_markers", "case_errors", "case_fuzz"],
     # chain walk + layout on the host even where the device could (K3)
     "hostlayout": ["case_known_answer_vectors", "case_flush_streams", "case_configs_1_3_5", "case_overflow_and_underrun",
                    "case_false_markers", "case_device_buffers", "case_errors", "case_gzip_members", "case_fuzz"],

@@ -50,12 +50,14 @@ def test_emu_case(eng, case, request):
 
 def test_emu_large_items_handed_to_wide_gangs():
     """a gang narrower than 64 lanes declines items far larger than the launch's mean (SEG_WIDE) and the host decodes
-    them with gangs of 64: forced here with gangs of 8 and a 20 Kbit threshold (TBZ_WIDE_BITS is read per call)"""
+    them with gangs of 64: forced here with gangs of 8 and a 20 Kbit threshold (every TBZ_* switch is read when the
+    context is created)"""
     T = importlib.import_module("3bz_amd")
     os.environ["TBZ_K1_MODE"] = "gang8"
+    os.environ["TBZ_WIDE_BITS"] = "20000"
     e = T.Engine(0, lib_path=os.path.join(EMU_DIR, "libtbz_emu.so"))
     os.environ.pop("TBZ_K1_MODE", None)
-    os.environ["TBZ_WIDE_BITS"] = "20000"
+    os.environ.pop("TBZ_WIDE_BITS", None)
     try:
         import zlib
         from tools import corpus as K
@@ -68,15 +70,14 @@ def test_emu_large_items_handed_to_wide_gangs():
         P.case_flush_streams(e)
         P.case_overflow_and_underrun(e)
     finally:
-        os.environ.pop("TBZ_WIDE_BITS", None)
         e.close()
 
 
 def test_emu_k0b_two_tiles_per_wave():
     """large launches of the K0b validation put two tiles on a wave (32 lanes each): forced here at a small size"""
     T = importlib.import_module("3bz_amd")
-    e = T.Engine(0, lib_path=os.path.join(EMU_DIR, "libtbz_emu.so"))
     os.environ["TBZ_K0B_PAIR"] = "1"
+    e = T.Engine(0, lib_path=os.path.join(EMU_DIR, "libtbz_emu.so"))
     try:
         P.case_block_starts_found(e, n_blocks=10)
         os.environ["TBZ_FIND"] = "always"

@@ -70,27 +70,25 @@ def test_gpu_large_items_handed_to_wide_gangs():
     stream's blocks back (SEG_WIDE) to gangs of 64 — here with a forced 20 Kbit threshold, and once with the engine's own"""
     import zlib
     T = importlib.import_module("3bz_amd")
-    e = T.Engine(0)
-    try:
-        small = [K.enwik_like(3000 + 37 * i, 100 + i) for i in range(600)]
-        big = K.enwik_like(6 << 20, 7)
-        plains = small + [big]
-        streams = [zlib.compress(p, 6) for p in plains]
-        for forced in ("20000", None):
+    small = [K.enwik_like(3000 + 37 * i, 100 + i) for i in range(600)]
+    big = K.enwik_like(6 << 20, 7)
+    plains = small + [big]
+    streams = [zlib.compress(p, 6) for p in plains]
+    for forced in ("20000", None):
+        if forced:
+            os.environ["TBZ_WIDE_BITS"] = forced  # (read when the context is created)
+        e = T.Engine(0)
+        os.environ.pop("TBZ_WIDE_BITS", None)
+        try:
+            outs = [bytearray(len(p)) for p in plains]
+            res = e.inflate_batch(streams, T.FORMATS["zlib"], outs)
+            t = e.timings()
+            for r, o, p in zip(res, outs, plains):
+                assert r.status == 0 and bytes(o) == p and r.adler32 == zlib.adler32(p)
             if forced:
-                os.environ["TBZ_WIDE_BITS"] = forced
-            try:
-                outs = [bytearray(len(p)) for p in plains]
-                res = e.inflate_batch(streams, T.FORMATS["zlib"], outs)
-                t = e.timings()
-                for r, o, p in zip(res, outs, plains):
-                    assert r.status == 0 and bytes(o) == p and r.adler32 == zlib.adler32(p)
-                if forced:
-                    assert t.huff_launches >= 2, t.huff_launches
-            finally:
-                os.environ.pop("TBZ_WIDE_BITS", None)
-    finally:
-        e.close()
+                assert t.huff_launches >= 2, t.huff_launches
+        finally:
+            e.close()
 
 
 def test_gpu_config2_128mib_properties(eng):

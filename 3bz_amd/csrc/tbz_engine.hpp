@@ -63,6 +63,7 @@ struct tbz_ctx {
     int sub_min = 0, ovl = 0; // 0: the defaults
     long wide_bits = -1;      // -1: by gang width
     int slice = 0, h_join = 0, k6_block = 0;
+    long k0c_max_block = 0;
     bool k6_two_levels = false, no_fused_adler = false, debug = false, debug2 = false;
     std::string debug_cands;
   } tun;
@@ -385,7 +386,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   // arrays are fetched only by the general (host) layout path.
   std::vector<Item> items;
   bool host_tables = false, have_find = false, have_resolve = false;
-  uint32_t n_mark = 0;
+  uint32_t n_mark = 0, n_fixed_items = 0;  // flush markers; how many of them are followed by a fixed-Huffman block
   std::vector<uint32_t> first_marker(n + 1, 0);
   if (tiles) {
     if ((r = upload(ctx, ctx->d_str_off, h_off))) return r;
@@ -395,22 +396,24 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if ((r = ensure(ctx, ctx->d_tile_offsets, (tiles + 1) * 4))) return r;
     if ((r = ensure(ctx, ctx->d_k0_slots, tiles * (size_t)K0_SLOTS * 8))) return r;
     if ((r = ensure(ctx, ctx->d_markers, tiles * (size_t)K0_SLOTS * 8 + 16))) return r;
-    if ((r = ensure(ctx, ctx->d_k0_fm, (n + 1) * 4 + 8))) return r;  // [0..1] head, [2..] first_marker
+    if ((r = ensure(ctx, ctx->d_k0_fm, (n + 1) * 4 + 12))) return r;  // [0..1] head, [2..] first_marker, [n+3] fixed-block items
     if ((r = ensure(ctx, ctx->d_items, (tiles * (size_t)K0_SLOTS + n) * sizeof(Item)))) return r;
-    if ((r = pinned(ctx, (n + 3) * 4 + sizeof(K3Global) + (n + 1) * sizeof(K3Stream)))) return r;
+    if ((r = pinned(ctx, (n + 4) * 4 + sizeof(K3Global) + (n + 1) * sizeof(K3Stream)))) return r;
     K0Params k0{(const u8*)d_in, (const u64*)ctx->d_str_off.p, (const u64*)ctx->d_str_len.p,
                 (const u32*)ctx->d_tile_first.p, (u32)n, (u32)tiles, (u32*)ctx->d_tile_counts.p,
                 (u32*)ctx->d_tile_offsets.p, (u64*)ctx->d_markers.p, (u64*)ctx->d_k0_slots.p,
-                (u32*)ctx->d_k0_fm.p + 2, (u32*)ctx->d_k0_fm.p, (Item*)ctx->d_items.p, (u32)format, 0, bit_off};
+                (u32*)ctx->d_k0_fm.p + 2, (u32*)ctx->d_k0_fm.p, (Item*)ctx->d_items.p, (u32)format, 0, bit_off,
+                (u32*)ctx->d_k0_fm.p + (n + 3)};
     const size_t max_items = tiles * (size_t)K0_SLOTS + n;
     TBZ_LAUNCH(tbz_k0_scan_tiles, tiles, ctx->stream, k0);
     TBZ_LAUNCH_WG(tbz_k0_scan_offsets, 1, K0_SCAN_THREADS, ctx->stream, k0);
     TBZ_LAUNCH(tbz_k0_compact, tiles, ctx->stream, k0);
     TBZ_LAUNCH(tbz_k0_items, (max_items + 63) / 64, ctx->stream, k0);
     uint32_t* h_head = (uint32_t*)ctx->h_pin;
-    TBZ_HIP(hipMemcpyAsync(h_head, ctx->d_k0_fm.p, (n + 3) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TBZ_HIP(hipMemcpyAsync(h_head, ctx->d_k0_fm.p, (n + 4) * 4, hipMemcpyDeviceToHost, ctx->stream));
     TBZ_HIP(hipStreamSynchronize(ctx->stream));
     n_mark = h_head[0];
+    n_fixed_items = h_head[n + 3];
     for (size_t s = 0; s <= n; s++) first_marker[s] = h_head[2 + s];
     if (h_head[1]) {  // a tile with more markers than slots: the second, emitting pass
       if ((r = ensure(ctx, ctx->d_markers, (size_t)n_mark * 8 + 16))) return r;
@@ -435,7 +438,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if ((r = ensure(ctx, ctx->d_k0_fm, (n + 1) * 4 + 8))) return r;
     std::vector<uint32_t> zero(n + 3, 0);
     if ((r = upload(ctx, ctx->d_k0_fm, zero))) return r;
-    if ((r = pinned(ctx, (n + 3) * 4 + sizeof(K3Global) + (n + 1) * sizeof(K3Stream)))) return r;
+    if ((r = pinned(ctx, (n + 4) * 4 + sizeof(K3Global) + (n + 1) * sizeof(K3Stream)))) return r;
     for (size_t s = 0; s < n; s++) {
       StreamPlan& S = sp[s];
       Item it;
@@ -494,7 +497,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
                    (const u64*)ctx->d_markers.p, (const u32*)ctx->d_k0_fm.p + 2, (u64*)ctx->d_markers2.p,
                    (u32*)ctx->d_kb_fm2.p + 2, (u32*)ctx->d_kb_fm2.p, bit_off, K0B_SLOTS,
                    ctx->tun.k0b_pair >= 0 ? (u32)(ctx->tun.k0b_pair != 0) : (tiles_b >= 8192 ? 1u : 0u), nullptr, nullptr,
-                   (u64*)ctx->d_kb_keep.p, (u32*)ctx->d_kb_kcounts.p};
+                   (u64*)ctx->d_kb_keep.p, (u32*)ctx->d_kb_kcounts.p, 0};
       TBZ_LAUNCH(tbz_k0b_scan, tiles_b, ctx->stream, kb);
       // (a launch that fits the chip at once — 64 MiB of input — is as long as its slowest wave: a tile per wave; beyond
       // that it is throughput that counts: two tiles per wave, 32 lanes each)
@@ -561,6 +564,11 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   // searched for "end-of-block + BTYPE 1" patterns; each hit's one block is skimmed and the hits that chain are kept.
   if (tiles && ctx->find_mode) {
     constexpr uint64_t FIXED_MIN_ITEM_BITS = 8ull * (256u << 10);
+    // flush-delimited items that begin with fixed-Huffman blocks (K0 counted them) are chains of such blocks, and a
+    // periodic bitstream — what fixed-Huffman territory tends to be — never lets K1's lanes fall into step: block starts
+    // are what makes such items parallel, so they are searched from 32 Kbit per item on
+    const bool fixed_territory = n_fixed_items != 0 && 2 * (uint64_t)n_fixed_items >= n_mark;
+    const uint64_t min_item_bits = fixed_territory ? 32u << 10 : FIXED_MIN_ITEM_BITS;
     std::vector<uint32_t> tfc(n + 1);
     uint64_t tiles_c = 0;
     const bool enough = (size_t)n_mark + n >= 2048;
@@ -568,7 +576,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       tfc[s] = (uint32_t)tiles_c;
       const uint64_t items_s = 1 + (first_marker[s + 1] - first_marker[s]);
       const bool search = ctx->find_mode == 2 ? sp[s].in_len >= 64
-                                              : (!enough && sp[s].in_len * 8 / items_s >= FIXED_MIN_ITEM_BITS);
+                                              : (!enough && sp[s].in_len * 8 / items_s >= min_item_bits);
       if (search) tiles_c += ((((uintptr_t)d_in + in_offs[s]) & 15) + in_lens[s] + K0C_TILE - 1) / K0C_TILE;
       if (tiles_c > 0x7fffffffu) return TBZ_E_ARG;
     }
@@ -595,7 +603,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
                    (u32*)ctx->d_kb_offsets.p, (u64*)ctx->d_kb_cands.p, (u32*)ctx->d_kb_fc.p, (u32*)ctx->d_kb_head.p,
                    d_markers_cur, d_first_marker, (u64*)ctx->d_markers3.p,
                    (u32*)ctx->d_kc_fm2.p + 2, (u32*)ctx->d_kc_fm2.p, bit_off, K0C_SLOTS, 0, (u64*)ctx->d_kc_ends.p,
-                   (u8*)ctx->d_kc_link.p, (u64*)ctx->d_kb_keep.p, (u32*)ctx->d_kb_kcounts.p};
+                   (u8*)ctx->d_kc_link.p, (u64*)ctx->d_kb_keep.p, (u32*)ctx->d_kb_kcounts.p,
+                   ctx->tun.k0c_max_block ? (u64)ctx->tun.k0c_max_block : K0C_MAX_BLOCK};
       TBZ_LAUNCH(tbz_k0c_scan, tiles_c, ctx->stream, kc);
       TBZ_LAUNCH(tbz_k0c_skim, tiles_c * (size_t)(K0C_SLOTS / 64), ctx->stream, kc);
       TBZ_LAUNCH(tbz_k0c_link, tiles_c, ctx->stream, kc);
@@ -858,7 +867,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   ctx->tim.huff_launches = 1;
   bool simple = false;
   bool fused_adler = false;  // adler32 partials come from K2 (simple path, zlib, all groups in the two-wave kernel)
-  char* pin_k3 = (char*)ctx->h_pin + (((n + 3) * 4 + 15) & ~(size_t)15);
+  char* pin_k3 = (char*)ctx->h_pin + (((n + 4) * 4 + 15) & ~(size_t)15);
   K3Global* h_glob = (K3Global*)pin_k3;
   K3Stream* h_k3s = (K3Stream*)(pin_k3 + sizeof(K3Global));
   if (try_simple) {
@@ -919,7 +928,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       const u32 n_it = (u32)n_items;
       fused_adler = format == TBZ_FORMAT_ZLIB && !ctx->k2_single && h_glob->n_big == 0 && !ctx->tun.no_fused_adler;
       K2Params k2{pool_tok(false), pool_runs(false), nullptr, nullptr, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, nullptr,
-                  (const u8*)d_in, (u8*)d_out, n_it, 0, 0, nullptr, nullptr, 0, 0, 0};
+                  (const u8*)d_in, (u8*)d_out, n_it, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0};
       if (h_glob->n_big < n_it) {
         k2.win_bytes = (u32)((h_glob->max_small + K2_SLACK + 63) & ~63ull);
         k2.cls = h_glob->n_big ? 1 : 0;
@@ -1261,7 +1270,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     S.seg_first = (uint32_t)h_segs.size();
     const size_t g0 = h_groups.size();  // this stream's first group
     // a group keeps taking in history-needing segments below this size: K6's chain grows with the cube root of their number, so
-    // groups grow with the call's output while the ring kernel still gets some 2048 of them (x 2 planes; 1024 fit the chip)
+    // groups grow with the call's output while the ring kernel still gets some 2048 of them (x 2 planes)
     const uint64_t H_JOIN_BELOW = h_join_below;
     bool after_big = false;
     for (size_t i = 0; i < v.size(); i++) {
@@ -1481,11 +1490,21 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
           jj = e;
         }
         // ---- its superblocks: runs of adjacent blocks
+        // (a superblock that begins 32 KiB or more after the one before it ended sees nothing of it: everything in
+        // between came out of groups that needed no history and is final in memory — such superblocks open a list of
+        // their own, i.e. a workgroup of their own: config 5f alternates H-groups and plain ones, and ONE workgroup
+        // walked its thousand superblocks for 2.4 ms)
         K6List ls{(u32)r2.size(), 0};
+        uint64_t prev_SE = 0;
         for (size_t q = 0, qe; q < blks.size(); q = qe) {
           qe = q + 1;
           while (three && qe < blks.size() && qe - q < bmax && blks[qe].B0 == blks[qe - 1].E) qe++;
           const uint64_t S0 = blks[q].B0, SE = blks[qe - 1].E, fl = blks[q].fl;
+          if (ls.count && S0 - prev_SE >= K6_W) {
+            l2.push_back(ls);
+            ls = K6List{(u32)r2.size(), 0};
+          }
+          prev_SE = SE;
           const uint64_t s_last_lo = SE - S0 > K6_W ? SE - K6_W : S0;
           if (qe - q > 1) {
             l1b.push_back(K6List{(u32)r1b.size(), (u32)(qe - q)});
@@ -1517,9 +1536,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       if ((r = upload(ctx, ctx->d_hg, ranges))) return r;
       if ((r = upload(ctx, ctx->d_k6s, lists))) return r;
       // ONE launch of the ring kernel: the plain large groups, and both planes of every H-group (octets -> out, pointer
-      // high octets -> the mark plane) as neighbouring workgroups, which read the same tokens (measured on the 64 MiB
-      // no-flush stream: three launches of 1 + 1304 + 1304 workgroups took 0.29 + 0.37 + 0.37 ms, four workgroups
-      // fit a CU)
+      // high octets -> the mark plane) as neighbouring workgroups, which read the same tokens
       k2.order = (const u32*)ctx->d_order.p + order_small.size();
       k2.n_groups = (u32)(order_big.size() + order_h.size());
       k2.win_bytes = 0;
@@ -1721,6 +1738,7 @@ int tbz_ctx_create(int device_id, tbz_ctx** out_ctx) {
     if (const char* m = getenv("TBZ_SLICE")) t.slice = atoi(m);
     if (const char* m = getenv("TBZ_H_JOIN")) t.h_join = atoi(m);
     if (const char* m = getenv("TBZ_K6_BLOCK")) t.k6_block = atoi(m);
+    if (const char* m = getenv("TBZ_K0C_MAX_BLOCK")) t.k0c_max_block = atol(m);
     t.k6_two_levels = getenv("TBZ_K6_TWO_LEVELS") != nullptr;
     t.no_fused_adler = getenv("TBZ_NO_FUSED_ADLER") != nullptr;
     t.debug = getenv("TBZ_DEBUG") != nullptr;

@@ -131,6 +131,8 @@ struct K0Params {
   u32 format;
   u32 second_pass;        // items: the marker array was written by the emitting pass
   u32 start_bit_off;      // stream 0's first block header sits at this bit of the stream's first octet (resumed streams)
+  u32* n_fixed;           // items: counts the marker items whose first block is a fixed-Huffman block (nullptr: not wanted) —
+                          // where most are, the streams are fixed-Huffman territory and K0c looks for block chains inside them
 };
 constexpr u32 K0_SLOTS = 32;  // markers kept per 64 KiB tile by the one-pass scan (flush every 16 KiB of text: ~8)
 
@@ -264,6 +266,7 @@ TBZ_KERNEL_WG(1024, 1) void tbz_k0_scan_offsets(K0Params P) {
   if (tid == 0) {
     u32 ov = 0;
     for (u32 k = 0; k < 16; k++) ov += wover[k];
+    if (P.n_fixed) *P.n_fixed = 0;  // (tbz_k0_items, launched after this kernel, counts into it)
     P.tile_offsets[P.n_tiles] = carry;
     P.head[0] = carry;
     P.head[1] = ov;
@@ -300,6 +303,11 @@ TBZ_KERNEL void tbz_k0_items(K0Params P) {
   it.stream = s;
   it.flags = (P.format << ITEM_FMT_SHIFT) | (k == 0 ? ITEM_HEAD : 0u);
   P.items[i] = it;
+  if (P.n_fixed) {  // BTYPE of the block at a marker (markers are octet positions; the stream has at least one octet there)
+    bool fx = false;
+    if (k != 0 && (it.start_bit >> 3) < it.end_byte) fx = ((P.in_base[it.start_bit >> 3] >> 1) & 3) == 1;
+    if (fx) tbz_atomic_add_global(P.n_fixed, 1u);  // (lanes past the list have left: no collective here)
+  }
 }
 
 TBZ_KERNEL void tbz_k0_scan_emit(K0Params P) {
@@ -381,6 +389,7 @@ struct K0bParams {
                            //   candidate a block ends too
   u64* keep;               // [n_tiles][slots_per_tile / 64]: which of a tile's `counts` slots survive the spacing rule
   u32* kcounts;            // [n_tiles]: how many (what tbz_k0b_offsets scans)
+  u64 max_block;           // K0c: bits after which a skimmed block is given up (K0C_MAX_BLOCK)
 };
 TBZ_DEV u32 k0b_find_stream(const K0bParams& P, u32 tile) {
   u32 lo = 0, hi = P.n_streams;  // tile_first[lo] <= tile < tile_first[hi]; streams without tiles are skipped over
@@ -753,7 +762,7 @@ TBZ_KERNEL void tbz_k0b_space(K0bParams P) {
 // ================================================================================================
 constexpr u32 K0C_TILE = 16u << 10;       // octets of memory per workgroup of the scan
 constexpr u32 K0C_SLOTS = 512;            // pattern hits kept per 16 KiB tile (random data: ~256)
-constexpr u64 K0C_MAX_BLOCK = 64u << 10;  // bits: a candidate whose block would be longer is not followed (the skim is one
+constexpr u64 K0C_MAX_BLOCK = 16u << 10;  // bits: a candidate whose block would be longer is not followed (the skim is one
                                           // lane per block: its longest block is the kernel's duration)
 
 TBZ_KERNEL void tbz_k0c_scan(K0bParams P) {
@@ -813,7 +822,7 @@ TBZ_KERNEL void tbz_k0c_scan(K0bParams P) {
 // one fixed-Huffman block from bit position p on, nothing written: the bit position after its end-of-block code,
 // or 0 if it is not a block (a symbol that may not be used, deflate.lisp:438,:481 / huffman-tree.lisp:172-177, or
 // no end within the stream / K0C_MAX_BLOCK)
-TBZ_DEV u64 k0c_skim_one(const u8* in_base, u64 p, u64 p_end) {
+TBZ_DEV u64 k0c_skim_one(const u8* in_base, u64 p, u64 p_end, u64 max_block) {
   K0bBits b;
   const uintptr_t a0 = (uintptr_t)in_base;
   const u32 mis = (u32)(a0 & 15);
@@ -832,7 +841,7 @@ TBZ_DEV u64 k0c_skim_one(const u8* in_base, u64 p, u64 p_end) {
   b.n -= (u32)(a & 31);
   u64 used = 3;
   k0b_take(b, 3);  // BFINAL, BTYPE = 01 (the scan saw them)
-  const u64 limit = p_end - p < K0C_MAX_BLOCK ? p_end - p : K0C_MAX_BLOCK;
+  const u64 limit = p_end - p < max_block ? p_end - p : max_block;
   for (;;) {
     if (used + 48 > limit) return 0;
     k0b_need(b, 32);
@@ -874,7 +883,7 @@ TBZ_KERNEL void tbz_k0c_skim(K0bParams P) {
   const u32 count = P.counts[tile];
   for (u32 j = part * 64 + lane; j < count; j += K0C_SLOTS) {
     const u64 p = slots[j];
-    const u64 e = k0c_skim_one(P.in_base, p, p_end);
+    const u64 e = k0c_skim_one(P.in_base, p, p_end, P.max_block);
     P.ends[(u64)tile * P.slots_per_tile + j] = 0;
     if (!e) continue;
     // the candidate at bit e, if there is one: it lives in the tile that holds the OCTET e / 8 - 1 + ... = the pattern's
@@ -1877,6 +1886,8 @@ struct GangState {  // per gang, in LDS; owned by the leader
                             //   block's.  A round is sized to what is left of the BLOCK, not of the item: the lanes
                             //   beyond an end-of-block code decode nothing that counts (measured on 256 KiB gzip members
                             //   of five blocks each: 17 of 64 lanes committed in a block's first round)
+  u32 ptry;                 // 1: the round before committed next to nothing (lanes do not fall into step: a PERIODIC bitstream —
+                            //   a run of one repeated match, zeros in a file, config 5): the next round tries kg_periodic
 };
 template <int G>
 struct KgLds {
@@ -2568,9 +2579,20 @@ TBZ_DEV void kg_lane_round(const GangTables& gt, BitReader& B, u64 start, u64 re
   bool junk = false;
   while (B.pos < rec_from) {  // run-up
     if (kg_span<false>(gt, B, rec_from, lim64, to, cap, out, mdef) == 0) break;
+    const u64 q = B.pos;  // (the reader is AT the token the fast loop would not take)
     if (kg_exact_step(gt, B, lim64, false, to, out, mdef, ro, il)) {
-      junk = true;  // ended (end-of-block / failure) during the run-up: nothing of this lane can be valid
-      break;
+      // An invalid code or an end-of-block code met during the run-up says the lane is not on the true token sequence
+      // (or that the block ends before its sub-range: nothing of it will count then).  Giving up costs the round its
+      // chain; starting over ONE BIT FURTHER ON is a new draw.  Measured on 32 KiB of random octets as fixed-Huffman
+      // literals (codes of 8 and 9 bits: config 5's 294 Kbit block): 27 % of the starts die on a seven-zero end-of-block
+      // or an unused distance code, 73 % of the lanes were in step after 512 bits; 96.5 % with the restart.  Whatever
+      // the lane does here, it counts only if it starts recording exactly where its predecessor stops.
+      if (ro.flag == RF_LIMIT || q + 1 >= rec_from) {
+        junk = true;
+        break;
+      }
+      br_seek_fill(B, q + 1);
+      il.cur_bf = -1;
     }
   }
   ro.c = ~0ull;
@@ -2604,6 +2626,41 @@ TBZ_DEV void kg_lane_round(const GangTables& gt, BitReader& B, u64 start, u64 re
 #ifdef TBZ_WAVE_TRACE
   ro.li = to.li;
 #endif
+}
+
+// ---- periodic bitstreams.  Speculative lanes fall into step because Huffman codes self-synchronise — unless the bits
+// repeat: a shifted parse of a periodic stream is itself periodic and never meets the true one (a run of ONE repeated
+// match: 258 zeros after 258 zeros, the commonest thing in sparse files; config 5 is made of it).  But there the true
+// parse is known without decoding: if the token at P is T bits long and the raw bits from P to x are T-periodic, the
+// decoder is at a token start at every P + kT up to x (same bits, same state: same token).  kg_token_bits: length of
+// the plain literal / valid match at `pos`, 0 for anything else; kg_periodic: bits[x] == bits[x + T] over [x0, x1).
+TBZ_DEV u32 kg_token_bits(const GangTables& gt, BitReader& B, u64 pos, u64 lim64) {
+  br_seek_fill(B, pos);
+  const u32 pk = br_peek(B);
+  u32 e = gt.lfast[pk & ((1u << KG_TBL) - 1)];
+  if (((e & 15) == 0) & (e != 0)) e = gt.lfast[(1u << KG_TBL) + (e >> 7) + tbz_bfe(pk, KG_TBL, (e >> 4) & 7)];
+  const u32 L = e & 15;
+  if (L == 0) return 0;
+  if (e < 0x1000u) return pos + L <= lim64 ? L : 0u;  // a literal
+  if (e < 0x8000u) return 0;                          // end of block, 286/287
+  const u32 X = tbz_bfe(e, 12, 3);
+  br_skip(B, L + X);
+  const u32 pd = br_peek(B);
+  u32 ed = gt.dfast[pd & ((1u << KG_TBD) - 1)];
+  if (((ed & 15) == 0) & (ed != 0)) ed = gt.dfast[(1u << KG_TBD) + (ed >> 7) + tbz_bfe(pd, KG_TBD, (ed >> 4) & 7)];
+  if (ed < 0x8000u) return 0;
+  const u32 T = L + X + (ed & 15) + tbz_bfe(ed, 9, 4);
+  return pos + T <= lim64 ? T : 0u;
+}
+TBZ_DEV u32 kg_bits32(const BitReader& b, u64 pos) {
+  const u64 a = pos + b.bias, i = a >> 5;
+  return tbz_alignbit(br_word_global(b, i + 1), br_word_global(b, i), (u32)(a & 31));
+}
+TBZ_DEV bool kg_periodic(const BitReader& b, u64 x0, u64 x1, u32 T, u64 lim64) {
+  if (x1 + T + 32 > lim64) return false;
+  u32 diff = 0;
+  for (u64 x = x0; x < x1; x += 32) diff |= kg_bits32(b, x) ^ kg_bits32(b, x + T);
+  return diff == 0;
 }
 
 // run-table slots an item may use once it has consumed the bitstream up to `upto`: the table is
@@ -2812,6 +2869,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     gs.nruns = gs.blk_runs = 0;
     gs.rounds = gs.valid_lanes = 0;
     gs.inl = gs.noinline = 0;
+    gs.ptry = 0;
     // (an item far larger than any block an encoder emits holds several: a first guess, replaced after the first block)
     gs.est = (have && !fixup && lim64 > it.start_bit && lim64 - it.start_bit >= KG_MULTI_BLOCK_BITS) ? KG_BLOCK_GUESS_BITS : 0u;
     if (G < 64 && have && !fixup && P.wide_bits && lim64 > it.start_bit && lim64 - it.start_bit > P.wide_bits) {
@@ -2895,8 +2953,9 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     const bool inl_on = inblk && gs.tables == 1 && !fixup && !gs.noinline;
     u16* stage = P.tok;
     u64 s_lo = 0;  // token-pool index of this lane's region
+    // sub-range per lane: what is left of the item split evenly (the next marker is where it should end)
+    u32 sub = P.sub_min;
     if (inblk) {
-      // sub-range per lane: what is left of the item split evenly (the next marker is where it should end)
       u64 remb = lim64 > Pb ? lim64 - Pb : 0;
       if (gs.est) {  // what is left of the block if it is as long as the one before it (+ 1/8), else a quarter more
         const u64 used = Pb - gs.blk_pos;
@@ -2904,17 +2963,31 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
         remb = remb < left ? remb : left;
       }
       const u64 per = (remb + G - 1) / G;
-      u32 sub = per >= KG_SUB_MAX ? KG_SUB_MAX : (u32)per;
+      sub = per >= KG_SUB_MAX ? KG_SUB_MAX : (u32)per;
       sub = (sub + 63) & ~63u;
       sub = sub < P.sub_min ? P.sub_min : sub;
-      const u64 s_g = Pb + (u64)g * sub;
-      const u64 start = g == 0 ? Pb : s_g - P.ovl;
+    }
+    const u64 s_g = Pb + (u64)g * sub;
+    // a periodic stretch (see kg_periodic): the lanes before the first one whose piece of the bitstream is not T-periodic
+    // start exactly on a token, with no run-up
+    u64 pstart = 0;
+    const bool ptry = inblk && gs.ptry != 0;
+    if (tbz_ballot(ptry) != 0) {  // wave-uniform: collectives inside
+      u32 T = 0;
+      if (ptry) T = kg_token_bits(gt, st.br, Pb, lim64);
+      const bool okp = ptry && T != 0 && (g == 0 || kg_periodic(st.br, s_g - sub, s_g + 64, T, lim64));
+      const u64 okm = (tbz_ballot(okp) >> base) & (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1));
+      const u32 f = okm == (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1)) ? (u32)G : (u32)__builtin_ctzll(~okm);
+      if (ptry && g != 0 && g < f) pstart = Pb + ((s_g - Pb + T - 1) / T) * T;
+    }
+    if (inblk) {
+      const u64 start = g == 0 ? Pb : pstart ? pstart : (s_g - Pb > P.ovl ? s_g - P.ovl : Pb);
       s_lo = s_g & ~7ull;
       stage = P.tok + s_lo;  // private region of the token pool: [s_g & ~7, (s_g + sub) & ~7), 16-octet aligned
       Inl il;
       il.on = inl_on;
       il.cur_bf = g == 0 ? (i32)gs.bfinal : -1;
-      kg_lane_round(gt, st.br, start, s_g, s_g + sub, lim64, stage, S.tokring + lane * KG_RING_STRIDE, sub - 16, ro, il);
+      kg_lane_round(gt, st.br, start, pstart ? pstart : s_g, s_g + sub, lim64, stage, S.tokring + lane * KG_RING_STRIDE, sub - 16, ro, il);
     }
     tr_b = TBZ_TR_NOW();
     tr_round += tr_b - tr_a;
@@ -3020,6 +3093,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     } else if (leader && inblk) {
       gs.rounds += 1;
       gs.valid_lanes += v;
+      gs.ptry = (v <= 2 && flag_last == RF_STOP) ? 1u : 0u;  // (inside a block, and next to nothing committed)
       if (any_hdr) {  // the chain went through block headers: the current block is the last of them
         if (bf_last >= 0) gs.bfinal = (u32)bf_last;
         gs.blk_pos = hdr_last;
@@ -3122,7 +3196,7 @@ TBZ_K1G_KERNEL(64, 3)
 #undef TBZ_K1G_KERNEL
 
 // ================================================================================================
-// K2 — LZ77 resolve: tokens -> LDS ring window -> coalesced 16-byte stores.  One wave per group.
+// K2 — LZ77 resolve: tokens -> LDS window -> coalesced 16-byte stores.  One workgroup per group.
 //
 // A batch is up to 128 token words, two per lane.  Lanes classify their words (literal / match head / payload) with
 // ballots, a DPP prefix sum gives every token its output offset, literals are stored at once, and
@@ -3132,18 +3206,47 @@ TBZ_K1G_KERNEL(64, 3)
 // makes progress; typical text needs 2-4 rounds per batch.  Long matches (> 32 octets) and stored
 // runs are copied cooperatively by all 64 lanes.  Replaces copy-history / out-byte / :copy-block
 // (deflate.lisp:233-359, :538-573).
+//
+// Two windows:
+//   LINEAR  a group whose whole output fits the LDS (up to 32 KiB: flush-delimited segments) keeps every octet at
+//           window[a0 + offset]: no wrap arithmetic, one flush at the end;
+//   RING    any other group runs through a SMALL ring: K2R_HIST octets of history plus the batches in flight (11 KB
+//           instead of the 36 KB a whole deflate window takes: ten workgroups per CU instead of four).  The ring is
+//           flushed every K2R_FLUSH octets, and a match whose distance exceeds K2R_HIST copies from the OUTPUT the
+//           group has already flushed (L2-resident: written a few microseconds earlier by the same workgroup) —
+//           always final, so such matches are resolved first, in one round of wide loads.
+// Groups that need history they do not hold (H-groups, see K6) run through the ring kernel twice — K2's copies are the
+// same whatever the octets are — once per PLANE (octets -> out, marks -> the mark plane), as neighbouring workgroups
+// that read the same tokens; a source before the group's first octet is a pointer computed on the spot (nothing to
+// initialise), and a far source comes from the plane's own flushed output.  (Both planes in one workgroup — two rings
+// moved by the same copies — was built and measured: 26.6 KB of LDS, six workgroups per CU, 8.4 ms per GiB against
+// 6.4 ms for two passes at ten per CU: profiles/README.md.)
 // ================================================================================================
 constexpr u32 ADLER_P = 65521;
-constexpr u32 K2_WIN = 36096;   // 32 KiB history + one batch span + 256 of slack; multiple of 16 (38.7 KB of LDS with the
-                                // token ring: four workgroups per CU)
-constexpr u32 K2_SPAN = 3072;   // max octets one batch may produce (cut otherwise)
-constexpr u32 K2_FLUSH = 8192;  // flush the ring to HBM every this many octets
-constexpr u32 K2_SHORT = 32;    // matches up to this length are copied by their own lane
-constexpr u32 K2_TCH = 512;     // token words per staged chunk: one 16-octet load per lane
+constexpr u32 K2_SPAN = 3072;    // (one-wave ring kernel) most octets one batch may produce
+constexpr u32 K2R_SPAN = 1536;   // ring kernels on two waves: most octets one batch may produce (two batches are in flight)
+constexpr u32 K2R_HIST = 8192;   // ring kernels: a match up to this distance copies inside the ring, a longer one from the output
+constexpr u32 K2R_FLUSH = 2048;  // ring kernels: flush every this many octets (what a far match reads must have left the ring:
+                                 // K2R_HIST >= K2R_FLUSH + K2_SPAN + 258 + 16)
+constexpr u32 K2_SHORT = 32;     // matches up to this length are copied by their own lane
+constexpr u32 K2_TCH = 512;      // token words per staged chunk: one 16-octet load per lane
 constexpr u32 K2_TOKBUF = 2 * K2_TCH;  // LDS token ring: the chunk in use + the next one (prefetched a chunk ahead)
-constexpr u32 K2_SLACK = 64;    // window octets past a group's output: alignment (16) + room for wide reads
+constexpr u32 K2_SLACK = 64;     // window octets past a group's output: alignment (16) + room for wide reads
 constexpr u32 K2_SMALL_MAX = 32768;  // groups producing at most this much (incl. K2_SLACK) take the linear path
+constexpr u32 K2_IDT = 256 + 40; // identity octets (k & 255): the low plane of a run of computed pointers, read like any source
+static_assert(K2R_HIST >= K2R_FLUSH + K2_SPAN + 258 + 16 + K2R_SPAN, "far sources must have been flushed");
 
+// window flavours: RW = 0 is the linear window; otherwise a ring of RW octets (a multiple of 16) of which HIST are
+// history
+template <u32 RW_, u32 HIST_>
+struct K2W {
+  static constexpr u32 RW = RW_, HIST = HIST_;
+  static constexpr bool LINEAR = RW_ == 0;
+};
+using K2Linear = K2W<0, 0>;
+constexpr u32 K2R_RW = K2R_HIST + K2_SPAN + 64;  // history + two spans (one-wave kernel: one span of twice the size)
+static_assert(K2R_RW % 16 == 0 && K2_SPAN == 2 * K2R_SPAN, "16-octet chunks must not straddle the ring's seam");
+using K2Ring = K2W<K2R_RW, K2R_HIST>;
 
 struct K2Params {
   const u16* tok;
@@ -3160,8 +3263,8 @@ struct K2Params {
   u32 cls;            // with order == nullptr: 1 = only groups that fit the linear window, 2 = only the others
   CkPartial* gck;     // two-wave kernel: adler32 partial of every group's output, computed from the window while it
   CkChunk* gchunks;   //   is flushed (nullptr: not wanted); gchunks[g].len = octets the group stored
-  // ---- groups decoded against a SYMBOLIC history (ring kernel only; SURVEY §8f-1, see K6 below)
-  u32 hist;           // 1: the 32 KiB before the group's first octet are not in this window: fill them with pointers
+  // ---- groups decoded against a SYMBOLIC history (ring kernels only; SURVEY §8f-1, see K6 below)
+  u32 hist;           // 1: the 32 KiB before the group's first octet are not known: a source there is a POINTER
   u32 plane;          // 0: octets (a pointer's low octet where the source is symbolic) -> out_base
                       // 1: 0 for a known octet, 0x80 | pointer >> 8 for a symbolic one    -> out_base = the mark plane
   u64 out_bias;       // octet x of the output lives at out_base[x - out_bias] (the mark plane covers the streams' extent only)
@@ -3173,17 +3276,15 @@ struct K2Params {
   u64 mark_bias;
 };
 
-// A group whose whole output fits the LDS window needs no ring: LINEAR = true keeps every octet of
-// the group at window[a0 + offset] (no wrap arithmetic, no span cut, one flush at the end) and takes
-// its window from dynamic LDS sized by the host to the largest such group, so that e.g. 16 KiB
-// segments run 8 workgroups per CU instead of 4.  LINEAR = false is the general 32 KiB-history ring.
-template <bool LINEAR>
-TBZ_DEV u32 ring(u32 x) { return LINEAR ? x : (x >= K2_WIN ? x - K2_WIN : x); }  // x < 2*K2_WIN
+template <class W>
+TBZ_DEV u32 ring(u32 x) { return W::LINEAR ? x : (x >= W::RW ? x - W::RW : x); }  // x < 2 * RW
 
 // store window[from..to) (group-relative octet offsets) to out, clipped at `clip`; `a0` = (address of
 // the group's first octet) & 15 so that window index == address (mod 16) and 16-byte chunks are aligned
-template <bool LINEAR>
+template <class W>
 TBZ_DEV void k2_flush(const u8* win, u8* outp, u64 from, u64 to, u64 clip, u32 a0) {
+  constexpr bool LINEAR = W::LINEAR;
+  constexpr u32 RW = LINEAR ? 1u : W::RW;
   if (to > clip) to = clip;
   if (from >= to) return;
   const u32 lane = tbz_lane();
@@ -3191,67 +3292,279 @@ TBZ_DEV void k2_flush(const u8* win, u8* outp, u64 from, u64 to, u64 clip, u32 a
   u64 head_end = ((from + a0 + 15) & ~15ull) - a0;  // first 16-aligned offset >= from
   if (head_end > to) head_end = to;
   u64 body_end = head_end + ((to - head_end) & ~15ull);
-  if (from + lane < head_end) outp[from + lane] = win[LINEAR ? (u32)(from + lane + a0) : (u32)((from + lane + a0) % K2_WIN)];
+  if (from + lane < head_end) outp[from + lane] = win[LINEAR ? (u32)(from + lane + a0) : (u32)((from + lane + a0) % RW)];
   u64 nchunk = (body_end - head_end) >> 4;
-  u32 r0 = LINEAR ? (u32)(head_end + a0) : (u32)((head_end + a0) % K2_WIN);
+  u32 r0 = LINEAR ? (u32)(head_end + a0) : (u32)((head_end + a0) % RW);
   for (u32 c = lane; c < (u32)nchunk; c += 64) {
-    u32 ri = ring<LINEAR>(r0 + c * 16);
+    u32 ri = LINEAR ? r0 + c * 16 : (r0 + c * 16) % RW;
     uint4 v = *(const uint4*)(win + ri);
     *(uint4*)(outp + head_end + (u64)c * 16) = v;
   }
   if (body_end + lane < to)
-    outp[body_end + lane] = win[LINEAR ? (u32)(body_end + lane + a0) : (u32)((body_end + lane + a0) % K2_WIN)];
+    outp[body_end + lane] = win[LINEAR ? (u32)(body_end + lane + a0) : (u32)((body_end + lane + a0) % RW)];
   tbz_sync();
 }
 
-// all 64 lanes copy l octets inside the window: dst index rd, source rs = rd - dd.  An overlapping
-// copy (dd < l) repeats the dd-octet pattern (the special cases of deflate.lisp:281-334).
-template <bool LINEAR>
-TBZ_DEV void k2_copy_coop(u8* win, u32 rd, u32 dd, u32 l) {
+// what a resolve step needs to know about the group beyond the window
+struct K2Src {
+  u8* win;
+  const u8* idt;    // RING: K2_IDT identity octets (the octet plane of computed pointers)
+  const u8* g0;     // RING: the group's first octet in the output plane this workgroup writes (far sources)
+  u32 hist, plane;  // RING: K2Params::hist / plane of this workgroup
+};
+
+// window index of the group-relative offset t, given that offset `gpos` sits at index `rpos` (|t - gpos| < RW)
+template <class W>
+TBZ_DEV u32 k2_index(u32 rpos, u64 gpos, i64 t) {
+  if (W::LINEAR) return (u32)((i64)rpos + (t - (i64)gpos));
+  const i64 dlt = t - (i64)gpos;
+  return dlt >= 0 ? ring<W>(rpos + (u32)dlt) : (rpos >= (u32)(-dlt) ? rpos - (u32)(-dlt) : rpos + W::RW - (u32)(-dlt));
+}
+// eight mark octets of the pointers q, q+1, ... (0x80 | index >> 8; the high part steps where the low octet wraps)
+TBZ_DEV u64 k2_mark8(u32 q) {
+  const u32 hi = 0x80u | (q >> 8), nb = 256 - (q & 255);
+  const u64 v = (u64)hi * 0x0101010101010101ull;
+  return nb < 8 ? v + (0x0101010101010101ull << (8 * nb)) : v;
+}
+
+// One match copied by all 64 lanes, whatever its source: l octets to group-relative offset d (window index rd), from
+// distance dd.  An overlapping copy (dd < l) repeats the dd-octet pattern (the special cases of deflate.lisp:281-334).
+// Sources: inside the window; RING: octets the group flushed earlier (distance beyond HIST); H-groups: before the group's
+// first octet = a computed pointer.  Everything the copy reads is final (the caller's readiness rule).
+template <class W>
+TBZ_DEV void k2_copy_coop(const K2Src& S, u32 rpos, u64 gpos, i64 d, u32 rd, u32 dd, u32 l) {
+  constexpr bool LINEAR = W::LINEAR;
   const u32 lane = tbz_lane();
-  u32 rs = LINEAR ? (rd >= dd ? rd - dd : 0) : (rd >= dd ? rd - dd : rd + K2_WIN - dd);
-  if (dd >= l) {  // disjoint
-    if (LINEAR || (rs + l <= K2_WIN && rd + l <= K2_WIN)) {  // 4-octet pieces, then the tail
-      const u32 np = l >> 2;
-      for (u32 j = lane; j < np; j += 64) k2_st32(win + rd + 4 * j, k2_ld32(win + rs + 4 * j));
-      if (lane < (l & 3)) win[rd + 4 * np + lane] = win[rs + 4 * np + lane];
+  const i64 s = d - (i64)dd;
+  u8* win = S.win;
+  const bool inwin = LINEAR || (dd <= W::HIST && (!S.hist || s >= 0));
+  if (inwin) {
+    const u32 rs = LINEAR ? (rd >= dd ? rd - dd : 0) : (rd >= dd ? rd - dd : rd + W::RW - dd);
+    if (dd >= l) {  // disjoint
+      if (LINEAR || (rs + l <= W::RW && rd + l <= W::RW)) {  // 4-octet pieces, then the tail
+        const u32 np = l >> 2;
+        for (u32 j = lane; j < np; j += 64) {
+          k2_st32(win + rd + 4 * j, k2_ld32(win + rs + 4 * j));
+        }
+        if (lane < (l & 3)) {
+          win[rd + 4 * np + lane] = win[rs + 4 * np + lane];
+        }
+        return;
+      }
+      for (u32 j = lane; j < l; j += 64) {
+        win[ring<W>(rd + j)] = win[ring<W>(rs + j)];
+      }
       return;
     }
+    float inv = 1.0f / (float)dd;
     for (u32 j = lane; j < l; j += 64) {
-      u8 b = win[ring<LINEAR>(rs + j)];
-      win[ring<LINEAR>(rd + j)] = b;
+      u32 q = (u32)((float)j * inv);
+      i32 r = (i32)j - (i32)(q * dd);
+      if (r < 0) r += (i32)dd;
+      if (r >= (i32)dd) r -= (i32)dd;
+      win[ring<W>(rd + j)] = win[ring<W>(rs + (u32)r)];
     }
     return;
   }
-  float inv = 1.0f / (float)dd;
-  for (u32 j = lane; j < l; j += 64) {
-    u32 q = (u32)((float)j * inv);
-    i32 r = (i32)j - (i32)(q * dd);
-    if (r < 0) r += (i32)dd;
-    if (r >= (i32)dd) r -= (i32)dd;
-    u8 b = win[ring<LINEAR>(rs + (u32)r)];
-    win[ring<LINEAR>(rd + j)] = b;
+  if (!LINEAR && s >= 0 && dd > W::HIST && rd + l <= W::RW) {
+    // wholly in the flushed output (a distance beyond HIST is longer than any match: disjoint): eight octets per lane,
+    // one memory round trip for the whole match
+    const u32 k = 8 * lane;
+    u64 v0 = 0, v1 = 0;
+    if (k < l) tbz_gload64x2(S.g0 + s + k, S.g0 + s + k, v0, v1);
+    if (k + 8 <= l) {
+      k2_st64(win + rd + k, v0);
+    } else if (k < l) {
+      for (u32 b = 0; b < l - k; b++) win[rd + k + b] = (u8)(v0 >> (8 * b));
+    }
+    return;
+  }
+  if (!LINEAR) {
+    // octet by octet: each source octet is a pointer (before the group), in the window, or in the flushed output
+    for (u32 j0 = 0; j0 < l; j0 += 64) {  // wave-uniform trip count (the loads below are waited for together)
+      const u32 j = j0 + lane;
+      const bool act = j < l;
+      const u32 r = dd >= l ? j : j % dd;
+      const i64 t = s + (i64)r;
+      u32 b0 = 0, b1 = 0;
+      const bool sym = t < 0;
+      const bool near = !sym && (i64)gpos - t <= (i64)W::HIST;
+      if (act && sym && S.hist) {
+        const u32 q = (u32)(32768 + t);  // (a distance is at most 32768)
+        b0 = S.plane ? (0x80u | (q >> 8)) : (q & 0xffu);
+      } else if (act && near) {
+        b0 = win[k2_index<W>(rpos, gpos, t)];
+      } else if (act && !sym) {
+        tbz_gload8x2(S.g0 + t, S.g0 + t, b0, b1);
+      }
+      if (act) win[ring<W>(rd + j)] = (u8)b0;
+    }
   }
 }
 
 // Multi-round resolution of one batch's matches (at most one per lane).  `pend` = lanes holding an
-// unresolved match; dofs = octet offset of the match inside the batch, whose first octet sits at
-// window index rpos.  A match is ready when the part of its source that it does not produce itself
+// unresolved match; dofs = octet offset of the match inside the batch, whose first octet (group-relative offset gpos)
+// sits at window index rpos.  A match is ready when the part of its source that it does not produce itself
 // lies below the high-water mark (the offset of the first unresolved match; everything below is
 // final).  The first unresolved match is always ready, so every round makes progress.
-template <bool LINEAR>
-TBZ_DEV void k2_resolve(u8* win, u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) {
+// RING: matches that copy from the flushed output or from computed pointers depend on nothing in flight: they go
+// first, all at once (one memory round trip per batch that has any).
+template <class W>
+TBZ_DEV void k2_resolve(const K2Src& S, u64 pend, u32 rpos, u64 gpos, u32 dofs, u32 len, u32 dist) {
+  constexpr bool LINEAR = W::LINEAR;
+  constexpr u32 RW = LINEAR ? 1u : W::RW;
+  u8* win = S.win;
+  const bool SYM = !LINEAR && S.hist != 0;  // (wave-uniform)
   const u32 lane = tbz_lane();
   const u64 lane_bit = 1ull << lane;
   // the part of the source a match does not write itself ends at dofs - dist + min(len, dist)
   const i32 need = (i32)dofs - (i32)dist + (i32)(len < dist ? len : dist);
-  const u32 rd = ring<LINEAR>(rpos + dofs);
-  const u32 rs = LINEAR ? (rd >= dist ? rd - dist : 0) : (rd >= dist ? rd - dist : rd + K2_WIN - dist);
+  const u32 rd = ring<W>(rpos + dofs);
+  const u32 rs = LINEAR ? (rd >= dist ? rd - dist : 0) : (rd >= dist % RW ? rd - dist % RW : rd + RW - dist % RW);
   const u64 longm = tbz_ballot(len > K2_SHORT);
-  // octet-addressed wide LDS accesses: a disjoint match is one or two reads and two (overlapping)
-  // writes that cover exactly [rd, rd + len)
-  const bool fastable = len <= K2_SHORT && dist >= len && (LINEAR || (rs + 32 <= K2_WIN && rd + 32 <= K2_WIN));
+  const i64 d = (i64)gpos + dofs, s = d - (i64)dist;
+  const bool mine = (pend & lane_bit) != 0;
   tbz_sync();
+  if (!LINEAR) {
+    // ---- round 0: sources outside the window.  far: wholly in the flushed output; symall: wholly before the group
+    const bool symall = SYM && s + (i64)len <= 0;
+#ifdef TBZ_EXP_NOFAR
+    const bool far = false;  // (timing experiment: far sources read as garbage from the ring)
+    const bool odd = mine && !symall && (SYM && s < 0);
+#else
+    const bool far = !symall && dist > W::HIST && s >= 0;
+    // straddles the group's start (or an invalid stream's distance): one by one
+    const bool odd = mine && !symall && !far && (dist > W::HIST || (SYM && s < 0));
+#endif
+    const bool wide = len <= K2_SHORT && rd + 32 <= RW;
+    const u64 farm = tbz_ballot(mine && far), symm = tbz_ballot(mine && symall), oddm = tbz_ballot(odd);
+    if (farm | symm) {
+      const bool fw = mine && wide && (far || symall);
+      u64 A0 = 0, A1 = 0, B0 = 0, B1 = 0;
+      const u64 m17 = tbz_ballot(fw && far && len >= 17);
+      if (fw && far) {
+        // sixteen octets from the match's first octet for everyone, the last sixteen for the matches longer than that
+        // (one load instruction per batch, mostly)
+        const u8* p = S.g0 + s;
+        tbz_u32x4 L0, L1;
+        tbz_gload128x2(p, p + len - 16, m17, L0, L1);
+        const u64 lo = ((u64)L0.y << 32) | L0.x, hi = ((u64)L0.w << 32) | L0.z;
+        A0 = lo;
+        if (len >= 17) {
+          A1 = hi;
+          B0 = ((u64)L1.y << 32) | L1.x;
+          B1 = ((u64)L1.w << 32) | L1.z;
+        } else if (len >= 9) {  // octets [len - 8, len) of the sixteen
+          const u32 sh = (len - 8) * 8;  // 8 .. 64
+          B1 = sh == 64 ? hi : ((lo >> sh) | (hi << (64 - sh)));
+        }
+      }
+      if (fw && symall) {  // computed pointers: the octet plane out of the identity table, the mark plane in arithmetic
+        const u32 q = (u32)(32768 + s);
+        if (S.plane) {
+          A0 = k2_mark8(q);
+          if (len >= 9) B1 = k2_mark8(q + len - 8);
+          if (len >= 17) {
+            A1 = k2_mark8(q + 8);
+            B0 = k2_mark8(q + len - 16);
+          }
+        } else {
+          A0 = k2_ld64(S.idt + (q & 255));
+          if (len >= 9) B1 = k2_ld64(S.idt + ((q + len - 8) & 255));
+          if (len >= 17) {
+            A1 = k2_ld64(S.idt + ((q + 8) & 255));
+            B0 = k2_ld64(S.idt + ((q + len - 16) & 255));
+          }
+        }
+      }
+      if (fw) {
+        if (len >= 17) {
+          k2_st64(win + rd, A0);
+          k2_st64(win + rd + 8, A1);
+          k2_st64(win + rd + len - 16, B0);
+          k2_st64(win + rd + len - 8, B1);
+        } else if (len >= 9) {
+          k2_st64(win + rd, A0);
+          k2_st64(win + rd + len - 8, B1);
+        } else if (len >= 4) {
+          k2_st32(win + rd, (u32)A0);
+          k2_st32(win + rd + len - 4, (u32)(A0 >> ((len - 4) * 8)));
+        } else {
+          k2_st16(win + rd, (u32)A0);
+          win[rd + 2] = (u8)(A0 >> 16);
+        }
+      }
+      // the rest of them (long, or at the ring's seam): one at a time, all lanes
+      u64 rest = (farm | symm) & ~tbz_ballot(fw);
+      while (rest) {
+        const u32 i = (u32)tbz_ffs64(rest) - 1;
+        rest &= rest - 1;
+        const u32 di = tbz_readlane(dofs, i);
+        k2_copy_coop<W>(S, rpos, gpos, (i64)gpos + di, tbz_readlane(rd, i), tbz_readlane(dist, i), tbz_readlane(len, i));
+      }
+      pend &= ~(farm | symm);
+      tbz_sync();
+    }
+    // ---- sources that straddle the group's first octet wait their turn like any other (their part inside the group
+    // must be final), then take the octet-by-octet path
+    const u64 oddq = oddm & pend;
+    // octet-addressed wide LDS accesses: a disjoint match is one or two reads and two (overlapping)
+    // writes that cover exactly [rd, rd + len)
+    const bool fastable = len <= K2_SHORT && dist >= len && rs + 32 <= RW && rd + 32 <= RW;
+    while (pend) {
+      const u32 first = (u32)tbz_ffs64(pend) - 1;
+      if ((oddq >> first) & 1) {  // the first unresolved match is an odd one: everything before it is final
+        k2_copy_coop<W>(S, rpos, gpos, (i64)gpos + tbz_readlane(dofs, first), tbz_readlane(rd, first), tbz_readlane(dist, first),
+                        tbz_readlane(len, first));
+        pend &= pend - 1;
+        tbz_sync();
+        continue;
+      }
+      const i32 hwm = (i32)tbz_readlane(dofs, first);
+      const bool ready = (pend & lane_bit) && need <= hwm && !((oddq >> lane) & 1);
+      const u64 rdy = tbz_ballot(ready);
+      u64 longs = rdy & longm;
+      if (ready && fastable) {
+        if (len >= 17) {
+          const u64 a0 = k2_ld64(win + rs), a1 = k2_ld64(win + rs + 8);
+          const u64 b0 = k2_ld64(win + rs + len - 16), b1 = k2_ld64(win + rs + len - 8);
+          k2_st64(win + rd, a0);
+          k2_st64(win + rd + 8, a1);
+          k2_st64(win + rd + len - 16, b0);
+          k2_st64(win + rd + len - 8, b1);
+        } else if (len >= 9) {
+          const u64 a = k2_ld64(win + rs), b = k2_ld64(win + rs + len - 8);
+          k2_st64(win + rd, a);
+          k2_st64(win + rd + len - 8, b);
+        } else if (len >= 4) {
+          const u64 a = k2_ld64(win + rs);
+          k2_st32(win + rd, (u32)a);
+          k2_st32(win + rd + len - 4, (u32)(a >> ((len - 4) * 8)));
+        } else {
+          const u32 a = k2_ld32(win + rs);
+          k2_st16(win + rd, a);
+          win[rd + 2] = (u8)(a >> 16);
+        }
+      } else if (ready && len <= K2_SHORT) {
+        // overlapping (the match repeats its dist-octet pattern, all of it final already) or at the ring's seam
+        u32 jj = 0;
+        for (u32 j = 0; j < len; j++) {
+          win[ring<W>(rd + j)] = win[ring<W>(rs + jj)];
+          jj = jj + 1 == dist ? 0 : jj + 1;
+        }
+      }
+      while (longs) {
+        const u32 i = (u32)tbz_ffs64(longs) - 1;
+        longs &= longs - 1;
+        k2_copy_coop<W>(S, rpos, gpos, (i64)gpos + tbz_readlane(dofs, i), tbz_readlane(rd, i), tbz_readlane(dist, i), tbz_readlane(len, i));
+      }
+      pend &= ~rdy;
+      tbz_sync();
+    }
+    return;
+  }
+  // ---- LINEAR
+  const bool fastable = len <= K2_SHORT && dist >= len;
 #ifdef TBZ_WAVE_TRACE
   u32 tr_rounds = 0;
   const u32 tr_matches = (u32)tbz_popc64(pend);
@@ -3265,46 +3578,8 @@ TBZ_DEV void k2_resolve(u8* win, u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist
     const bool ready = (pend & lane_bit) && need <= hwm;
     const u64 rdy = tbz_ballot(ready);
     u64 longs = rdy & longm;
-#ifdef TBZ_EXP_K2_HOIST
-    // every class's reads go out before any class's writes: one LDS round trip per round instead of one per class (no
-    // ready match writes below the high-water mark, where all their sources lie)
-    const bool fa = ready && fastable;
-    const bool k17 = fa && len >= 17, k9 = fa && len >= 9, k4 = fa && len >= 4;
-    u64 A0 = 0, A1 = 0, B0 = 0, B1 = 0;
-    if (fa) A0 = k2_ld64(win + rs);  // (len 3: the window is K2_SLACK longer than the output, the ring checked for 32)
-    if (k9) B1 = k2_ld64(win + rs + len - 8);
-    if (k17) {
-      A1 = k2_ld64(win + rs + 8);
-      B0 = k2_ld64(win + rs + len - 16);
-    }
-    if (k17) {
-      k2_st64(win + rd, A0);
-      k2_st64(win + rd + 8, A1);
-      k2_st64(win + rd + len - 16, B0);
-      k2_st64(win + rd + len - 8, B1);
-    } else if (k9) {
-      k2_st64(win + rd, A0);
-      k2_st64(win + rd + len - 8, B1);
-    } else if (k4) {
-      k2_st32(win + rd, (u32)A0);
-      k2_st32(win + rd + len - 4, (u32)(A0 >> ((len - 4) * 8)));
-    } else if (fa) {
-      k2_st16(win + rd, (u32)A0);
-      win[rd + 2] = (u8)(A0 >> 16);
-    }
-    if (ready && !fastable && len <= K2_SHORT) {
-      u32 jj = 0;
-      for (u32 j = 0; j < len; j++) {
-        win[ring<LINEAR>(rd + j)] = win[ring<LINEAR>(rs + jj)];
-        jj = jj + 1 == dist ? 0 : jj + 1;
-      }
-    }
-    if (false) {
-      if (false) {
-#else
     if (ready && fastable) {
       if (len >= 17) {
-#endif
         // (four 8-octet accesses each way: a 16-octet struct copy took a round trip through scratch memory here)
         const u64 a0 = k2_ld64(win + rs), a1 = k2_ld64(win + rs + 8);
         const u64 b0 = k2_ld64(win + rs + len - 16), b1 = k2_ld64(win + rs + len - 8);
@@ -3326,17 +3601,17 @@ TBZ_DEV void k2_resolve(u8* win, u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist
         win[rd + 2] = (u8)(a >> 16);
       }
     } else if (ready && len <= K2_SHORT) {
-      // overlapping (the match repeats its dist-octet pattern, all of it final already) or at the ring's seam
+      // overlapping (the match repeats its dist-octet pattern, all of it final already)
       u32 jj = 0;
       for (u32 j = 0; j < len; j++) {
-        win[ring<LINEAR>(rd + j)] = win[ring<LINEAR>(rs + jj)];
+        win[rd + j] = win[rs + jj];
         jj = jj + 1 == dist ? 0 : jj + 1;
       }
     }
     while (longs) {
       const u32 i = (u32)tbz_ffs64(longs) - 1;
       longs &= longs - 1;
-      k2_copy_coop<LINEAR>(win, tbz_readlane(rd, i), tbz_readlane(dist, i), tbz_readlane(len, i));
+      k2_copy_coop<W>(S, rpos, gpos, 0, tbz_readlane(rd, i), tbz_readlane(dist, i), tbz_readlane(len, i));
     }
     pend &= ~rdy;
     tbz_sync();
@@ -3365,37 +3640,18 @@ TBZ_DEV bool k2_pick_group(const K2Params& P, u32& gi, Group& g, Seg& sg_guess, 
   return true;
 }
 
-// ring launches: which group, and which plane of it, this workgroup decodes (Q = the launch parameters as k2_body wants
-// them for that group)
-TBZ_DEV bool k2_ring_select(const K2Params& P, K2Params& Q, u32& gi, Group& g, Seg& sg_guess) {
-  Q = P;
-  if (!P.mixed) return k2_pick_group(P, gi, g, sg_guess);
-  const u32 b = tbz_block();
-  u32 at = b;
-  if (b >= P.n_plain) {
-    const u32 h = b - P.n_plain;
-    at = P.n_plain + (h >> 1);
-    Q.hist = 1;
-    Q.plane = h & 1;
-    if (h & 1) {
-      Q.out_base = P.mark_base;
-      Q.out_bias = P.mark_bias;
-    }
-  }
-  return k2_pick_group(P, gi, g, sg_guess, at);
-}
-
 // The front end of a group: token fetch, classification, offsets, literals; every batch's matches go to
-// `emit(pend, rpos, dofs, len, dist)` — the resolve step itself in the one-wave kernels, the hand-off to the
-// resolving wave in the two-wave kernel — and `finish()` runs before the final flush.
+// `emit(pend, rpos, gpos, dofs, len, dist)` — the resolve step itself in the one-wave kernels, the hand-off to the
+// resolving wave in the two-wave kernels — and `finish()` runs before the final flush.
 // SPAN: most octets one batch may produce in the ring kernels.  DUAL (ring, two waves): `emit` hands the batch to the
 // resolving wave and returns while it is IN FLIGHT — so the ring is flushed only up to that batch's first octet, a
 // stored run (which this wave copies into the ring itself) waits for the resolving wave to drain, and the ring must
-// hold 32 KiB of history plus TWO spans.
-template <bool LINEAR, u32 SPAN, bool DUAL, class Emit, class Finish>
-TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_guess, u8* win, u16* tks, u32* rcache,
-                     Emit&& emit, Finish&& finish) {
-  static_assert(LINEAR || K2_WIN >= 32768 + (DUAL ? 2 : 1) * SPAN + 64, "ring: history + the spans in flight");
+// hold its history plus TWO spans.
+template <class W, u32 SPAN, bool DUAL, class Emit, class Finish>
+TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_guess, u8* win, u16* tks,
+                     u32* rcache, Emit&& emit, Finish&& finish) {
+  constexpr bool LINEAR = W::LINEAR;
+  static_assert(LINEAR || W::RW >= W::HIST + (DUAL ? 2 : 1) * SPAN + 64, "ring: history + the spans in flight");
   const u32 lane = tbz_lane();
   const u64 lane_bit = 1ull << lane;
   u8* outp = P.out_base + (g.out_abs - P.out_bias);
@@ -3403,25 +3659,22 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
   const u64 clip = g.out_end > g.out_abs ? g.out_end - g.out_abs : 0;
   u64 pos = 0, flushed = 0;
   u64 bstart = 0;  // DUAL: first octet of the batch in flight (everything before it is resolved)
-  u32 rpos = a0;  // window index of `pos`
-  const u32 litmask = (!LINEAR && P.plane) ? 0u : 0xffu;  // plane 1: every octet this group produces itself is "known" = 0
-  if (!LINEAR && P.hist) {
-    // Symbolic history: octet j before the group's first one (j = 1..32768) is not known here — the group before
-    // is being decoded by another workgroup right now.  It is represented by a 15-bit POINTER i = 32768 - j into
-    // "the 32 KiB before this group", low octet in plane 0, 0x80 | high bits in plane 1; the copies below move
-    // pointers exactly as they move octets (LZ77 resolution does not look at the data), and K6 replaces them.
-    for (u32 i0 = lane * 4; i0 < 32768; i0 += 256) {
-      const u32 r = (a0 + (K2_WIN - 32768) + i0) % K2_WIN;
-      const u32 v = P.plane ? (0x80u | (i0 >> 8)) * 0x01010101u
-                            : ((i0 & 0xff) | (((i0 + 1) & 0xff) << 8) | (((i0 + 2) & 0xff) << 16) | (((i0 + 3) & 0xff) << 24));
-      if (r + 4 <= K2_WIN) {
-        k2_st32(win + r, v);
-      } else {
-        for (u32 q = 0; q < 4; q++) win[(r + q) % K2_WIN] = (u8)(v >> (8 * q));
-      }
+  u32 rpos = a0;   // window index of `pos`
+  const u32 litmask = (!LINEAR && P.plane) ? 0u : 0xffu;  // mark plane: every octet this group produces itself is "known" = 0
+  bool stores_in_flight = false;  // RING: a flush has been issued since the last wait (a far match reads what it stored)
+  auto flush_upto = [&](u64 upto) {
+    if (upto <= flushed) return;
+    k2_flush<W>(win, outp, flushed, upto, clip, a0);
+    flushed = upto;
+    stores_in_flight = true;
+  };
+  auto emit_batch = [&](u64 pend, u32 dofs, u32 len, u32 dist) {
+    if (!LINEAR && stores_in_flight) {  // (wave-uniform) what was flushed must have arrived before a resolve step reads it back
+      tbz_vm_drain();
+      stores_in_flight = false;
     }
-    tbz_sync();
-  }
+    emit(pend, rpos, pos, dofs, len, dist);
+  };
 
   for (u32 s = 0; s < g.seg_count && pos < clip; s++) {
     const Seg sg = g.seg_first + s == gi ? sg_guess : P.segs[g.seg_first + s];
@@ -3541,16 +3794,16 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
         const u32 total = tbz_readlane(incl, last);
         const bool act = lane <= last;
         const u32 oa = incl - sum, ob = oa + len_a;
-        if (la && act) win[ring<LINEAR>(rpos + oa)] = (u8)(a & litmask);
-        if (lb && act) win[ring<LINEAR>(rpos + ob)] = (u8)(b & litmask);
+        if (la && act) win[ring<W>(rpos + oa)] = (u8)(a & litmask);
+        if (lb && act) win[ring<W>(rpos + ob)] = (u8)(b & litmask);
         const u32 na = tbz_wave_shl1(a);  // next lane's word a: the distance word of a head in b
         const bool hasm = (hav || hbv) && act;
         const u32 len = hav ? len_a : len_b;
         const u32 dist = ((hav ? b : na) & 0x7fffu) + 1;
         bstart = pos;
-        emit(tbz_ballot(hasm), rpos, hav ? oa : ob, hasm ? len : 0u, dist);
+        emit_batch(tbz_ballot(hasm), hav ? oa : ob, hasm ? len : 0u, dist);
         pos += total;
-        rpos = ring<LINEAR>(rpos + total);
+        rpos = ring<W>(rpos + total);
         p += m;
       } else {
         // ---- a stored run within reach: one word per lane, up to the run (or the run itself)
@@ -3567,26 +3820,21 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
           u64 cnt = (w0 & 0x3fff) | ((u64)(w1 & 3) << 14);
           u64 src = ((u64)(w1 >> 2) & 0x1fff) | ((u64)w2 << 13) | ((u64)w3 << 28);
           if (DUAL) {  // an empty batch: when its hand-over returns, the batch before it is resolved
-            emit(0ull, rpos, 0u, 0u, 1u);
+            emit_batch(0ull, 0u, 0u, 1u);
             bstart = pos;
           }
           while (cnt) {
-            u32 c = cnt < SPAN ? (u32)cnt : SPAN;  // (the ring holds 32 KiB of history + one span)
+            u32 c = cnt < SPAN ? (u32)cnt : SPAN;  // (the ring holds its history + one span)
             tbz_sync();
-            for (u32 j = lane; j < c; j += 64) win[ring<LINEAR>(rpos + j)] = (u8)(P.in_base[src + j] & litmask);
+            for (u32 j = lane; j < c; j += 64) win[ring<W>(rpos + j)] = (u8)(P.in_base[src + j] & litmask);
             tbz_sync();
             pos += c;
-            rpos = ring<LINEAR>(rpos + c);
+            rpos = ring<W>(rpos + c);
             src += c;
             cnt -= c;
             bstart = pos;
-            if (!LINEAR && (pos - flushed >= K2_FLUSH || pos >= clip)) {
-              u64 upto = pos >= clip ? pos : ((pos + a0) & ~15ull) - a0;
-              if (upto > flushed) {
-                k2_flush<LINEAR>(win, outp, flushed, upto, clip, a0);
-                flushed = upto;
-              }
-            }
+            if (!LINEAR && (pos - flushed >= K2R_FLUSH || pos >= clip))
+              flush_upto(pos >= clip ? pos : ((pos + a0) & ~15ull) - a0);
             if (pos >= clip) break;
           }
           p += 4;
@@ -3610,29 +3858,51 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
         const u64 act = m == 64 ? ~0ull : ((1ull << m) - 1);
         u32 dofs = incl - len;  // octet offset of this token inside the batch
         u32 dist = (tbz_wave_shl1(w) & 0x7fffu) + 1;
-        if (islit && (act & lane_bit)) win[ring<LINEAR>(rpos + dofs)] = (u8)(w & litmask);
+        if (islit && (act & lane_bit)) win[ring<W>(rpos + dofs)] = (u8)(w & litmask);
         bstart = pos;
-        emit(mb & act, rpos, dofs, len, dist);
+        emit_batch(mb & act, dofs, len, dist);
         pos += total;
-        rpos = ring<LINEAR>(rpos + total);
+        rpos = ring<W>(rpos + total);
         p += m;
       }
-      if (!LINEAR && pos - flushed >= K2_FLUSH) {
+      if (!LINEAR && pos - flushed >= K2R_FLUSH) {
         const u64 lim = DUAL ? bstart : pos;
-        u64 upto = ((lim + a0) & ~15ull) - a0;  // keep the unaligned tail in the ring
-        if (upto > flushed) {
-          k2_flush<LINEAR>(win, outp, flushed, upto, clip, a0);
-          flushed = upto;
-        }
+        flush_upto(((lim + a0) & ~15ull) - a0);  // keep the unaligned tail in the ring
       }
     }
   }
   finish(pos < clip ? pos : clip, a0);
-  k2_flush<LINEAR>(win, outp, flushed, pos, clip, a0);
+  k2_flush<W>(win, outp, flushed, pos, clip, a0);
 }
 
+// ring launches: which group, and which plane of it, this workgroup decodes (Q = the launch parameters as k2_body wants
+// them for that group)
+TBZ_DEV bool k2_ring_select(const K2Params& P, K2Params& Q, u32& gi, Group& g, Seg& sg_guess) {
+  Q = P;
+  if (!P.mixed) return k2_pick_group(P, gi, g, sg_guess);
+  const u32 b = tbz_block();
+  u32 at = b;
+  if (b >= P.n_plain) {
+    const u32 h = b - P.n_plain;
+    at = P.n_plain + (h >> 1);
+    Q.hist = 1;
+    Q.plane = h & 1;
+    if (h & 1) {
+      Q.out_base = P.mark_base;
+      Q.out_bias = P.mark_bias;
+    }
+  }
+  return k2_pick_group(P, gi, g, sg_guess, at);
+}
+// identity octets (the octet plane of computed pointers)
+TBZ_DEV void k2_idt_init(u8* idt, u32 nthreads) {
+  for (u32 k = tbz_lane() + 64 * tbz_wave(); k < K2_IDT; k += nthreads) idt[k] = (u8)k;
+}
+
+// ---- the ring kernel on ONE wave (TBZ_K2_MODE=single): front end and resolve in turn
 TBZ_KERNEL void tbz_k2_lz77(K2Params P) {
-  TBZ_SHARED __attribute__((aligned(16))) u8 win[K2_WIN];
+  TBZ_SHARED __attribute__((aligned(16))) u8 win[K2R_RW];
+  TBZ_SHARED __attribute__((aligned(16))) u8 idt[K2_IDT];
   TBZ_SHARED __attribute__((aligned(16))) u16 tks[K2_TOKBUF];
   TBZ_SHARED u32 rcache[128];
   u32 gi;
@@ -3640,9 +3910,12 @@ TBZ_KERNEL void tbz_k2_lz77(K2Params P) {
   Seg sg;
   K2Params Q;
   if (!k2_ring_select(P, Q, gi, g, sg)) return;
-  k2_body<false, K2_SPAN, false>(
+  k2_idt_init(idt, 64);
+  tbz_sync();
+  K2Src S{win, idt, Q.out_base + (g.out_abs - Q.out_bias), Q.hist, Q.plane};
+  k2_body<K2Ring, K2_SPAN, false>(
       Q, gi, g, sg, win, tks, rcache,
-      [&](u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) { k2_resolve<false>(win, pend, rpos, dofs, len, dist); },
+      [&](u64 pend, u32 rpos, u64 gpos, u32 dofs, u32 len, u32 dist) { k2_resolve<K2Ring>(S, pend, rpos, gpos, dofs, len, dist); },
       [](u64, u32) {});
 }
 
@@ -3654,9 +3927,10 @@ TBZ_KERNEL void tbz_k2_lz77_small(K2Params P) {
   Seg sg;
   if (!k2_pick_group(P, gi, g, sg)) return;
   u8* win = dyn;
-  k2_body<true, K2_SPAN, false>(
+  K2Src S{win, nullptr, nullptr, 0, 0};
+  k2_body<K2Linear, K2_SPAN, false>(
       P, gi, g, sg, win, (u16*)(dyn + P.win_bytes), (u32*)(dyn + P.win_bytes + 2 * K2_TOKBUF),
-      [&](u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) { k2_resolve<true>(win, pend, rpos, dofs, len, dist); },
+      [&](u64 pend, u32 rpos, u64 gpos, u32 dofs, u32 len, u32 dist) { k2_resolve<K2Linear>(S, pend, rpos, gpos, dofs, len, dist); },
       [](u64, u32) {});
 }
 
@@ -3669,6 +3943,7 @@ TBZ_KERNEL void tbz_k2_lz77_small(K2Params P) {
 struct K2Hand {
   u64 desc[64];  // per lane: dofs | len << 16 | dist << 32
   u64 pend;      // lanes holding a match
+  u64 gpos;      // group-relative offset of the batch's first octet
   u32 rpos;      // window index of the batch's first octet
   u32 end;       // 1: no batch — the group is done
 };
@@ -3685,14 +3960,15 @@ TBZ_KERNEL_WG(128, 2) void tbz_k2_lz77_dual(K2Params P) {
   [[maybe_unused]] u64 tr_wait = 0, tr_x = 0;
   if (tbz_wave() == 0) {
     u32 k = 0;
-    k2_body<true, K2_SPAN, false>(
+    k2_body<K2Linear, K2_SPAN, false>(
         P, gi, g, sg, win, (u16*)(dyn + P.win_bytes), (u32*)(dyn + P.win_bytes + 2 * K2_TOKBUF),
-        [&](u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) {
+        [&](u64 pend, u32 rpos, u64 gpos, u32 dofs, u32 len, u32 dist) {
           K2Hand& h = H[k & 1];
           h.desc[lane] = (u64)dofs | ((u64)len << 16) | ((u64)dist << 32);
           if (lane == 0) {
             h.pend = pend;
             h.rpos = rpos;
+            h.gpos = gpos;
             h.end = 0;
           }
           tr_x = TBZ_TR_NOW();
@@ -3723,11 +3999,12 @@ TBZ_KERNEL_WG(128, 2) void tbz_k2_lz77_dual(K2Params P) {
     if (lane == 0 && tbz_block() < 8192) tbz_dbg[tbz_block() * 8 + 1] = TBZ_TR_NOW();
 #endif
   } else {
+    K2Src S{win, nullptr, nullptr, 0, 0};
     for (u32 k = 0;; k++) {
       if (k > 0) {
         const K2Hand& h = H[(k - 1) & 1];
         const u64 d = h.desc[lane];
-        k2_resolve<true>(win, h.pend, h.rpos, (u32)(d & 0xffffu), (u32)((d >> 16) & 0xffffu), (u32)(d >> 32));
+        k2_resolve<K2Linear>(S, h.pend, h.rpos, h.gpos, (u32)(d & 0xffffu), (u32)((d >> 16) & 0xffffu), (u32)(d >> 32));
       }
       tr_x = TBZ_TR_NOW();
       tbz_wg_barrier();
@@ -3788,12 +4065,12 @@ TBZ_KERNEL_WG(128, 2) void tbz_k2_lz77_dual(K2Params P) {
 }
 
 // The ring kernel on TWO wavefronts (front end || resolve, as tbz_k2_lz77_dual does for the linear window): groups
-// larger than a linear window, and H-groups.  The same 36 KB ring serves: a batch produces at most K2_SPAN / 2 octets
-// here, so that the batch in flight and the one the front end is writing both fit beside 32 KiB of history
-// (k2_body, DUAL).  Four workgroups per CU, eight waves.
-constexpr u32 K2_SPAN_DUAL = K2_SPAN / 2;
-TBZ_KERNEL_WG(128, 1) void tbz_k2_lz77_ring2(K2Params P) {
-  TBZ_SHARED __attribute__((aligned(16))) u8 win[K2_WIN];
+// larger than a linear window, and H-groups (one workgroup per plane).  A batch produces at most K2R_SPAN octets, so
+// that the batch in flight and the one the front end is writing both fit beside the history.  15.3 KB of LDS: ten
+// workgroups per CU.
+TBZ_KERNEL_WG(128, 5) void tbz_k2_lz77_ring2(K2Params P) {
+  TBZ_SHARED __attribute__((aligned(16))) u8 win[K2R_RW];
+  TBZ_SHARED __attribute__((aligned(16))) u8 idt[K2_IDT];
   TBZ_SHARED __attribute__((aligned(16))) u16 tks[K2_TOKBUF];
   TBZ_SHARED u32 rcache[128];
   TBZ_SHARED K2Hand H[2];
@@ -3803,16 +4080,19 @@ TBZ_KERNEL_WG(128, 1) void tbz_k2_lz77_ring2(K2Params P) {
   K2Params Q;
   if (!k2_ring_select(P, Q, gi, g, sg)) return;  // both waves take the same decision
   const u32 lane = tbz_lane();
+  k2_idt_init(idt, 128);
+  tbz_wg_barrier();
   if (tbz_wave() == 0) {
     u32 k = 0;
-    k2_body<false, K2_SPAN_DUAL, true>(
+    k2_body<K2Ring, K2R_SPAN, true>(
         Q, gi, g, sg, win, tks, rcache,
-        [&](u64 pend, u32 rpos, u32 dofs, u32 len, u32 dist) {
+        [&](u64 pend, u32 rpos, u64 gpos, u32 dofs, u32 len, u32 dist) {
           K2Hand& h = H[k & 1];
           h.desc[lane] = (u64)dofs | ((u64)len << 16) | ((u64)dist << 32);
           if (lane == 0) {
             h.pend = pend;
             h.rpos = rpos;
+            h.gpos = gpos;
             h.end = 0;
           }
           tbz_wg_barrier();
@@ -3823,11 +4103,12 @@ TBZ_KERNEL_WG(128, 1) void tbz_k2_lz77_ring2(K2Params P) {
           tbz_wg_barrier();  // the last batch is resolved when this returns: the final flush may read the window
         });
   } else {
+    K2Src S{win, idt, Q.out_base + (g.out_abs - Q.out_bias), Q.hist, Q.plane};
     for (u32 k = 0;; k++) {
       if (k > 0) {
         const K2Hand& h = H[(k - 1) & 1];
         const u64 d = h.desc[lane];
-        k2_resolve<false>(win, h.pend, h.rpos, (u32)(d & 0xffffu), (u32)((d >> 16) & 0xffffu), (u32)(d >> 32));
+        k2_resolve<K2Ring>(S, h.pend, h.rpos, h.gpos, (u32)(d & 0xffffu), (u32)((d >> 16) & 0xffffu), (u32)(d >> 32));
       }
       tbz_wg_barrier();
       if (H[k & 1].end) break;

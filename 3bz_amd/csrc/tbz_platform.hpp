@@ -81,6 +81,7 @@ TBZ_DEV u32 tbz_ffs64(u64 v) { return (u32)__ffsll((long long)v); }  // 1-based,
 TBZ_DEV u32 tbz_brev32(u32 v) { return __brev(v); }
 TBZ_DEV u32 tbz_clz32(u32 v) { return (u32)__clz((int)v); }
 TBZ_DEV u32 tbz_atomic_add_lds(u32* p, u32 v) { return atomicAdd(p, v); }
+TBZ_DEV u32 tbz_atomic_add_global(u32* p, u32 v) { return atomicAdd(p, v); }
 
 // four sums of absolute differences of the 4 octets `ref` against s0's octets [j, j+4), j = 0..3, as
 // 4 x u16 (v_qsad_pk_u16_u8): a zero field is an exact 4-octet match at offset j
@@ -116,6 +117,51 @@ TBZ_DEV u32 tbz_wave_incl_scan_u32(u32 x) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
   return (u32)v;
 }
+
+// ---- coherent read-back of octets this workgroup stored earlier (the ring kernels' far matches).  `sc1` loads are served by
+// L2, past the CU's vector L1, which is never refreshed by stores (MI355X_MICROARCH.md, inter-workgroup visibility: a line
+// read once while partly written would be served stale).  The loads and their wait are ONE asm statement: the compiler
+// knows nothing of a load issued from inline asm, and a register copy it placed between the load and a separate wait
+// would copy the register's old contents.  Addresses need no alignment (gfx950 global accesses are octet-addressed).
+typedef u32 tbz_u32x4 __attribute__((ext_vector_type(4)));
+// 16 octets at p0 for every active lane, 16 more at p1 for the lanes of mask m1 (the others' `b` is left undefined)
+TBZ_DEV void tbz_gload128x2(const u8* p0, const u8* p1, u64 m1, tbz_u32x4& a, tbz_u32x4& b) {
+  u64 keep;
+  asm volatile(
+      "global_load_dwordx4 %0, %3, off sc1\n\ts_mov_b64 %2, exec\n\ts_and_b64 exec, exec, %5\n\t"
+      "global_load_dwordx4 %1, %4, off sc1\n\ts_mov_b64 exec, %2\n\ts_waitcnt vmcnt(0)"
+      : "=&v"(a), "=&v"(b), "=&s"(keep)
+      : "v"(p0), "v"(p1), "s"(m1)
+      : "memory");
+}
+// the same over two planes (p: octets, q: marks)
+TBZ_DEV void tbz_gload128x4(const u8* p0, const u8* p1, const u8* q0, const u8* q1, u64 m1, tbz_u32x4& a, tbz_u32x4& b,
+                            tbz_u32x4& c, tbz_u32x4& d) {
+  u64 keep;
+  asm volatile(
+      "global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %2, %7, off sc1\n\t"
+      "s_mov_b64 %4, exec\n\ts_and_b64 exec, exec, %9\n\t"
+      "global_load_dwordx4 %1, %6, off sc1\n\tglobal_load_dwordx4 %3, %8, off sc1\n\t"
+      "s_mov_b64 exec, %4\n\ts_waitcnt vmcnt(0)"
+      : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&s"(keep)
+      : "v"(p0), "v"(p1), "v"(q0), "v"(q1), "s"(m1)
+      : "memory");
+}
+// eight octets of each of two addresses
+TBZ_DEV void tbz_gload64x2(const u8* p0, const u8* p1, u64& a, u64& b) {
+  asm volatile("global_load_dwordx2 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(a), "=&v"(b)
+               : "v"(p0), "v"(p1)
+               : "memory");
+}
+TBZ_DEV void tbz_gload8x2(const u8* p0, const u8* p1, u32& a, u32& b) {
+  asm volatile("global_load_ubyte %0, %2, off sc1\n\tglobal_load_ubyte %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(a), "=&v"(b)
+               : "v"(p0), "v"(p1)
+               : "memory");
+}
+// every vector-memory operation this wave has issued (stores too) is complete
+TBZ_DEV void tbz_vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 #define TBZ_DYN_SHARED(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
 #define TBZ_LAUNCH_DYN(kernel, grid, lds_bytes, stream, ...) \

@@ -53,7 +53,12 @@ def parse_args(argv=None):
     ap.add_argument("--size-mib", type=float, default=0, help="decompressed MiB of the workload (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the byte compare of the output (status/checksum stay)")
+    ap.add_argument("--no-check", action="store_true", help="experiments with deliberately wrong kernels: time only")
     ap.add_argument("--gen-workers", type=int, default=0)
+    ap.add_argument("--corpus-cache", default=None, help="directory: load the workload from it if it is there, else generate "
+                    "and save it (profiler runs: generate first WITHOUT the profiler, whose library initialises the GPU before "
+                    "Python starts — the generators fork)")
+    ap.add_argument("--gen-only", action="store_true", help="generate (and cache) the workload, then exit")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
     ap.add_argument("--lib", default=None, help="engine library (tests: the CPU lane-emulator build)")
     return ap.parse_args(argv)
@@ -169,8 +174,23 @@ def main(argv=None):
     ncpu = os.cpu_count() or 1
     workers = args.gen_workers or max(1, min(16, ncpu // max(1, world)))
     t0 = time.time()
-    wl = build_workload(cfg, mib, rank, world, workers)      # forks its worker pool here, before any GPU / RCCL state
+    wl = None
+    cache = None
+    if args.corpus_cache:
+        import pickle
+        os.makedirs(args.corpus_cache, exist_ok=True)
+        cache = os.path.join(args.corpus_cache, "wl_%s_%g_r%dof%d.pkl" % (cfg, mib, rank, world))
+        if os.path.exists(cache):
+            with open(cache, "rb") as f:
+                wl = pickle.load(f)
+    if wl is None:
+        wl = build_workload(cfg, mib, rank, world, workers)  # forks its worker pool here, before any GPU / RCCL state
+        if cache:
+            with open(cache, "wb") as f:
+                pickle.dump(wl, f, protocol=4)
     gen_s = time.time() - t0
+    if args.gen_only:
+        return 0
 
     import torch
     dist = None
@@ -262,12 +282,14 @@ def main(argv=None):
     # ---- correctness of what was timed: status, length, checksum against what the generator computed from the
     # plaintext (and the engine's own trailer verdict), and a byte compare of the output
     for i, ((s, p, ck), r) in enumerate(zip(wl.streams, res)):
+        if args.no_check:
+            break
         assert r.status == 0 and r.out_len == len(p), (i, r.status, r.out_len, len(p))
         if wl.fmt == "zlib":
             assert r.adler32 == ck and (r.flags & 1), (i, hex(r.adler32), hex(ck))
         elif wl.fmt == "gzip":
             assert r.crc32 == ck and (r.flags & 1), (i, hex(r.crc32), hex(ck))
-    if not args.no_verify and n:
+    if not args.no_verify and not args.no_check and n:
         got = bytearray(opos)
         eng.d2h(got, d_out, opos)
         g = np.frombuffer(got, dtype=np.uint8)

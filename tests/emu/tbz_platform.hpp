@@ -296,6 +296,7 @@ TBZ_DEV u32 tbz_brev32(u32 v) {
 }
 TBZ_DEV u32 tbz_clz32(u32 v) { return v ? (u32)__builtin_clz(v) : 32; }
 TBZ_DEV u32 tbz_atomic_add_lds(u32* p, u32 v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+TBZ_DEV u32 tbz_atomic_add_global(u32* p, u32 v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
 TBZ_DEV u64 tbz_qsad4(u64 s0, u32 ref) {
   u64 r = 0;
@@ -340,6 +341,25 @@ TBZ_DEV u32 tbz_wave_incl_scan_u32(u32 v) {
   }
   return v;
 }
+
+// (the GPU flavour reads past the CU's L1; here memory is memory)
+TBZ_DEV u64 tbz_emu_ld64(const u8* p) { u64 v; memcpy(&v, p, 8); return v; }
+struct tbz_u32x4 {
+  u32 x, y, z, w;
+};
+TBZ_DEV tbz_u32x4 tbz_emu_ld128(const u8* p) { tbz_u32x4 v; memcpy(&v, p, 16); return v; }
+TBZ_DEV void tbz_gload128x2(const u8* p0, const u8* p1, u64 m1, tbz_u32x4& a, tbz_u32x4& b) {
+  a = tbz_emu_ld128(p0);
+  if ((m1 >> (tbz_emu::st().cur & 63)) & 1) b = tbz_emu_ld128(p1);
+}
+TBZ_DEV void tbz_gload128x4(const u8* p0, const u8* p1, const u8* q0, const u8* q1, u64 m1, tbz_u32x4& a, tbz_u32x4& b,
+                            tbz_u32x4& c, tbz_u32x4& d) {
+  tbz_gload128x2(p0, p1, m1, a, b);
+  tbz_gload128x2(q0, q1, m1, c, d);
+}
+TBZ_DEV void tbz_gload64x2(const u8* p0, const u8* p1, u64& a, u64& b) { a = tbz_emu_ld64(p0); b = tbz_emu_ld64(p1); }
+TBZ_DEV void tbz_gload8x2(const u8* p0, const u8* p1, u32& a, u32& b) { a = *p0; b = *p1; }
+TBZ_DEV void tbz_vm_drain() {}
 
 #define TBZ_DYN_SHARED(T, name) static __attribute__((aligned(16))) T name[64 * 1024]
 #define TBZ_LAUNCH_DYN(kernel, grid, lds_bytes, stream, ...) \

@@ -534,3 +534,33 @@ def config1_stream(two_blocks=False):
     n = 65536 if two_blocks else 65535
     payload = xorshift64star_bytes(n, 0x3B5A0001)
     return stored_stream(payload), payload
+
+
+# --------------------------------------------------------------------------- full-size corpora, generated in ONE pool
+# (for the -m gpu property tests: every fork happens before the process touches the GPU)
+
+
+def _full_job(job):
+    kind, n, seed = job
+    if kind == "2b":
+        return zlib_flush_stream(n, seed=seed, flush=zlib.Z_SYNC_FLUSH)
+    if kind == "nf":
+        p = enwik_like(n, seed)
+        return zlib.compress(p, 6), p, zlib.adler32(p)
+    if kind == "2":
+        return zlib_flush_stream(n, seed=seed)
+    if kind in ("5", "5f"):
+        s, p = adversarial_stream(n, sync_flush_every=(1 << 20) if kind == "5f" else 0)
+        return s, p, zlib.adler32(p)
+    if kind == "3":  # one slice of the member list: (first member, count)
+        first, count = seed
+        return [_gzip_member_job((0x3B2, (first + i) * n, n, 6)) for i in range(count)]
+    raise ValueError(kind)
+
+
+def full_size_corpora(jobs, workers=16):
+    """jobs: {name: (kind, n, seed)} -> {name: result}; every job runs in a worker process of one pool"""
+    names = list(jobs)
+    with ProcessPoolExecutor(max_workers=workers) as ex:
+        res = list(ex.map(_full_job, [jobs[k] for k in names]))
+    return dict(zip(names, res))

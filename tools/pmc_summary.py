@@ -24,7 +24,9 @@ def one(path):
 
 def main(pattern):
     rows = []
-    for p in sorted(glob.glob(pattern)):
+    import os
+    paths = sorted(set(glob.glob(pattern)) | set(glob.glob(pattern.replace('/*.db', '/*/*.db'))))
+    for p in paths:
         rows += one(p)
     ker = {}
     for k, c, n, avg, tot in rows:

@@ -38,3 +38,9 @@ print("  round 1: wave trips mean %.0f, phases %.1f, lane-iterations %.0f (%.0f%
       % (wt1.mean(), ph1.mean(), li1.mean(), 100 * li1.sum() / (64 * wt1.sum()), wt2.mean(), li2.mean()))
 r1 = a[:, 6].astype(np.float64) / 100.0
 print("  round 1: %.3f us per wave trip; later rounds: %.3f us per wave trip" % (r1.sum() / wt1.sum(), (a[:, 5].astype(np.float64) / 100.0 - r1).sum() / max(1.0, wt2.sum())))
+
+top = np.argsort(-life)[:8]
+print("  longest workgroups: (us, rounds, round-1 trips, later trips, start us)")
+for i in top:
+    print("    %.1f us, %d rounds, %d + %d trips, started at %.1f us, hdr+commit %.1f build %.1f rounds %.1f" % (
+        life[i], a[i, 7], a[i, 8], a[i, 11], t0[i] / 100.0, a[i, 3] / 100.0, a[i, 4] / 100.0, a[i, 5] / 100.0))

@@ -50,7 +50,7 @@ SYMBOLS = [
     "tbz_inflate_batch_device", "tbz_adler32_device", "tbz_crc32_device", "tbz_device_malloc",
     "tbz_device_free", "tbz_memcpy_h2d", "tbz_memcpy_d2h", "tbz_last_timings",
     "tbz_session_create", "tbz_session_destroy", "tbz_session_feed", "tbz_session_decompress",
-    "tbz_gzip_header_parse",
+    "tbz_gzip_header_parse", "tbz_inflate_gzip_members", "tbz_inflate_gzip_members_device",
 ]
 
 
@@ -101,6 +101,8 @@ def load(path=None):
     L.tbz_session_destroy.restype = None
     L.tbz_session_feed.argtypes = [vp, vp, sz, C.c_int]
     L.tbz_session_decompress.argtypes = [vp, vp, sz, C.POINTER(Result)]
+    L.tbz_inflate_gzip_members_device.argtypes = [vp, vp, sz, vp, sz, sz, C.POINTER(Result), u64p, u64p, C.POINTER(sz)]
+    L.tbz_inflate_gzip_members.argtypes = [vp, vp, sz, ALLOC_FN, vp, sz, C.POINTER(Result), u64p, C.POINTER(sz)]
     for s in SYMBOLS:
         getattr(L, s)  # AttributeError if the ABI is incomplete
     return L

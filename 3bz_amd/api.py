@@ -138,6 +138,36 @@ class Engine:
                                                       a(out_offs), a(out_caps), res))
         return res if raw else list(res)
 
+    def inflate_gzip_members_device(self, d_in, in_len, d_out, out_cap, max_members):
+        """every member of a concatenated gzip file, input and output in HBM: (results, in offsets, out offsets)"""
+        res = (_lib.Result * max_members)()
+        io, oo = (C.c_uint64 * max_members)(), (C.c_uint64 * max_members)()
+        n = C.c_size_t()
+        self._check(self.lib.tbz_inflate_gzip_members_device(self._ctx, d_in, in_len, d_out, out_cap, max_members, res, io, oo,
+                                                             C.byref(n)))
+        return res[:n.value], list(io[:n.value]), list(oo[:n.value])
+
+    def inflate_gzip_members(self, data, start=0, end=None, max_members=1 << 20):
+        """the same over host octets: (results, in offsets, list of bytearrays — None for a member that failed)"""
+        end = len(data) if end is None else end
+        res = (_lib.Result * max_members)()
+        io = (C.c_uint64 * max_members)()
+        n = C.c_size_t()
+        bufs = []
+
+        def alloc(_user, k):
+            bufs.append(bytearray(k))
+            return C.addressof((C.c_char * k).from_buffer(bufs[-1])) if k else 0
+
+        cb = _lib.ALLOC_FN(alloc)
+        base = _addr(data)
+        self._check(self.lib.tbz_inflate_gzip_members(self._ctx, (base or 0) + start if base else None, end - start, cb, None,
+                                                      max_members, res, io, C.byref(n)))
+        out, it = [], iter(bufs)
+        for r in res[:n.value]:
+            out.append(next(it) if r.status >= 0 else None)
+        return res[:n.value], list(io[:n.value]), out
+
     def adler32_device(self, d_buf, n, s1=1, s2=0):
         o1, o2 = C.c_uint32(), C.c_uint32()
         self._check(self.lib.tbz_adler32_device(self._ctx, d_buf, n, s1, s2, C.byref(o1), C.byref(o2)))
@@ -325,8 +355,8 @@ class ZlibState(DeflateState):
 class GzipState(DeflateState):
     """gzip-state (gzip.lisp:3-28).  The metadata slots are filled as the header arrives, with the reference's values
     (gzip.lisp:123-241; keywords as strings): compression_method "deflate", flags a list of "text" / "header-crc" /
-    "extra" / "name" / "comment" in the reference's (pushed) order, extra octets, name / comment strings (utf-8, else
-    iso-8859-1), operating_system, mtime_unix / mtime_universal (None when the header's MTIME is 0),
+    "extra" / "name" / "comment" in the reference's (pushed) order, extra octets, name / comment strings (utf-8 with
+    substitution, as the reference's :errorp nil decodes them), operating_system, mtime_unix / mtime_universal (None when the header's MTIME is 0),
     compression_level "maximum" / "fastest" / the XFL octet."""
     format = FORMATS["gzip"]
     format_name = "gzip"
@@ -366,11 +396,10 @@ def _note_gzip_header(eng, state, octets):
     stage = h.stage    # how far the parse got: 2 cm+flg, 3 mtime, 4 xfl+os, 5 extra, 6 name, 7 comment
 
     def text(off, n):
-        b = hb[off:off + n]
-        try:
-            return b.decode("utf-8")
-        except UnicodeDecodeError:
-            return b.decode("iso-8859-1")
+        # gzip.lisp:214-217, :236-239: (babel:octets-to-string ... :encoding :utf-8 :errorp nil) — with :errorp nil babel
+        # substitutes what is not utf-8 and returns, so the reference's iso-8859-1 branch is never reached.  (How many
+        # replacement characters an invalid run yields is babel's business and not pinned by any reference test.)
+        return bytes(hb[off:off + n]).decode("utf-8", errors="replace")
     if stage >= 2:
         state.compression_method = "deflate"
         state.flags = [k for bit, k in ((4, "comment"), (3, "name"), (2, "extra"), (1, "header-crc"), (0, "text"))
@@ -546,43 +575,14 @@ def decompress_gzip_members(compressed, start=0, end=None, engine=None):
     """every member of a gzip file, in order: a list of bytearrays.  Each member is exactly what
     `(decompress-vector v :format :gzip :start member-offset)` returns; a damaged or incomplete member
     raises what that call would.  Octets after the last member that do not start a member are ignored
-    (as gzip(1) does)."""
+    (as gzip(1) does).  One call of tbz_inflate_gzip_members: candidates, batch and walk run inside the library."""
     eng = engine or default_engine()
-    end = len(compressed) if end is None else end
-    data = bytes(compressed[start:end])
-    cands, p = [0], data.find(GZIP_MAGIC, 1)   # offset 0 is taken as given: the engine reports a bad magic there
-    while p >= 0:
-        cands.append(p)
-        p = data.find(GZIP_MAGIC, p + 1)
-    bounds = cands + [len(data)]
-
-    def isize_hint(lo, hi):  # ISIZE (gzip.lisp:96-101, unchecked there) sizes the buffer; a wrong one just fails the range
-        n = int.from_bytes(data[hi - 4:hi], "little") if hi - lo >= 18 else 0
-        return n if n <= 1032 * (hi - lo) + 64 else 0
-
-    ins = [data[bounds[i]:bounds[i + 1]] for i in range(len(cands))]
-    outs = [bytearray(isize_hint(bounds[i], bounds[i + 1])) for i in range(len(cands))]
-    res = eng.inflate_batch(ins, FORMATS["gzip"], outs)
-    members, i = [], 0
-    while i < len(cands):
-        lo = bounds[i]
-        if res[i].status == _lib.FINISHED and res[i].in_consumed == bounds[i + 1] - lo:
-            del outs[i][res[i].out_len:]   # (ISIZE is not checked by 3bz: it may overstate)
-            members.append(outs[i])
-            i += 1
-            continue
-        # not a whole member: a later candidate lies inside this member's data, or the member is damaged,
-        # or garbage follows it.  Decode from `lo` to the end (the ordinary one-stream call decides).
-        r, buf = eng.inflate_alloc(data, FORMATS["gzip"], start=lo)
+    res, _offs, bufs = eng.inflate_gzip_members(compressed, start=start, end=end)
+    members = []
+    for r, b in zip(res, bufs):
         if r.status < 0:
             raise ThreeBzError(r.status, eng.strerror(r.status))
         if r.status != _lib.FINISHED:
             raise ThreeBzError(-20, "incomplete gzip stream")
-        buf = buf if buf is not None else bytearray(0)
-        members.append(buf)
-        nxt = lo + r.in_consumed
-        while i < len(cands) and bounds[i] < nxt:
-            i += 1
-        if i < len(cands) and bounds[i] != nxt:
-            break  # what follows the member is not a member
+        members.append(b)
     return members

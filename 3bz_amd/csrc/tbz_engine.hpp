@@ -73,7 +73,7 @@ struct tbz_ctx {
   tbz::DevBuf d_str_off, d_str_len, d_tile_first, d_tile_counts, d_tile_offsets, d_markers, d_items, d_res,
       d_tok, d_scratch, d_runs, d_segs, d_groups, d_order, d_k3_fi, d_k3_ni, d_k3_oo, d_k3_oc, d_k3_sums, d_k3_flags,
       d_k3_gscan, d_k3_gne, d_k3_streams, d_k3_glob, d_redo_items, d_redo_res, d_k0_slots, d_k0_fm, d_hdr, d_gck, d_gchunks, d_ck_l1, d_tok2, d_runs2, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
-      d_out_stage, d_kb_tf, d_kb_slots, d_kb_counts, d_kb_offsets, d_kb_cands, d_kb_fc, d_kb_head, d_markers2, d_kb_fm2, d_mark, d_hg, d_k6s, d_bigs, d_recs, d_kc_tf, d_kc_slots, d_kc_ends, d_kc_link, d_kc_fm2, d_markers3, d_kb_keep, d_kb_kcounts;
+      d_out_stage, d_kb_tf, d_kb_slots, d_kb_counts, d_kb_offsets, d_kb_cands, d_kb_fc, d_kb_head, d_markers2, d_kb_fm2, d_mark, d_hg, d_k6s, d_bigs, d_recs, d_kc_tf, d_kc_slots, d_kc_ends, d_kc_link, d_kc_fm2, d_markers3, d_kb_keep, d_kb_kcounts, d_gz_cands, d_gz_count, d_gz_tmp;
 };
 
 namespace tbz {
@@ -90,7 +90,7 @@ static std::vector<DevBuf*> all_pools(tbz_ctx* ctx) {
           &ctx->d_kb_counts, &ctx->d_kb_offsets, &ctx->d_kb_cands, &ctx->d_kb_fc, &ctx->d_kb_head, &ctx->d_markers2,
           &ctx->d_kb_fm2, &ctx->d_mark, &ctx->d_hg, &ctx->d_k6s, &ctx->d_bigs, &ctx->d_recs, &ctx->d_kc_tf,
           &ctx->d_kc_slots, &ctx->d_kc_ends, &ctx->d_kc_link, &ctx->d_kc_fm2, &ctx->d_markers3, &ctx->d_kb_keep,
-          &ctx->d_kb_kcounts};
+          &ctx->d_kb_kcounts, &ctx->d_gz_cands, &ctx->d_gz_count, &ctx->d_gz_tmp};
 }
 static uint64_t scratch_total(tbz_ctx* ctx) {
   uint64_t t = 0;
@@ -2112,6 +2112,247 @@ int tbz_session_decompress(tbz_session* S, uint8_t* out, size_t out_cap, tbz_res
   return report(TBZ_INPUT_UNDERRUN, give);
 }
 
+}  // extern "C"
+
+namespace tbz {
+// ====================================================================================================
+// Multi-member gzip (K0g in tbz_kernels.hpp).  3bz decodes the first member and stops
+// (gzip.lisp:277-286): the caller is expected to call again with :start at the next member.  Here every candidate
+// range [c_i, c_i+1) is decoded in ONE batch call, its buffer sized by the ISIZE that ends the range, and the walk
+// from offset 0 accepts a range as a member iff it FINISHED having consumed exactly its octets (header, blocks,
+// CRC32, ISIZE: all verified by the engine).  Anything else — a later candidate lies inside the member's data (a
+// false magic), ISIZE understates, the member is damaged — is settled by the ordinary one-stream call from c_i to the
+// end of the input (sized first, then decoded), after which the walk goes on where that member ended.  Octets after
+// the last member that do not start a member are ignored (as gzip(1) does).
+// `place(k, n)`: device memory for the n octets of member k when it is decoded on its own; `done(k, d_ptr, res)`:
+// member k is complete (called in member order).
+// ====================================================================================================
+struct GzMember {
+  tbz_result res;
+  uint64_t in_off;
+};
+static int gzip_members_core(tbz_ctx* ctx, const void* d_in, size_t in_len, void* d_out, size_t out_cap, bool own_out,
+                             size_t max_members, const std::function<void*(size_t, uint64_t)>& place,
+                             const std::function<int(size_t, const void*, const tbz_result&, uint64_t)>& done,
+                             size_t* n_members, uint64_t* out_used) {
+  *n_members = 0;
+  if (out_used) *out_used = 0;
+  if (in_len == 0) return 0;
+  TBZ_HIP(hipSetDevice(ctx->device));
+  int r;
+  // ---- candidates
+  std::vector<GzCand> cands;
+  {
+    size_t cap = std::max<size_t>(4096, ctx->d_gz_cands.cap / sizeof(GzCand));
+    for (;;) {
+      if ((r = ensure(ctx, ctx->d_gz_cands, cap * sizeof(GzCand)))) return r;
+      if ((r = ensure(ctx, ctx->d_gz_count, 16))) return r;
+      TBZ_HIP(hipMemsetAsync(ctx->d_gz_count.p, 0, 16, ctx->stream));
+      K0gParams kp{(const u8*)d_in, (u64)in_len, (GzCand*)ctx->d_gz_cands.p, (u32*)ctx->d_gz_count.p, (u32)std::min<size_t>(cap, 0x7fffffffu)};
+      const size_t rows = ((((uintptr_t)d_in) & 15) + in_len + 1023) / 1024;
+      TBZ_LAUNCH(tbz_k0g_scan, rows, ctx->stream, kp);
+      TBZ_HIP(hipGetLastError());
+      uint32_t cnt = 0;
+      TBZ_HIP(hipMemcpyAsync(&cnt, ctx->d_gz_count.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+      TBZ_HIP(hipStreamSynchronize(ctx->stream));
+      if (cnt <= cap) {
+        cands.resize(cnt);
+        if (cnt) TBZ_HIP(hipMemcpy(cands.data(), ctx->d_gz_cands.p, cnt * sizeof(GzCand), hipMemcpyDeviceToHost));
+        break;
+      }
+      cap = (size_t)cnt + cnt / 4;
+    }
+    std::sort(cands.begin(), cands.end(), [](const GzCand& a, const GzCand& b) { return a.pos < b.pos; });
+    if (cands.empty() || cands[0].pos != 0) cands.insert(cands.begin(), GzCand{0, 0, 0});  // offset 0 is taken as given
+  }
+  const size_t nc = cands.size();
+  uint32_t tail_isize = 0;
+  if (in_len >= 4) TBZ_HIP(hipMemcpy(&tail_isize, (const uint8_t*)d_in + in_len - 4, 4, hipMemcpyDeviceToHost));
+  std::vector<uint64_t> io(nc), il(nc), oo(nc), oc(nc);
+  uint64_t pos_out = 0;
+  for (size_t i = 0; i < nc; i++) {
+    io[i] = cands[i].pos;
+    il[i] = (i + 1 < nc ? cands[i + 1].pos : (uint64_t)in_len) - cands[i].pos;
+    const uint64_t hint = i + 1 < nc ? cands[i + 1].before : tail_isize;
+    uint64_t cap = (il[i] >= 18 && hint <= 1032 * il[i] + 64) ? hint : 0;
+    if (!own_out) cap = std::min<uint64_t>(cap, out_cap > pos_out ? out_cap - pos_out : 0);
+    oo[i] = pos_out;
+    oc[i] = cap;
+    pos_out += (cap + 15) & ~15ull;
+  }
+  if (own_out) {
+    if ((r = ensure(ctx, ctx->d_out_stage, pos_out + 64))) return r;
+    d_out = ctx->d_out_stage.p;
+  }
+  std::vector<tbz_result> res(nc);
+  if ((r = inflate_passes(ctx, TBZ_FORMAT_GZIP, nc, d_in, io.data(), il.data(), d_out, oo.data(), oc.data(), res.data(), false)))
+    return r;
+  tbz_timings acc = ctx->tim;
+  // ---- second chances, all at once: the commonest reason for a range not to be a whole member is ONE false magic
+  // inside the member's data (one every 2^27 octets of compressed data: five in config 3's 518 MB).  Such a member is
+  // the range of c_i and the range of the false candidate c_i+1 together, and the latter's buffer was sized by the
+  // member's own ISIZE: every such pair is decoded again as one stream [c_i, c_i+2) into that buffer, in ONE batch call;
+  // `merged[i]` = it finished there, consuming exactly the two ranges.  Whatever else is wrong takes the one-stream
+  // path of the walk below.
+  std::vector<uint8_t> merged(nc, 0);
+  {
+    std::vector<size_t> idx;
+    for (size_t i = 0; i < nc;) {
+      if (res[i].status == TBZ_FINISHED && res[i].in_consumed == il[i]) { i++; continue; }
+      if (i + 1 < nc && oc[i + 1] != 0) idx.push_back(i);
+      i += 2;
+    }
+    if (!idx.empty()) {
+      const size_t nr = idx.size();
+      std::vector<uint64_t> rio(nr), ril(nr), roo(nr), roc(nr);
+      for (size_t q = 0; q < nr; q++) {
+        const size_t i = idx[q];
+        rio[q] = io[i];
+        ril[q] = il[i] + il[i + 1];
+        roo[q] = oo[i + 1];
+        roc[q] = oc[i + 1];
+      }
+      std::vector<tbz_result> rres(nr);
+      if ((r = inflate_passes(ctx, TBZ_FORMAT_GZIP, nr, d_in, rio.data(), ril.data(), d_out, roo.data(), roc.data(), rres.data(), false)))
+        return r;
+      acc.total_ms += ctx->tim.total_ms;
+      acc.huff_launches += ctx->tim.huff_launches;
+      for (size_t q = 0; q < nr; q++)
+        if (rres[q].status == TBZ_FINISHED && rres[q].in_consumed == ril[q]) {
+          merged[idx[q]] = 1;
+          res[idx[q]] = rres[q];
+        }
+    }
+  }
+  // ---- the walk
+  size_t k = 0, i = 0;
+  while (i < nc && k < max_members) {
+    const uint64_t lo = io[i];
+    if (merged[i]) {
+      if ((r = done(k, (const uint8_t*)d_out + oo[i + 1], res[i], lo))) return r;
+      k++;
+      i += 2;
+      continue;
+    }
+    if (res[i].status == TBZ_FINISHED && res[i].in_consumed == il[i]) {
+      if ((r = done(k, (const uint8_t*)d_out + oo[i], res[i], lo))) return r;
+      k++;
+      i++;
+      continue;
+    }
+    // not a whole member as it stands: a later candidate may lie inside it (a false magic).  The one-stream call over
+    // [lo, c_j) decides, j growing until the member finishes inside the range (one false magic in a member: one try)
+    uint64_t o1 = 0, l1 = 0, z = 0, cap1 = 0;
+    tbz_result r1;
+    for (size_t j = i + 2, step = 1;; j += step, step *= 2) {  // (a stored member full of magics: the range doubles)
+      l1 = (j < nc ? io[j] : (uint64_t)in_len) - lo;
+      if ((r = inflate_core(ctx, TBZ_FORMAT_GZIP, 1, (const uint8_t*)d_in + lo, &o1, &l1, nullptr, &z, &cap1, &r1, true))) return r;
+      acc.total_ms += ctx->tim.total_ms;
+      acc.huff_launches += ctx->tim.huff_launches;
+      if (r1.status != TBZ_INPUT_UNDERRUN || j >= nc) break;
+    }
+    if (r1.status != TBZ_FINISHED) {  // damaged or incomplete: what (decompress-vector v :format :gzip :start lo) reports
+      if (r1.status == TBZ_OUTPUT_OVERFLOW) r1.status = TBZ_E_INTERNAL;  // (cannot happen: unlimited space)
+      r1.out_len = 0;
+      if ((r = done(k, nullptr, r1, lo))) return r;
+      k++;
+      break;
+    }
+    cap1 = r1.out_total;
+    // room for it: the range of a false candidate INSIDE this member, if one is large enough — the last of them ends
+    // where the member ends, so it was sized by the member's own ISIZE — else wherever `place` finds some
+    void* dst = nullptr;
+    for (size_t j = i + 1; j < nc && io[j] < lo + r1.in_consumed; j++)
+      if (oc[j] >= cap1) {
+        dst = (uint8_t*)d_out + oo[j];
+        break;
+      }
+    if (!dst) dst = place(k, cap1);
+    if (!dst && cap1) {  // no room: reported as the reference reports a buffer that is too small
+      r1.status = TBZ_OUTPUT_OVERFLOW;
+      r1.out_len = 0;
+      if ((r = done(k, nullptr, r1, lo))) return r;
+      k++;
+      break;
+    }
+    tbz_result r2;
+    if ((r = inflate_core(ctx, TBZ_FORMAT_GZIP, 1, (const uint8_t*)d_in + lo, &o1, &l1, dst, &z, &cap1, &r2, false))) return r;
+    acc.total_ms += ctx->tim.total_ms;
+    acc.huff_launches += ctx->tim.huff_launches;
+    if ((r = done(k, dst, r2, lo))) return r;
+    k++;
+    if (r2.status != TBZ_FINISHED) break;
+    const uint64_t nxt = lo + r2.in_consumed;
+    while (i < nc && io[i] < nxt) i++;
+    if (i < nc && io[i] != nxt) break;  // what follows the member is not a member
+  }
+  *n_members = k;
+  if (out_used) *out_used = pos_out;
+  acc.n_candidates = nc;
+  ctx->tim = acc;
+  return 0;
+}
+}  // namespace tbz
+
+extern "C" {
+int tbz_inflate_gzip_members_device(tbz_ctx* ctx, const void* d_in, size_t in_len, void* d_out, size_t out_cap,
+                                    size_t max_members, tbz_result* results, uint64_t* member_in_off,
+                                    uint64_t* member_out_off, size_t* n_members) {
+  using namespace tbz;
+  if (!ctx || !n_members || (max_members && (!results || !member_in_off || !member_out_off)) || (in_len && !d_in)) return TBZ_E_ARG;
+  if (out_cap && !d_out) return TBZ_E_ARG;
+  // the candidate ranges take [0, out_used) of d_out in candidate order (16-octet aligned, sized by their ISIZE); a member
+  // that has to be decoded on its own is placed from the END of the buffer downwards
+  uint64_t top = out_cap;
+  auto place = [&](size_t, uint64_t n) -> void* {
+    if (n > top) return nullptr;
+    top = (top - n) & ~15ull;
+    return (uint8_t*)d_out + top;
+  };
+  auto done = [&](size_t k, const void* d_ptr, const tbz_result& r, uint64_t in_off) -> int {
+    results[k] = r;
+    member_in_off[k] = in_off;
+    member_out_off[k] = d_ptr ? (uint64_t)((const uint8_t*)d_ptr - (const uint8_t*)d_out) : 0;
+    return 0;
+  };
+  uint64_t out_used = 0;
+  int rc = gzip_members_core(ctx, d_in, in_len, d_out, out_cap, false, max_members, place, done, n_members, &out_used);
+  if (rc) return rc;
+  if (top < out_used)  // a member placed from the top ran into the ranges: it does not count as delivered
+    for (size_t k = 0; k < *n_members; k++)
+      if (results[k].status >= 0 && results[k].out_len && member_out_off[k] >= top && member_out_off[k] < out_used) {
+        results[k].status = TBZ_OUTPUT_OVERFLOW;
+        results[k].out_len = 0;
+      }
+  return 0;
+}
+
+int tbz_inflate_gzip_members(tbz_ctx* ctx, const uint8_t* in, size_t in_len, tbz_alloc_fn alloc, void* user,
+                             size_t max_members, tbz_result* results, uint64_t* member_in_off, size_t* n_members) {
+  using namespace tbz;
+  if (!ctx || !alloc || !n_members || (max_members && (!results || !member_in_off)) || (in_len && !in)) return TBZ_E_ARG;
+  TBZ_HIP(hipSetDevice(ctx->device));
+  int r;
+  if ((r = ensure(ctx, ctx->d_in_stage, in_len + 64))) return r;
+  if (in_len) TBZ_HIP(hipMemcpyAsync(ctx->d_in_stage.p, in, in_len, hipMemcpyHostToDevice, ctx->stream));
+  auto place = [&](size_t, uint64_t n) -> void* {
+    if (ensure(ctx, ctx->d_gz_tmp, n + 64)) return nullptr;
+    return ctx->d_gz_tmp.p;
+  };
+  auto done = [&](size_t k, const void* d_ptr, const tbz_result& res, uint64_t in_off) -> int {
+    results[k] = res;
+    member_in_off[k] = in_off;
+    if (res.status >= 0) {
+      uint8_t* out = alloc(user, (size_t)res.out_len);
+      if (res.out_len) {
+        if (!out) return TBZ_E_NOMEM;
+        TBZ_HIP(hipMemcpy(out, d_ptr, res.out_len, hipMemcpyDeviceToHost));
+      }
+    }
+    return 0;
+  };
+  return gzip_members_core(ctx, ctx->d_in_stage.p, in_len, nullptr, 0, true, max_members, place, done, n_members, nullptr);
+}
 }  // extern "C"
 
 extern "C" {

@@ -332,6 +332,74 @@ TBZ_KERNEL void tbz_k0_scan_emit(K0Params P) {
 }
 
 // ================================================================================================
+// K0g — gzip member starts.  A .gz file may hold many members back to back (RFC 1952 2.2); 3bz decodes the first and
+// stops (gzip.lisp:277-286), leaving the caller to call again at the next member — whose start is only known once
+// the member before it has been decoded.  Same move as for flush markers: every `1f 8b 08` with a legal FLG octet
+// (gzip.lisp:113-139) is a CANDIDATE start, all candidate ranges are decoded as one batch, and a candidate is a
+// member iff its predecessor FINISHED exactly there (tbz_inflate_gzip_members_device).  A record also carries the four
+// octets before the candidate: the ISIZE of the member that ends there, if one does — the size of its output buffer
+// (unchecked by the reference, gzip.lisp:96-101; a wrong one shows as output-overflow and the member is decoded again).
+// Records are appended in no particular order (one atomic per wave that found any); the host sorts them.
+// ================================================================================================
+struct GzCand {
+  u64 pos;     // octet offset of the `1f`
+  u32 before;  // the little-endian u32 that ends at pos (0 for pos < 4)
+  u32 pad;
+};
+struct K0gParams {
+  const u8* in;
+  u64 in_len;
+  GzCand* cands;
+  u32* count;   // [0] candidates found (may exceed cap: the host grows the list and scans again)
+  u32 cap;
+};
+TBZ_KERNEL void tbz_k0g_scan(K0gParams P) {
+  const u32 lane = tbz_lane();
+  const uintptr_t a0 = (uintptr_t)P.in & ~(uintptr_t)15;                 // 16-octet aligned rows of 1 KiB
+  const uintptr_t lo = (uintptr_t)P.in, hi = lo + P.in_len;
+  const uintptr_t c = a0 + (uintptr_t)tbz_block() * 1024 + lane * 16;    // this lane's chunk
+  uint4 v{};
+  if (c < hi && c + 16 > lo) v = *(const uint4*)c;                       // (an aligned chunk holding a stream octet is mapped)
+  u32 nx = tbz_wave_shl1(v.x);
+  if (lane == 63) {
+    const uintptr_t cn = c + 16;
+    nx = (cn < hi && cn + 16 > lo) ? *(const u32*)cn : 0u;
+  }
+  const u32 w[5] = {v.x, v.y, v.z, v.w, nx};
+  u32 m = 0;
+#pragma unroll
+  for (u32 k = 0; k < 16; k++) {
+    const u32 x = tbz_alignbit(w[(k >> 2) + 1], w[k >> 2], 8 * (k & 3));  // the four octets at chunk offset k
+    const uintptr_t a = c + k;
+    if ((x & 0xffffffu) == 0x088b1fu && (x >> 29) == 0 && a >= lo && a + 4 <= hi) m |= 1u << k;
+  }
+  const u64 any = tbz_ballot(m != 0);
+  if (any == 0) return;  // wave-uniform
+  const u32 n = (u32)__builtin_popcount(m);
+  const u32 inc = tbz_wave_incl_scan_u32(n);
+  u32 base = 0;
+  if (lane == 63) base = tbz_atomic_add_global(P.count, inc);
+  base = tbz_shfl(base, 63);
+  u32 at = base + inc - n;
+  while (m) {
+    const u32 k = (u32)__builtin_ctz(m);
+    m &= m - 1;
+    if (at < P.cap) {
+      GzCand g;
+      g.pos = (u64)(c + k - lo);
+      g.before = 0;
+      if (g.pos >= 4) {
+        const u8* q = P.in + g.pos - 4;
+        g.before = (u32)q[0] | ((u32)q[1] << 8) | ((u32)q[2] << 16) | ((u32)q[3] << 24);
+      }
+      g.pad = 0;
+      P.cands[at] = g;
+    }
+    at++;
+  }
+}
+
+// ================================================================================================
 // K0b — block-start finder for streams WITHOUT flush markers.  DEFLATE blocks are bit-aligned
 // and unmarked: 3bz finds the next block only by finishing the previous one (:block-end -> :start-of-block,
 // deflate.lisp:719-722).  But the header of a dynamic-Huffman block (deflate.lisp:577-669) is heavily
@@ -1511,6 +1579,11 @@ TBZ_DEV u32 crc_bitwise(u32 crc, u32 byte) {
   for (int k = 0; k < 8; k++) crc = (crc & 1) ? (0xedb88320u ^ (crc >> 1)) : (crc >> 1);
   return crc;
 }
+// keep the reader's LDS window over the position (a loop of k1_byte over a long field would otherwise fetch every word
+// from memory on its own: one round trip per four octets)
+TBZ_DEV void k1_window(BitReader& b) {
+  if (b.wi + 4 > b.bw + K1_INBUF) br_refill(b);
+}
 TBZ_DEV i32 k1_byte(K1State& st, u32* out, u64 p0) {
   *out = br_peek(st.br) & 0xff;
   br_skip(st.br, 8);
@@ -1521,7 +1594,16 @@ TBZ_DEV i32 k1_byte(K1State& st, u32* out, u64 p0) {
   return 0;
 }
 // container headers: zlib.lisp:14-37,:110-128  gzip.lisp:113-266
-TBZ_DEV i32 k1_container_header(K1State& st, u32 fmt) {
+// crc_tab: the 256-entry table of checksums.lisp:177-193 in LDS, or nullptr (bit by bit: 40 dependent operations per
+// octet — a false `1f 8b 08` candidate with FHCRC and FEXTRA set and 34 551 for a length kept ONE lane busy for 11.5 ms);
+// defer_hcrc: a header with FHCRC is not parsed at all (K1h: the gang kernel does it, with the table): returns 99
+// pre: the extra field's raw CRC (register starting at 0) and x^(8 * XLEN), computed by the whole gang (kg_extra_crc)
+struct GzExtraCrc {
+  u32 valid, raw, xpow;
+};
+TBZ_DEV u32 crc_mulmod(u32 a, u32 b);
+TBZ_DEV i32 k1_container_header(K1State& st, u32 fmt, const u32* crc_tab = nullptr, bool defer_hcrc = false,
+                                const GzExtraCrc* pre = nullptr) {
   const u64 p0 = st.br.pos;
   i32 e;
   u32 b0, b1, t;
@@ -1537,6 +1619,7 @@ TBZ_DEV i32 k1_container_header(K1State& st, u32 fmt) {
   if (fmt == 2) {
     u32 crc = 0xffffffffu;
     u32 flg = 0;
+    auto crc_step = [&](u32 c, u32 b) { return crc_tab ? (c >> 8) ^ crc_tab[(c ^ b) & 0xffu] : crc_bitwise(c, b); };
     for (int i = 0; i < 10; i++) {
       // the reference takes ID1+ID2 and CM+FLG as pairs: 16 bits or input-underrun, before it looks at either
       // octet (gzip.lisp:113-131)
@@ -1552,23 +1635,41 @@ TBZ_DEV i32 k1_container_header(K1State& st, u32 fmt) {
       if (i == 3) {
         flg = t;
         if (flg >> 5) return E_GZIP_FLAGS;
+        if (defer_hcrc && (flg & 2)) return 99;
       }
     }
+    const bool want_crc = (flg & 2) != 0;  // the header CRC is only looked at when FHCRC says there is one
     if (flg & 4) {
       if ((e = k1_byte(st, &b0, p0))) return e;
       if ((e = k1_byte(st, &b1, p0))) return e;
       crc = crc_bitwise(crc_bitwise(crc, b0), b1);
       u32 xlen = b0 | (b1 << 8);
-      for (u32 i = 0; i < xlen; i++) {
-        if ((e = k1_byte(st, &t, p0))) return e;
-        crc = crc_bitwise(crc, t);
+      if (!want_crc) {
+        // nobody reads the extra field here (the host has it: tbz_gzip_header_parse): step over it.  (Octet by octet
+        // with a bitwise CRC this was 10+ ms for ONE lane whenever a false `1f 8b 08` candidate — compressed data —
+        // happened to have FEXTRA set and 60 000 for a length.)
+        if (st.br.pos + 8ull * xlen > st.end_bit) {
+          st.fail_pos = p0;
+          return SEG_UNDERRUN;
+        }
+        br_seek(st.br, st.br.pos + 8ull * xlen);
+      } else if (pre && pre->valid && st.br.pos + 8ull * xlen <= st.end_bit) {
+        crc = crc_mulmod(pre->xpow, crc) ^ pre->raw;  // r(A || B) = Z^|B| r(A) ^ r(B), as K5 combines its chunks
+        br_seek(st.br, st.br.pos + 8ull * xlen);
+      } else {
+        for (u32 i = 0; i < xlen; i++) {
+          k1_window(st.br);
+          if ((e = k1_byte(st, &t, p0))) return e;
+          crc = crc_step(crc, t);
+        }
       }
     }
     for (u32 f = 8; f <= 16; f <<= 1) {  // FNAME, FCOMMENT: zero-terminated
       if (flg & f) {
         for (;;) {
+          k1_window(st.br);
           if ((e = k1_byte(st, &t, p0))) return e;
-          crc = crc_bitwise(crc, t);
+          if (want_crc) crc = crc_step(crc, t);
           if (t == 0) break;
         }
       }
@@ -1794,7 +1895,7 @@ TBZ_KERNEL void tbz_k1h_headers(K1hParams P) {
   h.sizes = 0;
   h.pad = 0;
   i32 status = 0;
-  if (it.flags & ITEM_HEAD) status = k1_container_header(st, fmt);
+  if (it.flags & ITEM_HEAD) status = k1_container_header(st, fmt, nullptr, true);
   if (status == 0) {
     h.hdr_bit = st.br.pos;
     const u32 pk = br_peek(st.br);
@@ -2849,6 +2950,60 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
   [[maybe_unused]] const u64 tr_t0 = TBZ_TR_NOW();
   [[maybe_unused]] u64 tr_hdr = 0, tr_build = 0, tr_round = 0, tr_commit = 0, tr_n = 0, tr_a = 0, tr_b = 0, tr_first = 0, tr_wt1 = 0, tr_li1 = 0, tr_ph1 = 0, tr_wt2 = 0, tr_li2 = 0;
 
+  // a gzip header with a header CRC (FHCRC): the gang builds the CRC table in its (still unused) lookup-table LDS first,
+  // and if there is an extra field (up to 65 535 octets: one lane took 10 ms over a false `1f 8b 08` candidate's) its
+  // lanes take the field's CRC in parallel: lane g its piece, the leader the ordered combine
+  const u32* crc_tab = nullptr;
+  GzExtraCrc xc{0, 0, 0};
+  {
+    bool hc = false;
+    if (have && (it.flags & ITEM_HEAD) && fmt == 2 && (it.start_bit >> 3) + 4 <= it.end_byte) hc = (P.in_base[(it.start_bit >> 3) + 3] & 2) != 0;
+    if (hc) {
+      u32* tab = (u32*)gt.lfast;
+      for (u32 n = g; n < 256; n += G) {
+        u32 c = n;
+        for (int k = 0; k < 8; k++) c = (c & 1) ? (0xedb88320u ^ (c >> 1)) : (c >> 1);
+        tab[n] = c;
+      }
+      crc_tab = tab;
+    }
+    tbz_sync();
+    const u64 b0 = it.start_bit >> 3;
+    u32 xlen = 0;
+    if (hc && b0 + 12 <= it.end_byte && (P.in_base[b0 + 3] & 4)) xlen = (u32)P.in_base[b0 + 10] | ((u32)P.in_base[b0 + 11] << 8);
+    const bool par = hc && xlen >= 256 && b0 + 12 + xlen <= it.end_byte;  // (gang-uniform)
+    u32 piece = 0, plen = 0, xp = 0;
+    if (par) {
+      const u32 chunk = (xlen + G - 1) / G;
+      const u32 lo_ = g * chunk < xlen ? g * chunk : xlen, hi_ = lo_ + chunk < xlen ? lo_ + chunk : xlen;
+      const u8* q = P.in_base + b0 + 12;
+      for (u32 i = lo_; i < hi_; i++) piece = (piece >> 8) ^ crc_tab[(piece ^ q[i]) & 0xffu];
+      plen = hi_ - lo_;
+      // x^(8 * plen) by squaring (x^1 = 0x40000000 in this reflected form, so x^8 = 0x00800000)
+      u32 pw = 0x80000000u, sq = 0x00800000u;
+      for (u32 n = plen; n; n >>= 1) {
+        if (n & 1) pw = crc_mulmod(sq, pw);
+        sq = crc_mulmod(sq, sq);
+      }
+      xp = pw;
+    }
+    // ordered combine over the gang's lanes (a loop of shuffles: every lane of the wave takes part)
+    u32 acc = 0, accp = 0x80000000u;
+    if (tbz_ballot(par) != 0) {
+      for (u32 k = 0; k < (u32)G; k++) {
+        const u32 pk_ = tbz_shfl(piece, (int)(base + k)), xk = tbz_shfl(xp, (int)(base + k)), nk = tbz_shfl(plen, (int)(base + k));
+        if (par && nk) {
+          acc = crc_mulmod(xk, acc) ^ pk_;
+          accp = crc_mulmod(xk, accp);
+        }
+      }
+      if (par) {
+        xc.valid = 1;
+        xc.raw = acc;
+        xc.xpow = accp;
+      }
+    }
+  }
   if (leader) {
     gs.P = it.start_bit;
     gs.T = 0;
@@ -2878,7 +3033,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     } else
     if (have && (it.flags & ITEM_HEAD)) {
       br_seek_fill(st.br, it.start_bit);
-      i32 e = k1_container_header(st, fmt);
+      i32 e = k1_container_header(st, fmt, crc_tab, false, &xc);
       if (e) {
         gs.status = e;
         gs.fail_pos = st.fail_pos;

@@ -11,7 +11,8 @@ input and output resident in HBM when the timed region starts.
   --config 2b  the same text with Z_SYNC_FLUSH (history crosses every flush point)
   --config nf  the same text, no flush at all (an ordinary zlib stream: ONE segment for a marker scanner)
   --config 1   :deflate, one stored block of 65 535 octets (plumbing / call floor)
-  --config 3   :gzip, 4 096 members x 256 KiB, one batch call (crc32 path)
+  --config 3   :gzip, 4 096 members x 256 KiB, one batch call (crc32 path), member offsets GIVEN
+  --config 3u  the same file as ONE blob, offsets NOT given: tbz_inflate_gzip_members_device finds the members (K0g)
   --config 4   the FIXED batch of 8 x 128 MiB independent :zlib streams, sharded over the ranks by
                multi.assign_streams, one tbz_inflate_batch_device call per rank  ("scaling": "strong")
   --config 5   adversarial LZ77 (256 MiB, fixed-Huffman blocks, distance 1 / 32 768), no flush markers
@@ -40,8 +41,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-CONFIGS = ("1", "2", "2b", "nf", "3", "4", "5", "5f")
-DEFAULT_MIB = {"1": 0, "2": 1024, "2b": 256, "nf": 64, "3": 1024, "4": 1024, "5": 256, "5f": 256}
+CONFIGS = ("1", "2", "2b", "nf", "3", "3u", "4", "5", "5f")
+DEFAULT_MIB = {"1": 0, "2": 1024, "2b": 256, "nf": 64, "3": 1024, "3u": 1024, "4": 1024, "5": 256, "5f": 256}
 
 
 def parse_args(argv=None):
@@ -98,14 +99,19 @@ def build_workload(cfg, mib, rank, world, workers):
         s, p = K.config1_stream()
         return Workload("config 1: :deflate, one stored block of 65535 uniform octets (xorshift64* 0x3B5A0001)",
                         "deflate", [(s, p, None)])
-    if cfg == "3":
+    if cfg in ("3", "3u"):
         member = 256 << 10
         n = max(1, U // member)
         blob, offs, plains = K.gzip_members(n, member, seed=seed, workers=workers)
         ends = offs[1:] + [len(blob)]
         streams = [(blob[o:e], pl, zlib.crc32(pl)) for o, e, pl in zip(offs, ends, plains)]
-        return Workload("config 3: :gzip, %d members x 256 KiB of the same text, one batch call, per-member parity "
-                        "(3bz stops after member 1), seed 0x3B2+rank" % n, "gzip", streams)
+        if cfg == "3u":
+            w = Workload("config 3u: :gzip, ONE file of %d members x 256 KiB of the same text, member starts found on the "
+                         "device (tbz_inflate_gzip_members_device), per-member parity, seed 0x3B2+rank" % n, "gzip", streams)
+            w.blob = blob
+            return w
+        return Workload("config 3: :gzip, %d members x 256 KiB of the same text, one batch call at GIVEN offsets, per-member "
+                        "parity (3bz stops after member 1), seed 0x3B2+rank" % n, "gzip", streams)
     if cfg == "4":
         M = importlib.import_module("3bz_amd.multi")
         n_streams, each = 8, max(64 << 10, U // 8)
@@ -221,17 +227,28 @@ def main(argv=None):
         out_offs.append(opos)
         out_caps.append(len(p))
         opos += (len(p) + 15) & ~15
+    blob = getattr(wl, "blob", None)
+    if blob is not None:   # one file: members back to back, output ranges 16-octet aligned + room for members decoded alone
+        ipos, opos = len(blob), opos + (4 << 20)
     d_in = eng.malloc(ipos + 64)
     d_out = eng.malloc(opos + 64)
-    for (s, _, _), o in zip(wl.streams, in_offs):
-        eng.h2d(d_in + o, s)
+    if blob is not None:
+        eng.h2d(d_in, blob)
+    else:
+        for (s, _, _), o in zip(wl.streams, in_offs):
+            eng.h2d(d_in + o, s)
 
     gathered = [None]
     # the batch entry point takes plain uint64 arrays: built once, as a caller decoding batches of one shape would
     c_in_offs, c_in_lens, c_out_offs, c_out_caps = (eng.u64_array(v) for v in (in_offs, in_lens, out_offs, out_caps))
 
+    member_offs = [None]
+
     def step():
-        if n == 0:
+        if blob is not None:
+            res, _io, member_offs[0] = eng.inflate_gzip_members_device(d_in, len(blob), d_out, opos, n + 8)
+            assert len(res) == n, (len(res), n)
+        elif n == 0:
             res = []
         elif n == 1:
             res = [eng.inflate_device(d_in, in_lens[0], d_out, out_caps[0], fmt)]
@@ -293,7 +310,7 @@ def main(argv=None):
         got = bytearray(opos)
         eng.d2h(got, d_out, opos)
         g = np.frombuffer(got, dtype=np.uint8)
-        for (s, p, _), o in zip(wl.streams, out_offs):
+        for (s, p, _), o in zip(wl.streams, member_offs[0] if blob is not None else out_offs):
             assert np.array_equal(g[o:o + len(p)], np.frombuffer(p, dtype=np.uint8)), "output differs from the plaintext"
 
     K_ = max(1, args.steps)

@@ -174,6 +174,27 @@ int tbz_inflate_batch_device(tbz_ctx* ctx, int format, size_t n, const void* d_i
                              const uint64_t* in_lens, void* d_out_base, const uint64_t* out_offs,
                              const uint64_t* out_caps, tbz_result* results);
 
+/* ---- every member of a concatenated gzip file ------------------------------------------------------
+ * 3bz decodes ONE member per call and stops after its trailer (gzip.lisp:277-286: "todo: support multiple
+ * members"); the caller is expected to call again with :start at the next member, whose offset is the consumed-octet
+ * count of the call before.  Here the member starts are found on the device (every `1f 8b 08` with a legal FLG octet
+ * is a candidate, gzip.lisp:113-139), all candidate ranges are decoded as one batch, and a candidate counts iff the
+ * member before it FINISHED exactly there — so member k is exactly what
+ *     (decompress-vector v :format :gzip :start member_in_off[k])
+ * returns, with results[k] what that call reports (status, out_len, crc32, trailer, in_consumed).  Walking stops at
+ * the first member that is damaged or incomplete (its error / input-underrun is results[n-1]) or where what follows a
+ * member is not a member (trailing garbage is ignored, as gzip(1) does); *n_members <= max_members.
+ * _device: input and output in HBM.  Member k's octets are d_out[member_out_off[k] .. + results[k].out_len); out_cap
+ * should be the sum of the members' sizes plus 16 octets per member (ranges are 16-octet aligned and sized by the
+ * ISIZE that ends them); a member whose ISIZE lies, or that holds a false magic, is decoded on its own and placed
+ * from the end of the buffer downwards; one that finds no room reports TBZ_OUTPUT_OVERFLOW.
+ * host variant: `alloc(user, n)` is called once per delivered member, in order, for its n octets (tbz_inflate_alloc). */
+int tbz_inflate_gzip_members_device(tbz_ctx* ctx, const void* d_in, size_t in_len, void* d_out, size_t out_cap,
+                                    size_t max_members, tbz_result* results, uint64_t* member_in_off,
+                                    uint64_t* member_out_off, size_t* n_members);
+int tbz_inflate_gzip_members(tbz_ctx* ctx, const uint8_t* in, size_t in_len, tbz_alloc_fn alloc, void* user,
+                             size_t max_members, tbz_result* results, uint64_t* member_in_off, size_t* n_members);
+
 /* ---- resumable decode: 3bz's chunked protocol with the state on the device ----------------------
  * A session is a deflate-state / zlib-state / gzip-state (deflate.lisp:4-62, zlib.lisp:3-12, gzip.lisp:3-28) whose
  * resumable part lives in HBM: the input not yet finished with, the 32 KiB window (deflate.lisp:121-137, :343-352)

@@ -77,6 +77,9 @@
 (cffi:defcfun ("tbz_session_decompress" %session-decompress) :int
   (session :pointer) (out :pointer) (out-cap :size) (res :pointer))
 (cffi:defcfun ("tbz_gzip_header_parse" %gzip-header-parse) :int (in :pointer) (in-len :size) (out :pointer))
+(cffi:defcfun ("tbz_inflate_gzip_members" %inflate-gzip-members) :int
+  (ctx :pointer) (in :pointer) (in-len :size) (alloc :pointer) (user :pointer) (max-members :size) (results :pointer)
+  (member-in-off :pointer) (n-members :pointer))
 
 (deftype octet () '(unsigned-byte 8))
 (deftype octet-vector () '(simple-array octet (*)))
@@ -207,10 +210,10 @@
                                           comment-off comment-len)
                                   h (:struct tbz-gzip-header))
           ;; the reference fills the slots as it reads (gzip.lisp:123-241): `stage` says how far the octets reach
-          (flet ((text (off len)           ; "rfc says 8859-1, but try utf8 anyway" (gzip.lisp:209-217)
-                   (let ((o (subseq hb off (+ off len))))
-                     (or (ignore-errors (babel:octets-to-string o :encoding :utf-8 :errorp t))
-                         (babel:octets-to-string o :encoding :iso-8859-1)))))
+          (flet ((text (off len)
+                   ;; the reference's own form (gzip.lisp:214-217, :236-239): with :ERRORP NIL babel substitutes
+                   ;; what is not utf-8 and returns a string, so the iso-8859-1 branch behind it never runs
+                   (babel:octets-to-string (subseq hb off (+ off len)) :encoding :utf-8 :errorp nil)))
             (when (>= stage 2)
               (setf (gs-compression-method state) :deflate
                     (gs-flags state) (append (when (logbitp 4 flg) '(:comment)) (when (logbitp 3 flg) '(:name))
@@ -290,15 +293,26 @@
               (ds-output-offset state)))))))
 
 ;;; ---- decompress-vector (api.lisp:23-65) -----------------------------------------------------
-(defvar *alloc-result* nil)
+;;; tbz_alloc_fn: the engine knows the size now and copies the octets into what this returns.  A Lisp vector is pinned
+;;; only INSIDE with-pointer-to-vector-data, and the engine writes after the callback has returned: so the callback
+;;; hands out foreign memory, and the octets move into a Lisp vector once the call is over (one host copy; a
+;;; static-vectors vector would save it where that library is at hand).
+(defvar *alloc-results* nil "list of (pointer . n), newest first")
 (cffi:defcallback alloc-octets :pointer ((user :pointer) (n :size))
   (declare (ignore user))
-  ;; tbz_alloc_fn: the engine knows the size now.  The vector must not move while the engine copies into it:
-  ;; a static vector (or a pinned one) — here CFFI's shareable vector
-  (setf *alloc-result* (cffi:make-shareable-byte-vector n))
-  (if (zerop n)
-      (cffi:null-pointer)
-      (cffi:with-pointer-to-vector-data (p *alloc-result*) p)))
+  (let ((p (if (zerop n) (cffi:null-pointer) (cffi:foreign-alloc :uint8 :count n))))
+    (push (cons p n) *alloc-results*)
+    p))
+(defun take-alloc-result (cell)
+  "the Lisp vector of one (pointer . n), the foreign memory freed"
+  (destructuring-bind (p . n) cell
+    (let ((v (make-array n :element-type 'octet)))
+      (unless (zerop n)
+        (cffi:with-pointer-to-vector-data (pv v)
+          (cffi:foreign-funcall "memcpy" :pointer pv :pointer p :size n :pointer))
+        (cffi:foreign-free p)
+        (setf (car cell) (cffi:null-pointer)))   ; (so that a clean-up pass does not free it again)
+      v)))
 
 (defun decompress-vector (compressed &key (format :zlib) (start 0) (end (length compressed)) output)
   "Returns (values buffer count)."
@@ -317,29 +331,38 @@
                             "tbz_inflate"))
               ;; the reference grows 32 KiB buffers by doubling and gathers (api.lisp:48-65); the engine decodes
               ;; once and asks for the buffer when it knows the size
-              (let ((*alloc-result* nil))
-                (check-call (%inflate-alloc (engine) fmt (cffi:inc-pointer pin start) (- end start)
-                                            (cffi:callback alloc-octets) (cffi:null-pointer) res)
-                            "tbz_inflate_alloc")
-                (setf output (or *alloc-result* (make-array 0 :element-type 'octet))))))
+              (let ((*alloc-results* nil))
+                (unwind-protect
+                     (check-call (%inflate-alloc (engine) fmt (cffi:inc-pointer pin start) (- end start)
+                                                 (cffi:callback alloc-octets) (cffi:null-pointer) res)
+                                 "tbz_inflate_alloc")
+                  (setf output (if *alloc-results*
+                                   (take-alloc-result (first *alloc-results*))
+                                   (make-array 0 :element-type 'octet)))))))
         (check (cffi:foreign-slot-value res '(:struct tbz-result) 'status))
         (values output (cffi:foreign-slot-value res '(:struct tbz-result) 'out-len))))))
 
 ;;; ---- every member of a multi-member .gz (SURVEY §8f-4; 3bz stops after the first: gzip.lisp:277-286) ----
-(defun decompress-gzip-members (compressed &key (start 0) (end (length compressed)))
+(defun decompress-gzip-members (compressed &key (start 0) (end (length compressed)) (max-members 1048576))
   "a list of octet vectors, one per member: each is what (decompress-vector v :format :gzip :start member-offset)
-returns.  Members are found one after the other (tbz_result.in_consumed says where the next one starts)."
-  (loop with pos = start
-        while (and (< (+ pos 2) end) (= (aref compressed pos) #x1f) (= (aref compressed (1+ pos)) #x8b))
-        collect (let ((state (make-gzip-state :output-buffer (make-array 0 :element-type 'octet)))
-                      (ctx (make-octet-vector-context compressed :start pos :end end))
-                      (parts nil))
-                  (loop for out = (make-array 65536 :element-type 'octet)
-                          then (make-array (* 2 (length out)) :element-type 'octet)
-                        do (replace-output-buffer state out)
-                           (let ((c (decompress ctx state)))
-                             (when (input-underrun state) (error "incomplete gzip stream"))
-                             (push (subseq out 0 c) parts))
-                        until (finished state))
-                  (setf pos (cb-offset (boxes ctx)))
-                  (apply #'concatenate 'octet-vector (nreverse parts)))))
+returns.  ONE call of tbz_inflate_gzip_members: the member starts are found on the device, all members are decoded as
+one batch, and the walk that proves them runs inside the library.  A damaged or incomplete member signals what the
+one-member call at its offset signals."
+  (let ((*alloc-results* nil) (members nil))
+    (cffi:with-foreign-objects ((res '(:struct tbz-result) max-members) (offs :uint64 max-members) (n :size))
+      (unwind-protect
+           (progn
+             (cffi:with-pointer-to-vector-data (pin compressed)
+               (check-call (%inflate-gzip-members (engine) (cffi:inc-pointer pin start) (- end start)
+                                                  (cffi:callback alloc-octets) (cffi:null-pointer) max-members res offs n)
+                           "tbz_inflate_gzip_members"))
+             (let ((cells (reverse *alloc-results*)))   ; one per delivered member, in order
+               (dotimes (k (cffi:mem-ref n :size))
+                 (let ((status (cffi:foreign-slot-value (cffi:mem-aptr res '(:struct tbz-result) k)
+                                                        '(:struct tbz-result) 'status)))
+                   (when (minusp status) (error "~a" (%strerror status)))
+                   (unless (zerop status) (error "incomplete gzip stream"))
+                   (push (take-alloc-result (pop cells)) members)))))
+        (dolist (cell *alloc-results*)   ; (what was handed out and not taken — an error above — is given back)
+          (unless (cffi:null-pointer-p (car cell)) (cffi:foreign-free (car cell))))))
+    (nreverse members)))

@@ -147,16 +147,15 @@ class State:
 
     def gzip_meta(self):
         """the gzip-state's metadata slots as decompress-gzip has filled them so far, with the reference's values
-        (gzip.lisp:123-241): keywords as strings, name / comment decoded utf-8 else iso-8859-1 (gzip.lisp:209-217)"""
+        (gzip.lisp:123-241): keywords as strings, name / comment decoded as utf-8 with substitution (gzip.lisp:209-217: :errorp nil)"""
         m = _GzipMeta()
         lib().tbzo_get_gzip_meta(self._p, C.byref(m))
 
         def text(p, n):
             b = C.string_at(p, n) if n else b""
-            try:
-                return b.decode("utf-8")
-            except UnicodeDecodeError:
-                return b.decode("iso-8859-1")
+            # (babel:octets-to-string ... :encoding :utf-8 :errorp nil) substitutes and returns: gzip.lisp:214-217, :236-239;
+            # the iso-8859-1 branch behind it is dead code.  The number of substitutes per invalid run is unpinned.
+            return b.decode("utf-8", errors="replace")
         out = {"compression_method": None, "flags": None, "extra": None, "name": None, "comment": None,
                "operating_system": None, "mtime_unix": None, "mtime_universal": None, "compression_level": "default"}
         if m.have_cm:

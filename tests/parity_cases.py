@@ -464,6 +464,9 @@ def case_gzip_metadata(eng):
     variants = [dict(), dict(name=b"file.txt", mtime=1_700_000_000, xfl=2),
                 dict(comment="caf\xe9 au lait".encode("latin-1"), name="na\u00efve".encode("utf-8"), os_=11, xfl=4),
                 dict(extra=b"\x01\x02abc" * 9, hcrc=True, text=True, os_=200, xfl=7, comment=b"c"),
+                # an extra field long enough for the gang to take its CRC in parallel (K1g), name + comment behind it
+                dict(extra=bytes((i * 7 + 3) & 0xff for i in range(3001)), hcrc=True, name=b"big-extra", comment=b"x" * 300),
+                dict(extra=bytes(range(256)) * 255, hcrc=True),
                 dict(name=b"", comment=b"", extra=b"")]
     for kw in variants:
         g, hlen = member(**kw)
@@ -474,6 +477,14 @@ def case_gzip_metadata(eng):
         assert se.gzip_meta() == so.gzip_meta(), (kw, se.gzip_meta(), so.gzip_meta())
         m = se.gzip_meta()
         assert m["compression_method"] == "deflate" and (m["name"] is None) == ("name" not in kw)
+        if kw.get("os_") == 11:  # not utf-8: substituted, NOT re-read as iso-8859-1 (gzip.lisp:236-239 with :errorp nil)
+            assert m["comment"] == "caf\ufffd au lait" and m["name"] == "na\u00efve", (m["comment"], m["name"])
+        if hlen > 1000:  # (a damaged octet inside the long extra field: the header CRC says so, as the reference's does)
+            bad = bytearray(g)
+            bad[hlen // 2] ^= 0x40
+            assert_same(eng, bytes(bad), "gzip", len(plain), what="header crc over a long extra field")
+            assert_same(eng, g[:hlen // 2], "gzip", len(plain), what="input ends inside a long extra field")
+            continue
         # the header in 3-octet chunks, then the rest
         so, se = O.State(FMT["gzip"], bytearray(len(plain))), A.make_gzip_state(bytearray(len(plain)))
         pos = 0
@@ -945,6 +956,28 @@ def case_gzip_members(eng, n_members=8, max_len=12_000, n_false=300):
         w = oracle_oneshot(blob, "gzip", len(p) + 8, start=off)
         assert w["flag"] == "finished" and w["bytes"] == p == bytes(g), ("member at", off)
         off += len(part)
+    # the same file resident in device memory: tbz_inflate_gzip_members_device — offsets found, never given
+    room = sum(len(p) for p in plains) + 16 * len(plains) + max(len(p) for p in plains) * 2 + 4096
+    d_in, d_out = eng.malloc(len(blob) + 64), eng.malloc(room + 64)
+    try:
+        eng.h2d(d_in, blob)
+        res, ioffs, ooffs = eng.inflate_gzip_members_device(d_in, len(blob), d_out, room, 64)
+        assert len(res) == len(plains), (len(res), len(plains))
+        host = bytearray(room)
+        eng.d2h(host, d_out)
+        off = 0
+        for r, io_, oo_, p, part in zip(res, ioffs, ooffs, plains, parts):
+            assert r.status == 0 and io_ == off and r.out_len == len(p) and r.in_consumed == len(part), (off, r.status, r.out_len)
+            assert r.crc32 == zlib.crc32(p) and bytes(host[oo_:oo_ + len(p)]) == p, ("member at", off)
+            off += len(part)
+        # max_members cuts the walk; a buffer with no room for the member that must be decoded on its own says so
+        res2, _, _ = eng.inflate_gzip_members_device(d_in, len(blob), d_out, room, 2)
+        assert len(res2) == 2 and all(r.status == 0 for r in res2)
+        res3, _, _ = eng.inflate_gzip_members_device(d_in, len(blob), d_out, 64, 64)
+        assert any(r.status == 2 for r in res3), [r.status for r in res3]
+    finally:
+        eng.free(d_in)
+        eng.free(d_out)
     assert [bytes(m) for m in A.decompress_gzip_members(blob + b"\x00trailing", engine=eng)] == plains
     assert [bytes(m) for m in A.decompress_gzip_members(b"xx" + blob, start=2, engine=eng)] == plains
     # a damaged / truncated member raises what the one-member call at its offset raises

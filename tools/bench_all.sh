@@ -4,7 +4,7 @@ tag=${1:-r02}
 out=gpurun_out/${tag}_bench.jsonl
 mkdir -p gpurun_out
 : > $out
-for c in 2 1 3 4 2b nf 5 5f; do
+for c in 2 1 3 3u 4 2b nf 5 5f; do
   steps=10; warm=2
   case $c in 2b|nf|5|5f) steps=3; warm=1;; esac
   echo "== config $c" >&2

@@ -49,8 +49,9 @@ SYMBOLS = [
     "tbz_device_count", "tbz_inflate", "tbz_inflate_size", "tbz_inflate_alloc", "tbz_inflate_batch", "tbz_inflate_device",
     "tbz_inflate_batch_device", "tbz_adler32_device", "tbz_crc32_device", "tbz_device_malloc",
     "tbz_device_free", "tbz_memcpy_h2d", "tbz_memcpy_d2h", "tbz_last_timings",
-    "tbz_session_create", "tbz_session_destroy", "tbz_session_feed", "tbz_session_decompress",
+    "tbz_session_create", "tbz_session_destroy", "tbz_session_feed", "tbz_session_decompress", "tbz_session_stats",
     "tbz_gzip_header_parse", "tbz_inflate_gzip_members", "tbz_inflate_gzip_members_device",
+    "tbz_inflate_to_device", "tbz_assign_streams", "tbz_inflate_batch_multi",
 ]
 
 
@@ -101,8 +102,13 @@ def load(path=None):
     L.tbz_session_destroy.restype = None
     L.tbz_session_feed.argtypes = [vp, vp, sz, C.c_int]
     L.tbz_session_decompress.argtypes = [vp, vp, sz, C.POINTER(Result)]
+    L.tbz_session_stats.argtypes = [vp, u64p, u64p]
     L.tbz_inflate_gzip_members_device.argtypes = [vp, vp, sz, vp, sz, sz, C.POINTER(Result), u64p, u64p, C.POINTER(sz)]
     L.tbz_inflate_gzip_members.argtypes = [vp, vp, sz, ALLOC_FN, vp, sz, C.POINTER(Result), u64p, C.POINTER(sz)]
+    L.tbz_inflate_to_device.argtypes = [vp, C.c_int, vp, sz, C.POINTER(vp), C.POINTER(Result)]
+    L.tbz_assign_streams.argtypes = [C.POINTER(sz), sz, sz, C.POINTER(C.c_uint32)]
+    L.tbz_inflate_batch_multi.argtypes = [C.POINTER(vp), sz, C.c_int, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz),
+                                          C.POINTER(Result)]
     for s in SYMBOLS:
         getattr(L, s)  # AttributeError if the ABI is incomplete
     return L

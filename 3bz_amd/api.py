@@ -118,6 +118,37 @@ class Engine:
         self._check(self.lib.tbz_inflate_batch(self._ctx, fmt, n, ins, il, os_, ol, res))
         return list(res)
 
+    def inflate_to_device(self, data, fmt, start=0, end=None):
+        """one decode of host octets into device memory the caller owns (self.free): (result, device pointer or None)"""
+        end = len(data) if end is None else end
+        res, p = _lib.Result(), C.c_void_p()
+        base = _addr(data)
+        self._check(self.lib.tbz_inflate_to_device(self._ctx, fmt, (base or 0) + start if base else None, end - start,
+                                                   C.byref(p), C.byref(res)))
+        return res, p.value
+
+    @staticmethod
+    def inflate_batch_multi(engines, datas, fmt, outs):
+        """n streams over several contexts (one per device): tbz_inflate_batch_multi — LPT assignment in C, one host thread
+        per context, results in stream order"""
+        n, k = len(datas), len(engines)
+        lib = engines[0].lib
+        ctxs = (C.c_void_p * k)(*[e._ctx for e in engines])
+        ins = (C.c_void_p * n)(*[_addr(d) for d in datas])
+        il = (C.c_size_t * n)(*[len(d) for d in datas])
+        os_ = (C.c_void_p * n)(*[_addr(o) for o in outs])
+        ol = (C.c_size_t * n)(*[len(o) for o in outs])
+        res = (_lib.Result * n)()
+        engines[0]._check(lib.tbz_inflate_batch_multi(ctxs, k, fmt, n, ins, il, os_, ol, res))
+        return list(res)
+
+    def assign_streams(self, sizes, parts):
+        """tbz_assign_streams: owner[i] of stream i among `parts` contexts / ranks"""
+        n = len(sizes)
+        owner = (C.c_uint32 * n)()
+        self._check(self.lib.tbz_assign_streams((C.c_size_t * n)(*sizes), n, parts, owner))
+        return list(owner)
+
     # ---- device buffers (raw device pointers as ints, e.g. torch.Tensor.data_ptr())
     def inflate_device(self, d_in, in_len, d_out, out_cap, fmt):
         res = _lib.Result()
@@ -209,6 +240,12 @@ class Engine:
         res = _lib.Result()
         self._check(self.lib.tbz_session_decompress(sess, out_addr, cap, C.byref(res)))
         return res
+
+    def session_stats(self, sess):
+        """(engine calls made by the session, input octets handed to them — re-decoded ones counted again)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.tbz_session_stats(sess, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def trim(self):
         """release the context's device scratch (it only grows otherwise)"""

@@ -24,6 +24,7 @@
 #include <cstring>
 #include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/tbz_amd.h"
@@ -198,6 +199,7 @@ struct StreamPlan {
   bool stored_cut = false;    // the input ran out inside a stored block's payload
   bool blk_known = false;     // not finished: where a resumed decode would start (CoreOpts)
   uint64_t blk_bit = 0, blk_out = 0;
+  uint64_t hdr_bit = 0;       // ... exactly: the header of the block the input ran out in (K1 reports it with every underrun)
   uint32_t trailer0 = 0, trailer1 = 0, trailer_have = 0;
   bool saw_final = false;
   uint32_t seg_first = 0, seg_count = 0;
@@ -320,6 +322,8 @@ struct CoreOpts {
   // ---- in
   uint32_t start_bit_off = 0;  // the stream's first block header sits at this bit of its first octet (a continuation:
                                // raw blocks entered at a block boundary, deflate.lisp:518-528 needs no other state)
+  uint64_t resume_tok_bit = 0; // != 0: a continuation INSIDE a block — the block's header is parsed at start_bit_off, then the
+                               // token loop is entered at this bit (from the stream's first octet; beyond the header)
   uint64_t hist_len = 0;       // octets of earlier output that precede this call's output in the buffer (at
                                // out_off - hist_len ...): matches may reach into them (deflate.lisp:343-352, the window)
   bool prefix_on_error = false;  // a stream that fails is still laid out and decoded up to the failing token
@@ -332,6 +336,8 @@ struct CoreOpts {
   uint64_t blk_bit = 0;        // start of the block in which the input ended (or the position where it ended, when that is
                                // where a block starts), in bits from the stream's first octet
   uint64_t blk_out = 0;        // octets produced before that block
+  uint64_t hdr_bit = 0;        // the header of the block in which the input ended, exactly (also after blocks decoded through)
+  uint64_t tok_bit = 0;        // start of the token (or header field) the input ended in: everything before it is decoded
   uint64_t end_bit = 0;        // finished: bit position after the final block (octet-aligned, before any trailer the
                                // engine did not parse because the format was raw deflate)
   int32_t first_error = 0;     // prefix_on_error: the status a plain call would have reported (0 if none)
@@ -348,6 +354,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   const uint64_t hist_len = opt ? opt->hist_len : 0;
   if (hist_len && !ctx->sym_hist) return TBZ_E_UNSUPPORTED;  // (TBZ_HIST=off: no way to reach octets of an earlier call)
   const uint32_t bit_off = opt ? opt->start_bit_off : 0;
+  const uint64_t resume_abs = (opt && opt->resume_tok_bit && n) ? in_offs[0] * 8 + opt->resume_tok_bit : 0;
   TBZ_HIP(hipSetDevice(ctx->device));
   ctx->tim = tbz_timings{};
   ctx->gang_rounds = ctx->gang_valid = 0;
@@ -403,7 +410,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
                 (const u32*)ctx->d_tile_first.p, (u32)n, (u32)tiles, (u32*)ctx->d_tile_counts.p,
                 (u32*)ctx->d_tile_offsets.p, (u64*)ctx->d_markers.p, (u64*)ctx->d_k0_slots.p,
                 (u32*)ctx->d_k0_fm.p + 2, (u32*)ctx->d_k0_fm.p, (Item*)ctx->d_items.p, (u32)format, 0, bit_off,
-                (u32*)ctx->d_k0_fm.p + (n + 3)};
+                (u32*)ctx->d_k0_fm.p + (n + 3), resume_abs ? 1u : 0u};
     const size_t max_items = tiles * (size_t)K0_SLOTS + n;
     TBZ_LAUNCH(tbz_k0_scan_tiles, tiles, ctx->stream, k0);
     TBZ_LAUNCH_WG(tbz_k0_scan_offsets, 1, K0_SCAN_THREADS, ctx->stream, k0);
@@ -446,7 +453,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       it.limit_bit = ~0ull;
       it.end_byte = S.in_off + S.in_len;
       it.stream = (uint32_t)s;
-      it.flags = ((uint32_t)format << ITEM_FMT_SHIFT) | ITEM_HEAD;
+      it.flags = ((uint32_t)format << ITEM_FMT_SHIFT) | ITEM_HEAD | ((s == 0 && resume_abs) ? ITEM_RESUME : 0u);
       items.push_back(it);
       S.first_item = (uint32_t)s;
       S.first_marker = 0;
@@ -543,6 +550,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         k0m.format = (u32)format;
         k0m.second_pass = 1;
         k0m.start_bit_off = bit_off;
+        k0m.resume = resume_abs ? 1u : 0u;
         TBZ_LAUNCH(tbz_k0_items, ((size_t)n_mark + n + 63) / 64, ctx->stream, k0m);
         d_markers_cur = (const u64*)ctx->d_markers2.p;
         d_first_marker = (const u32*)ctx->d_kb_fm2.p + 2;
@@ -633,6 +641,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         k0m.format = (u32)format;
         k0m.second_pass = 1;
         k0m.start_bit_off = bit_off;
+        k0m.resume = resume_abs ? 1u : 0u;
         TBZ_LAUNCH(tbz_k0_items, ((size_t)n_mark + n + 63) / 64, ctx->stream, k0m);
         d_markers_cur = (const u64*)ctx->d_markers3.p;
         d_first_marker = (const u32*)ctx->d_kc_fm2.p + 2;
@@ -699,7 +708,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     int rr = ensure(ctx, ctx->d_scratch, n_it * (size_t)K1_SCRATCH);
     if (rr) return rr;
     K1Params k1{(const u8*)d_in, pool_tok(fix), d_items, d_res, d_markers_cur,
-                (u8*)ctx->d_scratch.p, pool_runs(fix), d_first_marker, (u32)n_mark, (u32)n_it, items_per_wg(n_it)};
+                (u8*)ctx->d_scratch.p, pool_runs(fix), d_first_marker, (u32)n_mark, (u32)n_it, items_per_wg(n_it), resume_abs};
     TBZ_LAUNCH(tbz_k1_huff_decode, (n_it + k1.items_per_wg - 1) / k1.items_per_wg, ctx->stream, k1);
     return 0;
   };
@@ -745,7 +754,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         if ((rr = ensure(ctx, ctx->d_redo_res, wide.size() * sizeof(SegResult)))) return rr;
         K1gParams kg{(const u8*)d_in, pool_tok(fix), pool_runs(fix), (const Item*)ctx->d_redo_items.p,
                      (SegResult*)ctx->d_redo_res.p, d_markers_cur, d_first_marker, nullptr, nullptr, (u32)n_mark,
-                     (u32)wide.size(), ovl_for(64), sub_min_for(64), 0};
+                     (u32)wide.size(), ovl_for(64), sub_min_for(64), 0, resume_abs};
 #ifdef TBZ_WAVE_TRACE
         kg.trace = nullptr;
 #endif
@@ -793,7 +802,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if (ctx->k1h) TBZ_LAUNCH(tbz_k1h_headers, (n_it + 63) / 64, ctx->stream, kh);
     K1gParams kg{(const u8*)d_in, pool_tok(fix), pool_runs(fix), d_items, d_res,
                  d_markers_cur, d_first_marker, ctx->k1h ? (const HdrRec*)ctx->d_hdr.p : nullptr,
-                 (const u8*)ctx->d_scratch.p, (u32)n_mark, (u32)n_it, ovl_for(G), sub_min_for(G), wide_for(G, fix)};
+                 (const u8*)ctx->d_scratch.p, (u32)n_mark, (u32)n_it, ovl_for(G), sub_min_for(G), wide_for(G, fix), resume_abs};
 #ifdef TBZ_WAVE_TRACE
     {
       static int n_launch = 0;
@@ -992,6 +1001,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
           S.blk_bit = k.last_start;
           S.blk_out = k.total_out - k.last.out_bytes;
         }
+        S.hdr_bit = (uint64_t)k.last.trailer0 | ((uint64_t)k.last.trailer1 << 32);
       }
       S.stored_cut = k.last.status == SEG_UNDERRUN && k.last.pad == 2;
       if (k.last.status == SEG_UNDERRUN && k.last.pad == 1 && !(k.last.end_bit & 7)) {
@@ -1076,6 +1086,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         S.blk_bit = it.start_bit;
         S.blk_out = S.total_out - q.out_bytes;
       }
+      S.hdr_bit = (uint64_t)q.trailer0 | ((uint64_t)q.trailer1 << 32);
       if (q.pad == 1 && !(q.end_bit & 7)) {  // ran out exactly at an octet-aligned block start
         S.boundary_bit = q.end_bit;
         S.boundary_out = S.total_out;
@@ -1108,6 +1119,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         it.end_byte = sp[s].in_off + sp[s].in_len;
         it.stream = (uint32_t)s;
         it.flags = ((uint32_t)format << ITEM_FMT_SHIFT) | ITEM_FIXUP;
+        if (resume_abs && s == 0 && it.start_bit == sp[0].in_off * 8 + bit_off) it.flags |= ITEM_RESUME;  // (the block the session resumes in)
         fix.push_back(it);
         fix_stream.push_back(s);
       }
@@ -1623,6 +1635,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     opt->blk_known = sp[0].blk_known;
     opt->blk_bit = sp[0].blk_bit > sp[0].in_off * 8 ? sp[0].blk_bit - sp[0].in_off * 8 : 0;
     opt->blk_out = sp[0].blk_out;
+    opt->hdr_bit = sp[0].hdr_bit > sp[0].in_off * 8 ? sp[0].hdr_bit - sp[0].in_off * 8 : 0;
+    opt->tok_bit = sp[0].in_end_bit > sp[0].in_off * 8 ? sp[0].in_end_bit - sp[0].in_off * 8 : 0;
     opt->end_bit = sp[0].in_end_bit > sp[0].in_off * 8 ? sp[0].in_end_bit - sp[0].in_off * 8 : 0;
   }
   for (size_t s = 0; s < n; s++) {
@@ -1851,22 +1865,35 @@ int tbz_inflate_batch_device(tbz_ctx* ctx, int format, size_t n, const void* d_i
 struct tbz_session {
   tbz_ctx* ctx = nullptr;
   int format = 0;
-  tbz::DevBuf d_in, d_dec, d_hist, d_tmp;
-  size_t in_len = 0;          // valid octets in d_in: the stream from the octet that holds the resume point on
-  uint64_t in_abs = 0;        // how many octets of the stream precede d_in[0]
-  uint32_t bit_off = 0;       // the resume block's header starts at this bit of d_in[0]
+  tbz::DevBuf d_in, d_dec, d_hist, d_tmp, d_hdr, d_cat;
+  // ---- input.  The stream's octets from the resume point on live at d_in[in_off, in_off + in_len): a grow-only buffer
+  // whose front is given up by moving in_off (no allocation, copy or synchronisation per call).
+  size_t in_off = 0, in_len = 0;
+  uint64_t in_abs = 0;        // how many octets of the stream precede d_in[in_off]
+  // ---- resume point.  A block start (tok_bit = 0: the header at bit bit_off of the first octet is where decoding is
+  // entered, deflate.lisp:518-528) or a TOKEN inside a block: the header is parsed again and the token loop entered at
+  // tok_bit — what the reference gets by pushing the bits of an unfinished symbol back (deflate.lisp:399-427).  Far
+  // into a long block the octets between the header and the token are not kept: the header's SESSION_HB octets are set
+  // aside in d_hdr (hdr_on) and the engine decodes d_hdr ++ d_in, entering the token loop behind the seam.
+  uint32_t bit_off = 0;       // the resume block's header starts at this bit of its first octet (d_in[in_off], or d_hdr[0])
+  uint64_t tok_bit = 0;       // != 0: resume at this bit (from d_in[in_off]'s first bit; with hdr_on it is < 8)
+  bool hdr_on = false;
+  uint64_t hdr_abs = 0;       // hdr_on: how many octets of the stream precede d_hdr[0]
   bool header_done = false;   // the container header is behind the resume point: what is left are raw blocks
   uint64_t hist_len = 0;      // octets in d_hist (the output just before the resume point), at most 32768
   uint64_t out_abs = 0;       // octets of output before the resume point
   uint32_t ck = 0;            // adler32 (s1 | s2 << 16) / crc32 of those octets
-  // the decode of d_in as it stands (valid until more input arrives)
+  // ---- the decode of the input as it stands (valid until more input arrives)
   bool dec_valid = false;
+  bool sliced = false;        // it covered a first part of the input only (decode-ahead is bounded: SESSION_AHEAD)
   uint64_t dec_len = 0;       // octets decoded from the resume point on (at d_dec + 32768)
   uint64_t delivered = 0;     // ... of which the caller has these
   int32_t dec_status = 0;     // finished / input-underrun / the error met after dec_len octets
   uint32_t dec_flags = 0;
   bool blk_known = false;
-  uint64_t blk_bit = 0, blk_out = 0, end_bit = 0;
+  uint64_t blk_abs_bit = 0, blk_out = 0;  // block-granular resume point (absolute bit in the stream) and the output before it
+  uint64_t hdr_abs_bit = 0, tok_abs_bit = 0, end_abs_bit = 0;  // absolute bits: header of the block the input ran out in,
+                                                               // the token it ran out in, the end of the final block
   uint32_t total_ck = 0, trailer_check = 0, trailer_isize = 0;
   uint64_t consumed_abs = 0;  // finished: octets of the stream consumed, trailer included
   bool finished = false;
@@ -1877,9 +1904,13 @@ struct tbz_session {
   // octet is therefore an error before the first overflow and reads zeros after it; so does the session:
   bool window = false;        // an output-overflow has been reported
   bool pad_hist = false;      // the history is the full 32 KiB, zeros in front
+  // ---- measurement (tbz_session_stats)
+  uint64_t n_decodes = 0, in_decoded = 0;  // engine calls made, input octets handed to them (re-decoded ones included)
 };
 
 namespace tbz {
+constexpr uint64_t SESSION_HB = 320;            // octets that hold any block header (17 + 57 + 316 * 7 bits = 286 octets)
+constexpr uint64_t SESSION_AHEAD = 8ull << 20;  // input octets one decode takes at most: what a call materialises is bounded
 static uint32_t session_ck_init(int format) { return format == TBZ_FORMAT_ZLIB ? 1u : 0u; }
 
 // checksum of d[0, n) continuing from `init`
@@ -1918,34 +1949,54 @@ static int session_decode(tbz_session* S) {
     return S->d_dec.p;
   };
   const int fmt = S->header_done ? TBZ_FORMAT_DEFLATE : S->format;
-  uint64_t io = 0, il = S->in_len, oo = 32768, oc = 1ull << 62;
-  tbz_result R;
   if ((r = ensure(ctx, S->d_in, 64))) return r;  // (an empty first call: there is a buffer to point at)
-  r = inflate_core(ctx, fmt, 1, S->d_in.p, &io, &il, nullptr, &oo, &oc, &R, false, &opt);
+  // what the engine sees: the input as it stands (a first part of it), behind the set-aside header when there is one
+  const uint64_t take = std::min<uint64_t>(S->in_len, SESSION_AHEAD);
+  S->sliced = take < S->in_len;
+  const uint8_t* tail = (const uint8_t*)S->d_in.p + S->in_off;
+  const void* d_src = tail;
+  uint64_t seam = 0;  // octets of header in front of the tail
+  if (S->hdr_on) {
+    seam = SESSION_HB;
+    if ((r = ensure(ctx, S->d_cat, seam + take + 64))) return r;
+    TBZ_HIP(hipMemcpyAsync(S->d_cat.p, S->d_hdr.p, seam, hipMemcpyDeviceToDevice, ctx->stream));
+    if (take) TBZ_HIP(hipMemcpyAsync((uint8_t*)S->d_cat.p + seam, tail, take, hipMemcpyDeviceToDevice, ctx->stream));
+    d_src = S->d_cat.p;
+  }
+  opt.resume_tok_bit = S->tok_bit ? seam * 8 + S->tok_bit : 0;
+  uint64_t io = 0, il = seam + take, oo = 32768, oc = 1ull << 62;
+  tbz_result R;
+  r = inflate_core(ctx, fmt, 1, d_src, &io, &il, nullptr, &oo, &oc, &R, false, &opt);
   if (r) return alloc_err ? alloc_err : r;
+  S->n_decodes++;
+  S->in_decoded += il;
+  // positions of the engine's input -> absolute bits of the stream
+  auto abs_bit = [&](uint64_t p) { return p < seam * 8 ? S->hdr_abs * 8 + p : S->in_abs * 8 + (p - seam * 8); };
   S->dec_valid = true;
   S->dec_len = R.out_total;
   S->dec_status = R.status;
   S->dec_flags = R.flags;
   S->blk_known = opt.blk_known;
-  S->blk_bit = opt.blk_bit;
+  S->blk_abs_bit = abs_bit(opt.blk_bit);
   S->blk_out = opt.blk_out;
-  S->end_bit = opt.end_bit;
+  S->hdr_abs_bit = abs_bit(opt.hdr_bit);
+  S->tok_abs_bit = abs_bit(opt.tok_bit);
+  S->end_abs_bit = abs_bit(opt.end_bit);
   S->trailer_check = R.trailer_check;
   S->trailer_isize = R.trailer_isize;
   if (R.status == TBZ_E_DISTANCE && S->dec_len < S->delivered) S->dec_len = S->delivered;  // (no place found: nothing new)
   if (S->dec_len < S->delivered) return TBZ_E_INTERNAL;       // a longer input cannot decode to less
   const void* d_new = (const uint8_t*)S->d_dec.p + 32768;
   if (R.status == TBZ_FINISHED) {
-    S->consumed_abs = S->in_abs + R.in_consumed;
+    S->consumed_abs = abs_bit(R.in_consumed * 8) / 8;
     if (fmt == TBZ_FORMAT_DEFLATE && S->format != TBZ_FORMAT_DEFLATE) {
       // raw blocks were decoded: the container's trailer is read here, as zlib.lisp:80-95 / gzip.lisp:78-106 do
       // (the checksum of ALL output = the resume point's, continued over these octets)
       if ((r = session_chain_ck(S, d_new, S->dec_len, S->ck, &S->total_ck))) return r;
-      const uint64_t at = S->end_bit / 8;
+      const uint64_t at = S->end_abs_bit / 8 - S->in_abs;  // (the final block ends in the tail, behind any seam)
       const uint64_t have = S->in_len > at ? S->in_len - at : 0;
       uint8_t tr[8] = {0};
-      if (have) TBZ_HIP(hipMemcpy(tr, (const uint8_t*)S->d_in.p + at, std::min<uint64_t>(have, 8), hipMemcpyDeviceToHost));
+      if (have) TBZ_HIP(hipMemcpy(tr, tail + at, std::min<uint64_t>(have, 8), hipMemcpyDeviceToHost));
       S->dec_flags |= 2;
       if (S->format == TBZ_FORMAT_ZLIB) {
         const uint32_t stored = ((uint32_t)tr[0] << 24) | ((uint32_t)tr[1] << 16) | ((uint32_t)tr[2] << 8) | tr[3];
@@ -1965,6 +2016,7 @@ static int session_decode(tbz_session* S) {
         }
       }
       S->blk_known = false;  // (trailer cut off: the next call decodes the last blocks again, which is all there is left)
+      S->tok_abs_bit = S->hdr_abs_bit = 0;
     } else {
       S->total_ck = S->format == TBZ_FORMAT_ZLIB ? R.adler32 : R.crc32;
       if (S->out_abs && S->format != TBZ_FORMAT_DEFLATE) return TBZ_E_INTERNAL;  // (a resumed stream is past its header)
@@ -1973,41 +2025,83 @@ static int session_decode(tbz_session* S) {
   return 0;
 }
 
-// the caller has everything that was decoded and the input ran out: move the resume point to the block it ran out in
+// give up the front of d_in: the stream's octet `abs_byte` becomes the first
+static void session_drop_to(tbz_session* S, uint64_t abs_byte) {
+  const uint64_t drop = abs_byte > S->in_abs ? std::min<uint64_t>(abs_byte - S->in_abs, S->in_len) : 0;
+  S->in_off += drop;
+  S->in_len -= drop;
+  S->in_abs += drop;
+}
+
+// the caller has everything that was decoded and the input ran out: move the resume point — to the TOKEN the input ran
+// out in where that is inside a Huffman block (everything decoded leaves the session's view), else to the start of the
+// block it ran out in
 static int session_advance(tbz_session* S) {
   tbz_ctx* ctx = S->ctx;
-  if (!S->blk_known || S->blk_bit == 0 || S->blk_out > S->dec_len) return 0;
-  if (S->blk_bit / 8 > S->in_len) return 0;
   int r;
-  // checksum and window at the new resume point: octets [0, blk_out) of the decode leave the session's view
   const uint8_t* d_new = (const uint8_t*)S->d_dec.p + 32768;
-  if (S->blk_out) {
-    if ((r = session_chain_ck(S, d_new, S->blk_out, S->ck, &S->ck))) return r;
-    const uint64_t nh = std::min<uint64_t>(32768, (S->pad_hist ? 32768 : S->hist_len) + S->blk_out);
+  const uint64_t B = S->hdr_abs_bit, T = S->tok_abs_bit;
+  const bool at_token = S->dec_status == TBZ_INPUT_UNDERRUN && !(S->dec_flags & 4) && S->blk_known && T > B &&
+                        T >= S->in_abs * 8 && S->delivered == S->dec_len;
+  uint64_t out_gone = 0;  // octets of the decode that lie before the new resume point
+  if (at_token) {
+    out_gone = S->dec_len;
+  } else {
+    if (!S->blk_known || S->blk_out > S->dec_len) return 0;
+    const uint64_t cur = S->hdr_on ? S->hdr_abs * 8 + S->bit_off : S->in_abs * 8 + S->bit_off;
+    if (S->blk_abs_bit <= cur || S->blk_abs_bit < S->in_abs * 8) return 0;  // (the block the session already resumes in)
+    if (S->blk_abs_bit / 8 > S->in_abs + S->in_len) return 0;
+    out_gone = S->blk_out;
+  }
+  // checksum and window at the new resume point: octets [0, out_gone) of the decode leave the session's view
+  if (out_gone) {
+    if ((r = session_chain_ck(S, d_new, out_gone, S->ck, &S->ck))) return r;
+    const uint64_t nh = std::min<uint64_t>(32768, (S->pad_hist ? 32768 : S->hist_len) + out_gone);
     if ((r = ensure(ctx, S->d_tmp, 32768 + 64))) return r;
     // (history and decode are contiguous in d_dec: the window is the nh octets that end at the resume point)
-    TBZ_HIP(hipMemcpyAsync(S->d_tmp.p, d_new + S->blk_out - nh, nh, hipMemcpyDeviceToDevice, ctx->stream));
+    TBZ_HIP(hipMemcpyAsync(S->d_tmp.p, d_new + out_gone - nh, nh, hipMemcpyDeviceToDevice, ctx->stream));
     TBZ_HIP(hipStreamSynchronize(ctx->stream));
     std::swap(S->d_hist, S->d_tmp);
     S->hist_len = nh;
   }
-  const uint64_t drop = S->blk_bit / 8;
-  if (drop) {
-    const size_t keep = S->in_len - drop;
-    tbz::DevBuf nb;
-    if ((r = ensure(ctx, nb, std::max<size_t>(keep, S->d_in.cap > 4096 ? S->d_in.cap / 2 : 4096) + 64))) return r;
-    if (keep) TBZ_HIP(hipMemcpyAsync(nb.p, (const uint8_t*)S->d_in.p + drop, keep, hipMemcpyDeviceToDevice, ctx->stream));
-    TBZ_HIP(hipStreamSynchronize(ctx->stream));
-    TBZ_HIP(hipFree(S->d_in.p));
-    S->d_in = nb;
-    S->in_len = keep;
-    S->in_abs += drop;
+  if (at_token) {
+    const uint64_t Bb = B / 8, Tb = T / 8;
+    if (S->hdr_on && Bb == S->hdr_abs) {
+      // still the block whose header is set aside
+    } else if (Tb - Bb >= SESSION_HB) {
+      // far into a block: its header's octets are set aside, the octets between header and token given up
+      if ((r = ensure(ctx, S->d_hdr, SESSION_HB + 64))) return r;
+      TBZ_HIP(hipMemcpyAsync(S->d_hdr.p, (const uint8_t*)S->d_in.p + S->in_off + (Bb - S->in_abs), SESSION_HB,
+                             hipMemcpyDeviceToDevice, ctx->stream));
+      S->hdr_on = true;
+      S->hdr_abs = Bb;
+    } else {
+      S->hdr_on = false;
+    }
+    S->bit_off = (uint32_t)(B & 7);
+    if (S->hdr_on) {
+      session_drop_to(S, Tb);
+      S->tok_bit = T & 7;
+      if (S->tok_bit == 0) {  // (0 means "none": keep the octet before — it is the token's first bit that counts)
+        S->in_off -= 1;
+        S->in_len += 1;
+        S->in_abs -= 1;
+        S->tok_bit = 8;
+      }
+    } else {
+      session_drop_to(S, Bb);
+      S->tok_bit = T - Bb * 8;
+    }
+  } else {
+    session_drop_to(S, S->blk_abs_bit / 8);
+    S->hdr_on = false;
+    S->bit_off = (uint32_t)(S->blk_abs_bit & 7);
+    S->tok_bit = 0;
   }
-  S->bit_off = (uint32_t)(S->blk_bit & 7);
   S->header_done = true;  // (a block start lies behind every container header)
-  S->out_abs += S->blk_out;
-  S->dec_len -= S->blk_out;
-  S->delivered -= S->blk_out;
+  S->out_abs += out_gone;
+  S->dec_len -= out_gone;
+  S->delivered -= out_gone;
   S->dec_valid = false;   // d_dec is laid out for the old resume point
   return 0;
 }
@@ -2028,7 +2122,7 @@ int tbz_session_create(tbz_ctx* ctx, int format, tbz_session** out) {
 void tbz_session_destroy(tbz_session* S) {
   if (!S) return;
   hipSetDevice(S->ctx->device);
-  for (tbz::DevBuf* b : {&S->d_in, &S->d_dec, &S->d_hist, &S->d_tmp})
+  for (tbz::DevBuf* b : {&S->d_in, &S->d_dec, &S->d_hist, &S->d_tmp, &S->d_hdr, &S->d_cat})
     if (b->p) hipFree(b->p);
   delete S;
 }
@@ -2039,15 +2133,22 @@ int tbz_session_feed(tbz_session* S, const void* in, size_t in_len, int in_on_de
   tbz_ctx* ctx = S->ctx;
   TBZ_HIP(hipSetDevice(ctx->device));
   if (in_len == 0 || S->finished || S->error) return 0;
-  if (S->in_len + in_len + 64 > S->d_in.cap) {  // grow, keeping what is there
-    DevBuf nb;
-    int r = ensure(ctx, nb, (S->in_len + in_len) * 2 + 4096);
-    if (r) return r;
-    if (S->in_len) TBZ_HIP(hipMemcpy(nb.p, S->d_in.p, S->in_len, hipMemcpyDeviceToDevice));
-    if (S->d_in.p) TBZ_HIP(hipFree(S->d_in.p));
-    S->d_in = nb;
+  const size_t need = S->in_len + in_len + 64;
+  if (S->in_off + need > S->d_in.cap) {
+    if (need <= S->d_in.cap && S->in_off >= S->in_len) {
+      // the octets still wanted fit in front of themselves: move them there (the ranges do not overlap)
+      if (S->in_len) TBZ_HIP(hipMemcpy(S->d_in.p, (const uint8_t*)S->d_in.p + S->in_off, S->in_len, hipMemcpyDeviceToDevice));
+    } else {  // grow (doubling: amortised), keeping what is there
+      DevBuf nb;
+      int r = ensure(ctx, nb, need * 2 + 4096);
+      if (r) return r;
+      if (S->in_len) TBZ_HIP(hipMemcpy(nb.p, (const uint8_t*)S->d_in.p + S->in_off, S->in_len, hipMemcpyDeviceToDevice));
+      if (S->d_in.p) TBZ_HIP(hipFree(S->d_in.p));
+      S->d_in = nb;
+    }
+    S->in_off = 0;
   }
-  TBZ_HIP(hipMemcpy((uint8_t*)S->d_in.p + S->in_len, in, in_len, in_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  TBZ_HIP(hipMemcpy((uint8_t*)S->d_in.p + S->in_off + S->in_len, in, in_len, in_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
   S->in_len += in_len;
   S->dec_valid = false;
   return 0;
@@ -2075,9 +2176,9 @@ int tbz_session_decompress(tbz_session* S, uint8_t* out, size_t out_cap, tbz_res
   if (S->error) return report(S->error, 0);
   if (S->finished) return report(TBZ_FINISHED, 0);
   int r;
-  if (!S->dec_valid && (r = session_decode(S))) return r;
   uint64_t give = 0;
   for (;;) {
+    if (!S->dec_valid && (r = session_decode(S))) return r;
     const uint64_t g = std::min<uint64_t>(out_cap - give, S->dec_len - S->delivered);
     if (g) {
       TBZ_HIP(hipMemcpy(out + give, (const uint8_t*)S->d_dec.p + 32768 + S->delivered, g, hipMemcpyDeviceToHost));
@@ -2088,7 +2189,14 @@ int tbz_session_decompress(tbz_session* S, uint8_t* out, size_t out_cap, tbz_res
       // the match that reaches before the stream's first octet: the reference has a window by now and reads zeros
       S->pad_hist = true;
       S->dec_valid = false;
-      if ((r = session_decode(S))) return r;
+      continue;
+    }
+    if (S->delivered == S->dec_len && S->dec_status == TBZ_INPUT_UNDERRUN && S->sliced) {
+      // the decode covered a first part of the input only: everything it produced is handed out, on with the next part
+      const size_t before = S->in_len;
+      const uint64_t tok_before = S->tok_bit;
+      if ((r = session_advance(S))) return r;
+      if (S->dec_valid || (S->in_len == before && S->tok_bit == tok_before)) break;  // (no progress: as a plain underrun)
       continue;
     }
     break;
@@ -2108,8 +2216,15 @@ int tbz_session_decompress(tbz_session* S, uint8_t* out, size_t out_cap, tbz_res
     S->finished = true;
     return report(TBZ_FINISHED, give);
   }
-  if ((r = session_advance(S))) return r;
+  if (S->dec_valid && (r = session_advance(S))) return r;
   return report(TBZ_INPUT_UNDERRUN, give);
+}
+
+int tbz_session_stats(const tbz_session* S, uint64_t* n_decodes, uint64_t* in_decoded) {
+  if (!S) return TBZ_E_ARG;
+  if (n_decodes) *n_decodes = S->n_decodes;
+  if (in_decoded) *in_decoded = S->in_decoded;
+  return 0;
 }
 
 }  // extern "C"
@@ -2522,6 +2637,89 @@ int tbz_inflate_alloc(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len
       TBZ_HIP(hipStreamSynchronize(ctx->stream));
     }
   }
+  return 0;
+}
+
+// one decode of host input into DEVICE memory the caller then owns (tbz_device_free): the buffer is allocated once K1
+// has sized it — no sizing pass, no second decode (what a rank of a sharded stream keeps: 3bz_amd/multi.py)
+int tbz_inflate_to_device(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len, void** d_out, tbz_result* res) {
+  using namespace tbz;
+  if (!ctx || !res || !d_out || (in_len && !in)) return TBZ_E_ARG;
+  *d_out = nullptr;
+  TBZ_HIP(hipSetDevice(ctx->device));
+  int r;
+  if ((r = ensure(ctx, ctx->d_in_stage, in_len + 64))) return r;
+  if (in_len) TBZ_HIP(hipMemcpyAsync(ctx->d_in_stage.p, in, in_len, hipMemcpyHostToDevice, ctx->stream));
+  CoreOpts opt;
+  void* buf = nullptr;
+  opt.alloc = [&](uint64_t total) -> void* {
+    if (hipMalloc(&buf, total + 64) != hipSuccess) buf = nullptr;
+    return buf;
+  };
+  uint64_t io = 0, il = in_len, oo = 0, oc = 1ull << 62;
+  r = inflate_core(ctx, format, 1, ctx->d_in_stage.p, &io, &il, nullptr, &oo, &oc, res, false, &opt);
+  ctx->tim.h2d_copies = in_len ? 1u : 0u;
+  if (r) {
+    if (buf) hipFree(buf);
+    return buf ? r : (r == TBZ_E_ARG ? TBZ_E_NOMEM : r);
+  }
+  *d_out = buf;
+  return 0;
+}
+
+// ---- several devices from one host process ----------------------------------------------------------------------
+// longest-processing-time-first on compressed size, ties by index: the assignment 3bz_amd/multi.py makes for its ranks
+int tbz_assign_streams(const size_t* in_lens, size_t n, size_t n_parts, uint32_t* owner) {
+  if (!owner || !n_parts || (n && !in_lens)) return TBZ_E_ARG;
+  std::vector<size_t> order(n);
+  for (size_t i = 0; i < n; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return in_lens[a] > in_lens[b]; });
+  std::vector<uint64_t> load(n_parts, 0);
+  for (size_t i : order) {
+    size_t best = 0;
+    for (size_t k = 1; k < n_parts; k++)
+      if (load[k] < load[best]) best = k;
+    owner[i] = (uint32_t)best;
+    load[best] += in_lens[i];
+  }
+  return 0;
+}
+
+// n independent streams over n_ctx contexts (one per device, normally): each context decodes its share in ONE batch
+// call on a host thread of its own; results come back in stream order.  Returns the first engine error, if any.
+int tbz_inflate_batch_multi(tbz_ctx* const* ctxs, size_t n_ctx, int format, size_t n, const uint8_t* const* ins,
+                            const size_t* in_lens, uint8_t* const* outs, const size_t* out_caps, tbz_result* results) {
+  if (!ctxs || !n_ctx || !results || (n && (!ins || !in_lens || !outs || !out_caps))) return TBZ_E_ARG;
+  for (size_t k = 0; k < n_ctx; k++)
+    if (!ctxs[k]) return TBZ_E_ARG;
+  std::vector<uint32_t> owner(n);
+  int r = tbz_assign_streams(in_lens, n, n_ctx, owner.data());
+  if (r) return r;
+  std::vector<int> rc(n_ctx, 0);
+  std::vector<std::thread> th;
+  for (size_t k = 0; k < n_ctx; k++)
+    th.emplace_back([&, k]() {
+      std::vector<size_t> idx;
+      for (size_t i = 0; i < n; i++)
+        if (owner[i] == k) idx.push_back(i);
+      if (idx.empty()) return;
+      const size_t m = idx.size();
+      std::vector<const uint8_t*> i_(m);
+      std::vector<uint8_t*> o_(m);
+      std::vector<size_t> il(m), ol(m);
+      std::vector<tbz_result> rs(m);
+      for (size_t q = 0; q < m; q++) {
+        i_[q] = ins[idx[q]];
+        il[q] = in_lens[idx[q]];
+        o_[q] = outs[idx[q]];
+        ol[q] = out_caps[idx[q]];
+      }
+      rc[k] = tbz_inflate_batch(ctxs[k], format, m, i_.data(), il.data(), o_.data(), ol.data(), rs.data());
+      for (size_t q = 0; q < m; q++) results[idx[q]] = rs[q];
+    });
+  for (auto& t : th) t.join();
+  for (size_t k = 0; k < n_ctx; k++)
+    if (rc[k]) return rc[k];
   return 0;
 }
 

@@ -133,6 +133,7 @@ struct K0Params {
   u32 start_bit_off;      // stream 0's first block header sits at this bit of the stream's first octet (resumed streams)
   u32* n_fixed;           // items: counts the marker items whose first block is a fixed-Huffman block (nullptr: not wanted) —
                           // where most are, the streams are fixed-Huffman territory and K0c looks for block chains inside them
+  u32 resume;             // items: stream 0's head item carries ITEM_RESUME (a session's continuation inside a block)
 };
 constexpr u32 K0_SLOTS = 32;  // markers kept per 64 KiB tile by the one-pass scan (flush every 16 KiB of text: ~8)
 
@@ -301,7 +302,7 @@ TBZ_KERNEL void tbz_k0_items(K0Params P) {
   it.limit_bit = k < nm ? P.markers[fm + k] : ~0ull;
   it.end_byte = P.str_off[s] + P.str_len[s];
   it.stream = s;
-  it.flags = (P.format << ITEM_FMT_SHIFT) | (k == 0 ? ITEM_HEAD : 0u);
+  it.flags = (P.format << ITEM_FMT_SHIFT) | (k == 0 ? ITEM_HEAD : 0u) | ((i == 0 && P.resume) ? ITEM_RESUME : 0u);
   P.items[i] = it;
   if (P.n_fixed) {  // BTYPE of the block at a marker (markers are octet positions; the stream has at least one octet there)
     bool fx = false;
@@ -1161,6 +1162,7 @@ struct K1Params {
   u32 n_markers;
   u32 n_items;
   u32 items_per_wg;  // 1..64: lanes >= items_per_wg idle (used to spread few large items over all CUs)
+  u64 resume_bit;    // ITEM_RESUME: where the token loop of the item's first block is entered (bit position relative to in_base)
 };
 
 // per-lane bit reader (deflate.lisp:140-231 restated): LSB-first, 32-bit words, one word of lookahead.
@@ -1764,6 +1766,7 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
         tables = 2;
       }
       if (status) break;
+      if ((it.flags & ITEM_RESUME) && blk_pos == it.start_bit && P.resume_bit > st.br.pos) br_seek(st.br, P.resume_bit);
       status = k1_decode_block(S, st, T, sc);
       if (status) break;
     }
@@ -2017,6 +2020,7 @@ struct K1gParams {
                             // in sync and take a longer run-up)
   u32 sub_min;              // least sub-range per lane (bits, multiple of 64): what the rounds after the first one run at
   u64 wide_bits;            // gangs narrower than 64 decline items longer than this (SEG_WIDE; 0: never)
+  u64 resume_bit;           // ITEM_RESUME: where the token loop of the item's first block is entered
 #ifdef TBZ_WAVE_TRACE
   u64* trace;               // experiment builds only: 8 words per workgroup (tools/exp/wave_trace.py)
 #endif
@@ -3052,7 +3056,12 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     if (tbz_ballot(gs.mode != GM_DONE) == 0) break;
     // ---- H: leaders whose gang is between blocks parse the next header
     tr_a = TBZ_TR_NOW();
-    if (leader && gs.mode == GM_HEADER) kg_leader_header(gt, gs, st, it, P, tok0, fmt, fixup, idx);
+    if (leader && gs.mode == GM_HEADER) {
+      kg_leader_header(gt, gs, st, it, P, tok0, fmt, fixup, idx);
+      // a continuation inside a block: the header has been read, the tokens go on where the session stopped
+      if ((it.flags & ITEM_RESUME) && gs.blk_pos == it.start_bit && (gs.mode == GM_BUILD || gs.mode == GM_BLOCK) && P.resume_bit > gs.P)
+        gs.P = P.resume_bit;
+    }
     tbz_sync();
     tr_b = TBZ_TR_NOW();
     tr_hdr += tr_b - tr_a;

@@ -23,6 +23,9 @@ enum : uint32_t {
   ITEM_HEAD = 1u,    // starts at the stream's first byte: parse the zlib/gzip container header first
   ITEM_FIXUP = 2u,   // chain repair: ignore `limit_bit`, land on ANY marker (binary search)
   ITEM_PROBE = 4u,   // re-decode by the one-lane kernel to locate a distance error: SegResult.reserved = its place
+  ITEM_RESUME = 8u,  // a session's continuation INSIDE a block: the block's header is parsed where the item starts, then the
+                     // token loop is entered at the launch's resume_bit (what deflate.lisp:399-427 achieves by pushing the
+                     // bits of an unfinished symbol back)
   ITEM_FMT_SHIFT = 8, // format in bits 8..9
   ITEM_HIST_SHIFT = 16 // bits 16..31: octets of the stream before the item (saturated at 65535), for the exact
                        // location of a distance-before-start error (one-lane re-decode of the offending item)

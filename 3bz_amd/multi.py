@@ -146,15 +146,8 @@ def shard_decode(eng, data, fmt, cuts, r):
     f = fmt if r == 0 else FMT_DEFLATE
     if hi == lo and r > 0:
         return [1, 0, 0, 0, 0, 0, 0, 0], None, 0   # nothing to do: trivially clean
-    sz = eng.inflate_size(data, f, lo, hi)          # K1 only: how much output this range makes
-    n = int(sz.out_total) if sz.status >= 0 else 0
-    d_in = eng.malloc(hi - lo + 64)
-    d_out = eng.malloc(n + 64)
-    try:
-        eng.h2d(d_in, memoryview(data)[lo:hi] if not isinstance(data, bytes) else data[lo:hi])
-        res = eng.inflate_device(d_in, hi - lo, d_out, n + 1, f)   # (slack: the scratch buffer is never "full")
-    finally:
-        eng.free(d_in)
+    # ONE decode: the output buffer is allocated on the device once K1 has sized it (tbz_inflate_to_device)
+    res, d_out = eng.inflate_to_device(data, f, lo, hi)
     got = int(res.out_len) if res.status >= 0 else 0
     ck = 0
     if res.status in (0, 1) and fmt != FMT_DEFLATE:
@@ -222,14 +215,7 @@ def inflate_sharded(eng, data, fmt, rank, world, dist, torch, device="cpu"):
     out = {"sharded": False, "why": v["why"], "d_out": None, "offset": 0, "len": 0}
     rec = [0] * 8
     if rank == 0:   # the ordinary path, on one GPU: its result IS the answer
-        sz = eng.inflate_size(data, fmt)
-        cap = int(sz.out_total) if sz.status >= 0 else 0
-        d_in, d_o = eng.malloc(len(data) + 64), eng.malloc(cap + 64)
-        try:
-            eng.h2d(d_in, data)
-            res = eng.inflate_device(d_in, len(data), d_o, cap + 1, fmt)
-        finally:
-            eng.free(d_in)
+        res, d_o = eng.inflate_to_device(data, fmt)
         got = int(res.out_len) if res.status >= 0 else 0
         rec = [int(res.status), got, int(res.in_consumed), len(data), int(res.adler32 if fmt == FMT_ZLIB else res.crc32), 0, 0, 0]
         out.update(d_out=d_o, len=got)

@@ -174,6 +174,21 @@ int tbz_inflate_batch_device(tbz_ctx* ctx, int format, size_t n, const void* d_i
                              const uint64_t* in_lens, void* d_out_base, const uint64_t* out_offs,
                              const uint64_t* out_caps, tbz_result* results);
 
+/* One decode of host input into DEVICE memory that the caller then owns (release it with tbz_device_free): *d_out is
+ * allocated once K1 has sized the output — no sizing pass, no second decode.  res->out_len octets at *d_out. */
+int tbz_inflate_to_device(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len, void** d_out, tbz_result* res);
+
+/* ---- several devices from ONE host process --------------------------------------------------------
+ * north_star: "many independent streams shard across the 8 GPUs of one node".  A host that is not a torch.distributed
+ * rank (the Lisp shim) creates one context per device (tbz_ctx_create(d, ...)) and hands them all to
+ * tbz_inflate_batch_multi: streams are assigned longest-compressed-first to the least loaded context
+ * (tbz_assign_streams: the same rule 3bz_amd/multi.py applies to ranks), every context decodes its share in ONE
+ * tbz_inflate_batch call on a host thread of its own, results[i] is stream i's.  No data-path collective: a
+ * deflate-state is self-contained (deflate.lisp:4-62). */
+int tbz_assign_streams(const size_t* in_lens, size_t n, size_t n_parts, uint32_t* owner);
+int tbz_inflate_batch_multi(tbz_ctx* const* ctxs, size_t n_ctx, int format, size_t n, const uint8_t* const* ins,
+                            const size_t* in_lens, uint8_t* const* outs, const size_t* out_caps, tbz_result* results);
+
 /* ---- every member of a concatenated gzip file ------------------------------------------------------
  * 3bz decodes ONE member per call and stops after its trailer (gzip.lisp:277-286: "todo: support multiple
  * members"); the caller is expected to call again with :start at the next member, whose offset is the consumed-octet
@@ -207,13 +222,19 @@ int tbz_inflate_gzip_members(tbz_ctx* ctx, const uint8_t* in, size_t in_len, tbz
  * far, res->in_consumed = (finished) octets of the stream consumed including the trailer, flags as in tbz_result.
  * A stream that turns out to be invalid reports its error in the call in which a front-to-back decoder would have
  * met it: after the output before it has been handed out (status < 0 with out_len = the last octets before it).
- * Cost per call: the new input plus the one block it continues (the resume point is a block start). */
+ * Cost per call: the new input plus one block header: the resume point is the TOKEN the input ran out in (the block's
+ * header is parsed again and the token loop entered there: what deflate.lisp:399-427 does by pushing an unfinished
+ * symbol's bits back); inside a stored block's payload it is the block's start (at most 64 KiB copied again).  One call
+ * decodes at most 8 MiB of input ahead of what the caller's buffers have taken. */
 typedef struct tbz_session tbz_session;
 int tbz_session_create(tbz_ctx* ctx, int format, tbz_session** out_session);
 void tbz_session_destroy(tbz_session* s);
 /* `in` is host memory, or device memory when in_on_device != 0 (a pointer context over HBM, io-mmap.lisp:47-54) */
 int tbz_session_feed(tbz_session* s, const void* in, size_t in_len, int in_on_device);
 int tbz_session_decompress(tbz_session* s, uint8_t* out, size_t out_cap, tbz_result* res);
+/* measurement: engine calls the session has made so far and the input octets handed to them (octets decoded again
+ * after a resume are counted again: in_decoded / octets fed is the re-decode factor) */
+int tbz_session_stats(const tbz_session* s, uint64_t* n_decodes, uint64_t* in_decoded);
 
 /* ---- gzip header metadata (host side; no device involved) --------------------------------------
  * What decompress-gzip leaves in the gzip-state's slots while it reads the header (gzip.lisp:110-266:

@@ -36,7 +36,9 @@
    ;; ---- engine management (no counterpart in 3bz: a deflate-state is self-contained)
    #:*engine* #:open-engine #:close-engine #:with-engine #:trim-engine
    ;; ---- beyond the reference (SURVEY §8f-4): every member of a multi-member .gz
-   #:decompress-gzip-members))
+   #:decompress-gzip-members
+   ;; ---- beyond the reference (SURVEY §8e): many independent streams over the GPUs of one node, from ONE Lisp process
+   #:*engines* #:open-engines #:close-engines #:decompress-vectors))
 (in-package #:3bz-amd)
 
 (cffi:define-foreign-library lib3bz-amd
@@ -77,6 +79,12 @@
 (cffi:defcfun ("tbz_session_decompress" %session-decompress) :int
   (session :pointer) (out :pointer) (out-cap :size) (res :pointer))
 (cffi:defcfun ("tbz_gzip_header_parse" %gzip-header-parse) :int (in :pointer) (in-len :size) (out :pointer))
+(cffi:defcfun ("tbz_device_count" %device-count) :int)
+(cffi:defcfun ("tbz_inflate_size" %inflate-size) :int
+  (ctx :pointer) (format :int) (in :pointer) (in-len :size) (res :pointer))
+(cffi:defcfun ("tbz_inflate_batch_multi" %inflate-batch-multi) :int
+  (ctxs :pointer) (n-ctx :size) (format :int) (n :size) (ins :pointer) (in-lens :pointer) (outs :pointer)
+  (out-caps :pointer) (results :pointer))
 (cffi:defcfun ("tbz_inflate_gzip_members" %inflate-gzip-members) :int
   (ctx :pointer) (in :pointer) (in-len :size) (alloc :pointer) (user :pointer) (max-members :size) (results :pointer)
   (member-in-off :pointer) (n-members :pointer))
@@ -366,3 +374,49 @@ one-member call at its offset signals."
         (dolist (cell *alloc-results*)   ; (what was handed out and not taken — an error above — is given back)
           (unless (cffi:null-pointer-p (car cell)) (cffi:foreign-free (car cell))))))
     (nreverse members)))
+
+;;; ---- many independent streams over several devices (SURVEY §8e; north_star: "host code stays Common Lisp") ----
+;;; One context per device; tbz_inflate_batch_multi assigns the streams (longest compressed first to the least loaded
+;;; context), decodes each context's share in one batch call on a host thread of its own, and returns the results in
+;;; stream order.  No collective: a deflate-state is self-contained (deflate.lisp:4-62).
+(defvar *engines* nil "list of tbz_ctx pointers, one per device (OPEN-ENGINES)")
+(defun open-engines (&optional (n (%device-count)))
+  (setf *engines*
+        (loop for d below n
+              collect (cffi:with-foreign-object (p :pointer)
+                        (let ((r (%ctx-create d p)))
+                          (unless (zerop r) (error "tbz_ctx_create(~d): ~a" d (%strerror r)))
+                          (cffi:mem-ref p :pointer))))))
+(defun close-engines ()
+  (mapc #'%ctx-destroy *engines*)
+  (setf *engines* nil))
+
+(defun decompress-vectors (vectors outputs &key (format :zlib))
+  "VECTORS: a list of octet vectors, each one stream.  OUTPUTS: a list of octet vectors to decode them into (as
+DECOMPRESS-VECTOR's :OUTPUT).  Returns the list of counts.  A stream that fails signals what DECOMPRESS-VECTOR signals."
+  (let* ((engines (or *engines* (open-engines)))
+         (n (length vectors)) (k (length engines)) (fmt (format-code format)))
+    (cffi:with-foreign-objects ((ctxs :pointer k) (ins :pointer n) (in-lens :size n) (outs :pointer n) (out-caps :size n)
+                                (res '(:struct tbz-result) n))
+      (loop for e in engines for i from 0 do (setf (cffi:mem-aref ctxs :pointer i) e))
+      ;; every vector stays pinned for the whole call: nested WITH-POINTER-TO-VECTOR-DATA, innermost = the call
+      (labels ((pin (vs os i)
+                 (if (null vs)
+                     (check-call (%inflate-batch-multi ctxs k fmt n ins in-lens outs out-caps res) "tbz_inflate_batch_multi")
+                     (cffi:with-pointer-to-vector-data (pi_ (first vs))
+                       (cffi:with-pointer-to-vector-data (po (first os))
+                         (setf (cffi:mem-aref ins :pointer i) pi_
+                               (cffi:mem-aref in-lens :size i) (length (first vs))
+                               (cffi:mem-aref outs :pointer i) po
+                               (cffi:mem-aref out-caps :size i) (length (first os)))
+                         (pin (rest vs) (rest os) (1+ i)))))))
+        (pin vectors outputs 0))
+      (loop for i below n
+            collect (cffi:with-foreign-slots ((status out-len) (cffi:mem-aptr res '(:struct tbz-result) i)
+                                              (:struct tbz-result))
+                      (when (minusp status) (error "stream ~d: ~a" i (%strerror status)))
+                      (unless (zerop status)
+                        (if (= status 1)
+                            (error "stream ~d: incomplete ~a stream" i format)
+                            (error "stream ~d: not enough space to decompress ~a stream" i format)))
+                      out-len)))))

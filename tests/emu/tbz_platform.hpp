@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 #define TBZ_EMU 1
@@ -189,8 +190,15 @@ inline void trampoline() {
   setcontext(nx == kMain ? &s.main_ctx : &s.fib[nx]);
 }
 // run kernel body `fn` for `grid` workgroups of `threads` (a multiple of 64, up to 1024) lanes, one workgroup after another
+inline std::recursive_mutex& launch_mutex() {
+  static std::recursive_mutex m;
+  return m;
+}
 inline void launch(u32 grid, const std::function<void()>& fn, int threads = 64) {
   if (grid == 0) return;
+  // one emulated launch at a time: the lanes of a workgroup are fibers over process-wide state (tbz_inflate_batch_multi
+  // drives two contexts from two host threads)
+  std::lock_guard<std::recursive_mutex> lock(launch_mutex());
   State& s = st();
   for (int l = 0; l < threads; l++)
     if (!s.stacks[l]) s.stacks[l] = (char*)malloc(kStack);

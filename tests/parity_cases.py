@@ -1043,6 +1043,42 @@ def case_pointer_contexts(eng, n=60_000):
             eng.free(d_in)
 
 
+def multi_context_batch(engines):
+    """tbz_inflate_batch_multi: n streams over several contexts, one host thread each, results in stream order; the
+    assignment is multi.assign_streams's (longest compressed first to the least loaded).  Statuses, counts, checksums
+    and octets are what one context reports for the same streams."""
+    M = importlib.import_module("3bz_amd.multi")
+    rng = random.Random(0x3B6)
+    plains = [K.enwik_like(rng.randrange(1, 200_000), seed=300 + i) for i in range(11)] + [b"", bytes(70_000)]
+    streams = [zlib.compress(p, rng.choice([1, 6, 9])) for p in plains]
+    streams[4] = streams[4][:len(streams[4]) // 2]            # input-underrun
+    streams[7] = streams[7][:40] + b"\xff" + streams[7][41:]  # (most likely) an error
+    caps = [len(p) for p in plains]
+    caps[2] = caps[2] // 3                                     # output-overflow
+    eng = engines[0]
+    sizes = [len(s) for s in streams]
+    for parts in (1, 2, 3, 8):
+        assert eng.assign_streams(sizes, parts) == M.assign_streams(sizes, parts), parts
+    outs1 = [bytearray(c) for c in caps]
+    want = eng.inflate_batch(streams, FMT["zlib"], outs1)
+    outs2 = [bytearray(c) for c in caps]
+    got = T.Engine.inflate_batch_multi(engines, streams, FMT["zlib"], outs2)
+    for i, (w, g) in enumerate(zip(want, got)):
+        assert (w.status, w.out_len, w.out_total, w.adler32, w.in_consumed) == (g.status, g.out_len, g.out_total, g.adler32, g.in_consumed), i
+        assert bytes(outs1[i][:w.out_len]) == bytes(outs2[i][:g.out_len]), i
+        o = oracle_oneshot(streams[i], "zlib", caps[i])
+        if o["flag"] != "error":
+            assert bytes(outs2[i][:g.out_len]) == o["bytes"], i
+    # ... and a single decode straight into device memory (tbz_inflate_to_device)
+    res, d = eng.inflate_to_device(streams[0], FMT["zlib"])
+    try:
+        back = bytearray(len(plains[0]))
+        eng.d2h(back, d)
+        assert res.status == 0 and res.out_len == len(plains[0]) and bytes(back) == plains[0]
+    finally:
+        eng.free(d)
+
+
 ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_reference_chunk_patterns, case_containers_and_levels, case_flush_streams,
              case_noflush_streams, case_block_starts_found, case_close_block_starts, case_fixed_block_chains, case_history_across_groups,
              case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_device_buffers,

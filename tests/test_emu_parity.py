@@ -73,6 +73,18 @@ def test_emu_large_items_handed_to_wide_gangs():
         e.close()
 
 
+def test_emu_batch_over_two_contexts():
+    """tbz_inflate_batch_multi with two (emulated) contexts: LPT assignment in C, a host thread per context"""
+    subprocess.check_call(["make", "-C", EMU_DIR, "libtbz_emu.so"], stdout=subprocess.DEVNULL)
+    T = importlib.import_module("3bz_amd")
+    engines = [T.Engine(0, lib_path=os.path.join(EMU_DIR, "libtbz_emu.so")) for _ in range(2)]
+    try:
+        P.multi_context_batch(engines)
+    finally:
+        for e in engines:
+            e.close()
+
+
 def test_emu_k0b_two_tiles_per_wave():
     """large launches of the K0b validation put two tiles on a wave (32 lanes each): forced here at a small size"""
     T = importlib.import_module("3bz_amd")

@@ -3592,14 +3592,9 @@ TBZ_DEV void k2_resolve(const K2Src& S, u64 pend, u32 rpos, u64 gpos, u32 dofs, 
   if (!LINEAR) {
     // ---- round 0: sources outside the window.  far: wholly in the flushed output; symall: wholly before the group
     const bool symall = SYM && s + (i64)len <= 0;
-#ifdef TBZ_EXP_NOFAR
-    const bool far = false;  // (timing experiment: far sources read as garbage from the ring)
-    const bool odd = mine && !symall && (SYM && s < 0);
-#else
     const bool far = !symall && dist > W::HIST && s >= 0;
     // straddles the group's start (or an invalid stream's distance): one by one
     const bool odd = mine && !symall && !far && (dist > W::HIST || (SYM && s < 0));
-#endif
     const bool wide = len <= K2_SHORT && rd + 32 <= RW;
     const u64 farm = tbz_ballot(mine && far), symm = tbz_ballot(mine && symall), oddm = tbz_ballot(odd);
     if (farm | symm) {

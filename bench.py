@@ -348,6 +348,30 @@ def main(argv=None):
         except Exception:
             pass
 
+    # the issue roof of the decode stage: a kernel of table lookups and bit arithmetic is bound by how many instructions
+    # the SIMDs can issue long before it is bound by HBM.  Like `traffic`, the figure is the last committed counter pass
+    # over the SAME config (tools/pmc_sq.sh -> tools/pmc_issue.py), stamped; null for any other config
+    roof["issue"] = None
+    pmi = os.path.join(ROOT, "profiles", "pmc_issue.json")
+    if os.path.exists(pmi) and world == 1:
+        try:
+            j = json.load(open(pmi))
+            if str(j.get("config", "2")) == cfg and (mib == DEFAULT_MIB[cfg]):
+                ks = {k: v for k, v in j["kernels"].items() if k.startswith(("tbz_k1g", "tbz_k1_huff", "tbz_k2_"))}
+                ins = sum(v["valu"] + v["salu"] + v["lds"] for v in ks.values())
+                slots = sum(v["issue_slots"] for v in ks.values())
+                roof["issue"] = {
+                    "bound": "issue", "unit": "wave-instructions per launch",
+                    "achieved": ins, "peak": slots, "frac": ins / slots if slots else None,
+                    "valu_frac": sum(v["valu"] for v in ks.values()) / slots if slots else None,
+                    "what": "VALU + SALU + LDS wave-instructions issued by the decode-stage kernels / (1024 SIMDs x busy cycles / 4): "
+                            "one instruction per SIMD per quad-cycle; valu_frac = the vector pipe's share alone",
+                    "kernels": {k: {q: v[q] for q in ("issue_frac", "valu_frac", "waves_per_simd", "parked", "issuing")} for k, v in ks.items()},
+                    "source": {q: j.get(q) for q in ("commit", "date", "config", "how")},
+                }
+        except Exception:
+            pass
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and n:
         from oracle import oracle as O

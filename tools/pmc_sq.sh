@@ -1,5 +1,7 @@
 #!/bin/bash
-# usage: tools/pmc_sq.sh <tag> <size-mib> [config] — the three SQ counter passes only (instruction mix, waits, LDS)
+# usage: tools/pmc_sq.sh <tag> <size-mib> [config] [commit] — the three SQ counter passes only (instruction mix, waits, LDS)
+# -> gpurun_out/pmc_<tag>.txt (every counter per kernel) and gpurun_out/pmc_issue_<tag>.json (the issue roof: bench.py reads
+#    profiles/pmc_issue.json)
 TAG=$1; SZ=${2:-1024}; CFG=${3:-2}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
@@ -12,4 +14,4 @@ for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C -d $R/gpurun_out/pmc_${TAG}_$i -o p -- python3 $R/bench.py --config $CFG --corpus-cache /tmp/tbz_corpus --steps 1 --warmup 1 --size-mib $SZ --no-cpu-baseline > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1 || { echo "pass $i failed"; tail -3 $R/gpurun_out/pmc_${TAG}_$i.log; }
 done
 python3 $R/tools/pmc_summary.py "$R/gpurun_out/pmc_${TAG}_*/*.db" > $R/gpurun_out/pmc_${TAG}.txt 2>&1
-grep -A30 "k1" $R/gpurun_out/pmc_${TAG}.txt | head -40
+python3 $R/tools/pmc_issue.py "$R/gpurun_out/pmc_${TAG}_*/*.db" $R/gpurun_out/pmc_issue_${TAG}.json $CFG ${4:-unknown} $(date -u +%Y-%m-%d)

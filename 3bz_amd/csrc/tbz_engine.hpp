@@ -66,6 +66,7 @@ struct tbz_ctx {
     int slice = 0, h_join = 0, k6_block = 0;
     long k0c_max_block = 0;
     bool k6_two_levels = false, no_fused_adler = false, debug = false, debug2 = false;
+    bool tok_full = false;    // token pools of one word per input bit for the gang kernels too (TBZ_TOK_FULL=1; default: per two)
     std::string debug_cands;
   } tun;
   int find_mode = 1;  // K0b block-start finder: 0 never, 1 for streams whose items are large (default), 2 for every stream
@@ -75,6 +76,8 @@ struct tbz_ctx {
       d_tok, d_scratch, d_runs, d_segs, d_groups, d_order, d_k3_fi, d_k3_ni, d_k3_oo, d_k3_oc, d_k3_sums, d_k3_flags,
       d_k3_gscan, d_k3_gne, d_k3_streams, d_k3_glob, d_redo_items, d_redo_res, d_k0_slots, d_k0_fm, d_hdr, d_gck, d_gchunks, d_ck_l1, d_tok2, d_runs2, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
       d_out_stage, d_kb_tf, d_kb_slots, d_kb_counts, d_kb_offsets, d_kb_cands, d_kb_fc, d_kb_head, d_markers2, d_kb_fm2, d_mark, d_hg, d_k6s, d_bigs, d_recs, d_kc_tf, d_kc_slots, d_kc_ends, d_kc_link, d_kc_fm2, d_markers3, d_kb_keep, d_kb_kcounts, d_gz_cands, d_gz_count, d_gz_tmp;
+  std::vector<tbz::DevBuf> dense;  // token regions of items the one-lane kernel decoded again (SEG_REDO, probes): one word per
+                                   // bit of those items only; released when the next call starts
 };
 
 namespace tbz {
@@ -93,11 +96,16 @@ static std::vector<DevBuf*> all_pools(tbz_ctx* ctx) {
           &ctx->d_kc_slots, &ctx->d_kc_ends, &ctx->d_kc_link, &ctx->d_kc_fm2, &ctx->d_markers3, &ctx->d_kb_keep,
           &ctx->d_kb_kcounts, &ctx->d_gz_cands, &ctx->d_gz_count, &ctx->d_gz_tmp};
 }
+static uint64_t dense_total(tbz_ctx* ctx) {
+  uint64_t t = 0;
+  for (const DevBuf& b : ctx->dense) t += b.cap;
+  return t;
+}
 static uint64_t scratch_total(tbz_ctx* ctx) {
   uint64_t t = 0;
   for (DevBuf* b : all_pools(ctx))
     if (b != &ctx->d_in_stage && b != &ctx->d_out_stage) t += b->cap;
-  return t;
+  return t + dense_total(ctx);
 }
 
 #define TBZ_HIP(call)                                                                       \
@@ -114,7 +122,7 @@ static int ensure(tbz_ctx* ctx, DevBuf& b, size_t bytes) {
   if (b.p) TBZ_HIP(hipFree(b.p));
   b.p = nullptr;
   b.cap = 0;
-  size_t want = bytes + bytes / 8 + 256;
+  size_t want = bytes + std::min<size_t>(bytes / 8, 32u << 20) + 256;  // (some room to grow into; a large pool is sized exactly)
   hipError_t e = hipMalloc(&b.p, want);
   if (e != hipSuccess) {
     ctx->err = std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e);
@@ -448,7 +456,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if ((r = pinned(ctx, (n + 4) * 4 + sizeof(K3Global) + (n + 1) * sizeof(K3Stream)))) return r;
     for (size_t s = 0; s < n; s++) {
       StreamPlan& S = sp[s];
-      Item it;
+      Item it{};
       it.start_bit = S.in_off * 8 + (s == 0 ? bit_off : 0);
       it.limit_bit = ~0ull;
       it.end_byte = S.in_off + S.in_len;
@@ -669,16 +677,22 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   };
   if ((r = record(ctx, 1))) return r;
 
-  // token pool: one u16 per input bit (K1 never writes more words than bits consumed); run tables: one 16-octet slot
-  // per 2^RUN_SHIFT input bits.  Both are addressed by bit position RELATIVE to the first stream octet of the call
-  // (pool_base: a batch that is a window into a large buffer pays for its own extent only); the repair launches'
-  // pools cover the repaired streams' tails only (pool2_base).
+  // token pool: one u16 per TWO input bits where gangs decode (a token of ordinary data takes eight bits and more; a
+  // lane whose region fills up ends its run early and an item that does not fit is declined — SEG_REDO — and decoded
+  // again by one lane into a region of its own: `dense`), one per bit where the one-lane kernel does (K1 never writes
+  // more words than bits consumed); run tables: one 16-octet slot per 2^RUN_SHIFT input bits.  Both are addressed by
+  // bit position RELATIVE to the first stream octet of the call (pool_base: a batch that is a window into a large
+  // buffer pays for its own extent only); the repair launches' pools cover the repaired streams' tails only (pool2_base).
   if (in_lo > in_extent) in_lo = in_extent;
   const uint64_t pool_base = (in_lo * 8) & ~(uint64_t)((1u << RUN_SHIFT) - 1);  // bits
   const uint64_t pool_bits = in_extent * 8 - pool_base;
   uint64_t pool2_base = pool_base, pool2_hi = 0;
-  if ((r = ensure(ctx, ctx->d_tok, (size_t)pool_bits * 2 + 256))) return r;
-  if ((r = ensure(ctx, ctx->d_runs, ((size_t)pool_bits >> RUN_SHIFT) * sizeof(RunRec) + 1024))) return r;
+  u32 half1 = 0, half2 = 0;  // log2 of the input bits per token word of the call's pool / the repair pool
+  if (!ctx->dense.empty()) {  // (the last call's; rare)
+    for (DevBuf& b : ctx->dense)
+      if (b.p) hipFree(b.p);
+    ctx->dense.clear();
+  }
   if ((r = ensure(ctx, ctx->d_res, n_items * sizeof(SegResult)))) return r;
   // K1 flavour.  One lane per item is bound by ONE item's serial chain (~1.1 us per token) and decodes
   // without lookup tables; a gang of G lanes shares one item and one set of LDS tables.  G follows the
@@ -692,6 +706,34 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     while (G < 64 && avg_bits > (uint64_t)G * 3072) G <<= 1;
     return G;
   };
+  half1 = (k1_gang(n_items) == 1 || ctx->tun.tok_full) ? 0u : 1u;
+  if ((r = ensure(ctx, ctx->d_tok, ((size_t)pool_bits >> half1) * 2 + 256))) return r;
+  if ((r = ensure(ctx, ctx->d_runs, ((size_t)pool_bits >> RUN_SHIFT) * sizeof(RunRec) + 1024))) return r;
+  // regions of their own for items that are decoded again: one word per bit of each item, and a run table
+  auto make_explicit = [&](std::vector<Item>& its) -> int {
+    uint64_t words = 0, slots = 0;
+    std::vector<uint64_t> at(its.size()), rat(its.size());
+    for (size_t k = 0; k < its.size(); k++) {
+      const Item& q = its[k];
+      const uint64_t hi = (q.flags & ITEM_FIXUP) ? q.end_byte * 8 : std::min(q.limit_bit, q.end_byte * 8);
+      const uint64_t span = hi > q.start_bit ? hi - q.start_bit : 0;
+      at[k] = words;
+      rat[k] = slots;
+      words += (span + 64 + 7) & ~7ull;
+      slots += (span >> RUN_SHIFT) + 2;
+    }
+    ctx->dense.emplace_back();
+    int rr = ensure(ctx, ctx->dense.back(), (size_t)words * 2 + (size_t)slots * sizeof(RunRec) + 256);
+    if (rr) return rr;
+    u16* tk = (u16*)ctx->dense.back().p;
+    RunRec* rn = (RunRec*)(tk + words);  // (words is a multiple of 8: 16-octet aligned)
+    for (size_t k = 0; k < its.size(); k++) {
+      its[k].flags |= ITEM_EXPLICIT;
+      its[k].tok = (uint64_t)(tk + at[k]);
+      its[k].runs = (uint64_t)(rn + rat[k]);
+    }
+    return 0;
+  };
   auto items_per_wg = [](size_t n_it) {  // lane-per-item flavour: spread few items over all CUs
     u32 ipw = 64;
     while (ipw > 1 && n_it / ipw < 512) ipw >>= 1;
@@ -700,11 +742,16 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   // Repair (fix-up) launches decode into pools of their own: a gang that repairs an item runs past the marker
   // it will land on, into the bit range of items whose tokens (position-addressed!) are already in place.
   // (kernels index the pools by absolute bit position: the pointers handed to them are shifted down by the pool's base)
-  auto pool_tok = [&](bool fix) { return fix ? (u16*)ctx->d_tok2.p - pool2_base : (u16*)ctx->d_tok.p - pool_base; };
+  auto pool_half = [&](bool fix) { return fix ? half2 : half1; };
+  auto pool_tok = [&](bool fix) {
+    return fix ? (u16*)ctx->d_tok2.p - ((pool2_base >> half2) & ~7ull) : (u16*)ctx->d_tok.p - ((pool_base >> half1) & ~7ull);
+  };
   auto pool_runs = [&](bool fix) {
     return fix ? (RunRec*)ctx->d_runs2.p - (pool2_base >> RUN_SHIFT) : (RunRec*)ctx->d_runs.p - (pool_base >> RUN_SHIFT);
   };
-  auto launch_lane = [&](const Item* d_items, SegResult* d_res, size_t n_it, bool fix) -> int {
+  // (the one-lane kernel writes one word per bit at most: its items live in a pool of that density, or bring their own regions)
+  auto launch_lane = [&](const Item* d_items, SegResult* d_res, size_t n_it, bool fix, bool explicit_items = false) -> int {
+    if (pool_half(fix) && !explicit_items) return TBZ_E_INTERNAL;
     int rr = ensure(ctx, ctx->d_scratch, n_it * (size_t)K1_SCRATCH);
     if (rr) return rr;
     K1Params k1{(const u8*)d_in, pool_tok(fix), d_items, d_res, d_markers_cur,
@@ -732,8 +779,10 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     // the 64 MiB no-flush stream 2.78 -> 1.56 ms, on config 3 8.96 -> 6.05 ms); gangs of 32 are flat from 512 to 768
     return G >= 64 ? 1024u : KG_OVL;
   };
-  // items the gang kernel declined (SEG_REDO: token stream as dense as the bitstream, run table full) are
-  // decoded again by the one-lane kernel, which writes one contiguous run
+  // items the gang kernel declined (SEG_REDO: more token words than the pool has for their bits — long runs of one
+  // octet code that way —, run table full) are decoded again into regions of their own: by gangs of 64 where the pool
+  // holds one word per two bits, and what those decline, or all of them, by the one-lane kernel, which writes one
+  // contiguous run
   auto redo = [&](const std::vector<Item>& its, std::vector<SegResult>& rs, bool fix) -> int {
     {  // items a narrow gang handed back (SEG_WIDE): gangs of 64, the leader parsing the first header itself
       std::vector<Item> wide;
@@ -752,7 +801,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         int rr;
         if ((rr = upload(ctx, ctx->d_redo_items, wide))) return rr;
         if ((rr = ensure(ctx, ctx->d_redo_res, wide.size() * sizeof(SegResult)))) return rr;
-        K1gParams kg{(const u8*)d_in, pool_tok(fix), pool_runs(fix), (const Item*)ctx->d_redo_items.p,
+        K1gParams kg{(const u8*)d_in, pool_tok(fix), pool_runs(fix), pool_half(fix), 0, (const Item*)ctx->d_redo_items.p,
                      (SegResult*)ctx->d_redo_res.p, d_markers_cur, d_first_marker, nullptr, nullptr, (u32)n_mark,
                      (u32)wide.size(), ovl_for(64), sub_min_for(64), 0, resume_abs};
 #ifdef TBZ_WAVE_TRACE
@@ -775,11 +824,43 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         idx.push_back(i);
       }
     if (sub.empty()) return 0;
+    if (pool_half(fix) && !ctx->k1_mode) {
+      if (ctx->tun.debug) fprintf(stderr, "tbz: %zu item(s) decoded again into regions of their own\n", sub.size());
+      int rr;
+      if ((rr = make_explicit(sub))) return rr;
+      if ((rr = upload(ctx, ctx->d_redo_items, sub))) return rr;
+      if ((rr = ensure(ctx, ctx->d_redo_res, sub.size() * sizeof(SegResult)))) return rr;
+      K1gParams kg{(const u8*)d_in, nullptr, nullptr, 0, 0, (const Item*)ctx->d_redo_items.p,
+                   (SegResult*)ctx->d_redo_res.p, d_markers_cur, d_first_marker, nullptr, nullptr, (u32)n_mark,
+                   (u32)sub.size(), ovl_for(64), sub_min_for(64), 0, resume_abs};
+#ifdef TBZ_WAVE_TRACE
+      kg.trace = nullptr;
+#endif
+      TBZ_LAUNCH(tbz_k1g64_huff_decode, sub.size(), ctx->stream, kg);
+      std::vector<SegResult> tmp(sub.size());
+      TBZ_HIP(hipMemcpyAsync(tmp.data(), ctx->d_redo_res.p, tmp.size() * sizeof(SegResult), hipMemcpyDeviceToHost,
+                             ctx->stream));
+      TBZ_HIP(hipStreamSynchronize(ctx->stream));
+      ctx->tim.huff_launches++;
+      std::vector<Item> sub2;
+      std::vector<size_t> idx2;
+      for (size_t k = 0; k < idx.size(); k++) {
+        rs[idx[k]] = tmp[k];
+        if (tmp[k].status == SEG_REDO) {
+          sub2.push_back(its[idx[k]]);
+          idx2.push_back(idx[k]);
+        }
+      }
+      sub.swap(sub2);
+      idx.swap(idx2);
+      if (sub.empty()) return 0;
+    }
     if (ctx->tun.debug) fprintf(stderr, "tbz: %zu item(s) redone by the one-lane kernel\n", sub.size());
     int rr;
+    if ((rr = make_explicit(sub))) return rr;
     if ((rr = upload(ctx, ctx->d_redo_items, sub))) return rr;
     if ((rr = ensure(ctx, ctx->d_redo_res, sub.size() * sizeof(SegResult)))) return rr;
-    if ((rr = launch_lane((const Item*)ctx->d_redo_items.p, (SegResult*)ctx->d_redo_res.p, sub.size(), fix))) return rr;
+    if ((rr = launch_lane((const Item*)ctx->d_redo_items.p, (SegResult*)ctx->d_redo_res.p, sub.size(), fix, true))) return rr;
     std::vector<SegResult> tmp(sub.size());
     TBZ_HIP(hipMemcpyAsync(tmp.data(), ctx->d_redo_res.p, tmp.size() * sizeof(SegResult), hipMemcpyDeviceToHost,
                            ctx->stream));
@@ -790,6 +871,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   };
   auto launch_k1 = [&](const Item* d_items, SegResult* d_res, size_t n_it, bool fix) -> int {
     int G = k1_gang(n_it);
+    if (G == 1 && pool_half(fix)) G = 8;  // (a repair launch of many small items into a pool laid out for gangs)
     if (!fix) ctx->tim.k1_gang = (uint32_t)G;
     if (G == 1) return launch_lane(d_items, d_res, n_it, fix);
     size_t per = 64 / G, nwg = (n_it + per - 1) / per;
@@ -800,7 +882,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if ((rr = ensure(ctx, ctx->d_hdr, n_it * sizeof(HdrRec)))) return rr;
     K1hParams kh{(const u8*)d_in, d_items, (u8*)ctx->d_scratch.p, (HdrRec*)ctx->d_hdr.p, (u32)n_it};
     if (ctx->k1h) TBZ_LAUNCH(tbz_k1h_headers, (n_it + 63) / 64, ctx->stream, kh);
-    K1gParams kg{(const u8*)d_in, pool_tok(fix), pool_runs(fix), d_items, d_res,
+    K1gParams kg{(const u8*)d_in, pool_tok(fix), pool_runs(fix), pool_half(fix), 0, d_items, d_res,
                  d_markers_cur, d_first_marker, ctx->k1h ? (const HdrRec*)ctx->d_hdr.p : nullptr,
                  (const u8*)ctx->d_scratch.p, (u32)n_mark, (u32)n_it, ovl_for(G), sub_min_for(G), wide_for(G, fix), resume_abs};
 #ifdef TBZ_WAVE_TRACE
@@ -936,7 +1018,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       if (!d_out) return TBZ_E_ARG;
       const u32 n_it = (u32)n_items;
       fused_adler = format == TBZ_FORMAT_ZLIB && !ctx->k2_single && h_glob->n_big == 0 && !ctx->tun.no_fused_adler;
-      K2Params k2{pool_tok(false), pool_runs(false), nullptr, nullptr, (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, nullptr,
+      K2Params k2{(const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, nullptr,
                   (const u8*)d_in, (u8*)d_out, n_it, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0};
       if (h_glob->n_big < n_it) {
         k2.win_bytes = (u32)((h_glob->max_small + K2_SLACK + 63) & ~63ull);
@@ -1028,13 +1110,13 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   auto consume = [&](StreamPlan& S, size_t s, const Item& it, const SegResult& q, bool is_fixup) {
     SegHost h;
     h.item = it;
-    h.seg.tok_index = it.start_bit;
+    h.seg.tok = q.tok;
     h.seg.tok_words = q.tok_words;
     h.seg.out_bytes = q.out_bytes;
     h.seg.n_runs = q.n_runs;
-    h.seg.pool = is_fixup ? 1u : 0u;
     h.seg.run_first = 0;
-    h.seg.pad = 0;
+    h.seg.runs = q.runs;
+    h.seg.run0 = q.run0;
     h.stream = (uint32_t)s;
     h.deficit = q.max_deficit;
     h.continues = S.next_continues;
@@ -1113,7 +1195,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     std::vector<size_t> fix_stream;
     for (size_t s = 0; s < n; s++)
       if (sp[s].pending_fixup && !sp[s].done) {
-        Item it;
+        Item it{};
         it.start_bit = sp[s].fix_start_bit;
         it.limit_bit = ~0ull;
         it.end_byte = sp[s].in_off + sp[s].in_len;
@@ -1146,7 +1228,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         if (pool2_hi != 0) return TBZ_E_INTERNAL;
         pool2_hi = in_extent * 8;
         const uint64_t bits2 = pool2_hi - pool2_base;
-        if ((r = ensure(ctx, ctx->d_tok2, (size_t)bits2 * 2 + 256))) return r;
+        half2 = (k1_gang(fix.size()) == 1 || ctx->tun.tok_full) ? 0u : 1u;
+        if ((r = ensure(ctx, ctx->d_tok2, ((size_t)bits2 >> half2) * 2 + 256))) return r;
         if ((r = ensure(ctx, ctx->d_runs2, ((size_t)bits2 >> RUN_SHIFT) * sizeof(RunRec) + 1024))) return r;
       }
     }
@@ -1190,7 +1273,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   uint64_t dist_at = ~0ull;  // (sessions: one stream)
   {
     struct Probe { size_t s, seg; uint64_t before; };
-    std::vector<Probe> probes[2];  // per token pool
+    std::vector<Probe> probes[1];
     for (size_t s = 0; s < n; s++) {
       uint64_t produced = 0;
       const uint64_t hist = s == 0 ? hist_len : 0;  // (a resumed stream: octets of earlier output that are there to copy from)
@@ -1198,26 +1281,26 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         const SegHost& h = per_stream[s][i];
         if (h.deficit && (uint64_t)h.deficit > produced + hist) {
           const uint64_t end = produced + h.seg.out_bytes, cap = sp[s].out_cap;
-          if (opt && opt->prefix_on_error) probes[h.seg.pool & 1].push_back({s, i, produced + hist});  // (a session wants the place)
+          if (opt && opt->prefix_on_error) probes[0].push_back({s, i, produced + hist});  // (a session wants the place)
           else if (cap >= end) dist_first[s] = DIST_FIRST;
           else if (cap < produced) dist_first[s] = DIST_AFTER_OVERFLOW;
-          else probes[h.seg.pool & 1].push_back({s, i, produced + hist});
+          else probes[0].push_back({s, i, produced + hist});
           break;
         }
         produced += h.seg.out_bytes;
       }
     }
-    for (int pool = 0; pool < 2; pool++) {
-      auto& pv = probes[pool];
-      if (pv.empty()) continue;
+    if (!probes[0].empty()) {
+      auto& pv = probes[0];
       std::vector<Item> its(pv.size());
       for (size_t k = 0; k < pv.size(); k++) {
         its[k] = per_stream[pv[k].s][pv[k].seg].item;
         its[k].flags |= ITEM_PROBE | ((uint32_t)std::min<uint64_t>(pv[k].before, 65535) << ITEM_HIST_SHIFT);  // < 32768: the item's reach-back exceeds it
       }
+      if ((r = make_explicit(its))) return r;
       if ((r = upload(ctx, ctx->d_redo_items, its))) return r;
       if ((r = ensure(ctx, ctx->d_redo_res, its.size() * sizeof(SegResult)))) return r;
-      if ((r = launch_lane((const Item*)ctx->d_redo_items.p, (SegResult*)ctx->d_redo_res.p, its.size(), pool == 1))) return r;
+      if ((r = launch_lane((const Item*)ctx->d_redo_items.p, (SegResult*)ctx->d_redo_res.p, its.size(), false, true))) return r;
       std::vector<SegResult> pr(its.size());
       TBZ_HIP(hipMemcpyAsync(pr.data(), ctx->d_redo_res.p, pr.size() * sizeof(SegResult), hipMemcpyDeviceToHost,
                              ctx->stream));
@@ -1226,8 +1309,10 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       for (size_t k = 0; k < pv.size(); k++) {
         SegHost& h = per_stream[pv[k].s][pv[k].seg];
         // the item's tokens are now the one-lane kernel's (same octets, one run)
+        h.seg.tok = pr[k].tok;
         h.seg.tok_words = pr[k].tok_words;
         h.seg.n_runs = pr[k].n_runs;
+        h.seg.run0 = pr[k].run0;
         const uint64_t at = pr[k].reserved;  // octets into the item; ~0: none found (cannot happen)
         const uint64_t hist_k = pv[k].s == 0 ? hist_len : 0;
         dist_first[pv[k].s] = (at != ~0ull && pv[k].before - hist_k + at > sp[pv[k].s].out_cap) ? DIST_AFTER_OVERFLOW : DIST_FIRST;
@@ -1371,7 +1456,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if (!bigs.empty()) {
       if ((r = upload(ctx, ctx->d_bigs, bigs))) return r;
       if ((r = ensure(ctx, ctx->d_recs, (size_t)n_recs * sizeof(SliceRec)))) return r;
-      K3sParams ks{(const BigSeg*)ctx->d_bigs.p, pool_runs(false), pool_runs(true),
+      K3sParams ks{(const BigSeg*)ctx->d_bigs.p,
                    (Seg*)ctx->d_segs.p, (Group*)ctx->d_groups.p, (SliceRec*)ctx->d_recs.p, (u32)bigs.size()};
       TBZ_LAUNCH(tbz_k3_slice, bigs.size(), ctx->stream, ks);
       TBZ_HIP(hipMemcpyAsync(recs.data(), ctx->d_recs.p, (size_t)n_recs * sizeof(SliceRec), hipMemcpyDeviceToHost, ctx->stream));
@@ -1418,8 +1503,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     order.insert(order.end(), order_h.begin(), order_h.end());
     ctx->tim.n_groups = order.size();
     if ((r = upload(ctx, ctx->d_order, order))) return r;
-    K2Params k2{pool_tok(false), pool_runs(false), pool_tok(true), pool_runs(true),
-                (const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, (const u32*)ctx->d_order.p, (const u8*)d_in, (u8*)d_out, 0, 0, 0, nullptr, nullptr,
+    K2Params k2{(const Seg*)ctx->d_segs.p, (const Group*)ctx->d_groups.p, (const u32*)ctx->d_order.p, (const u8*)d_in, (u8*)d_out, 0, 0, 0, nullptr, nullptr,
                 0, 0, 0, 0, 0, nullptr, 0};
     if (!order_small.empty()) {
       k2.n_groups = (u32)order_small.size();
@@ -1755,6 +1839,7 @@ int tbz_ctx_create(int device_id, tbz_ctx** out_ctx) {
     if (const char* m = getenv("TBZ_K0C_MAX_BLOCK")) t.k0c_max_block = atol(m);
     t.k6_two_levels = getenv("TBZ_K6_TWO_LEVELS") != nullptr;
     t.no_fused_adler = getenv("TBZ_NO_FUSED_ADLER") != nullptr;
+    t.tok_full = getenv("TBZ_TOK_FULL") != nullptr;
     t.debug = getenv("TBZ_DEBUG") != nullptr;
     t.debug2 = getenv("TBZ_DEBUG2") != nullptr;
     if (const char* m = getenv("TBZ_DEBUG_CANDS")) t.debug_cands = m;
@@ -1782,6 +1867,8 @@ void tbz_ctx_destroy(tbz_ctx* ctx) {
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   for (auto* b : tbz::all_pools(ctx))
     if (b->p) hipFree(b->p);
+  for (auto& b : ctx->dense)
+    if (b.p) hipFree(b.p);
   if (ctx->h_pin) hipHostFree(ctx->h_pin);
   for (auto& ev : ctx->ev)
     if (ev) hipEventDestroy(ev);
@@ -1798,12 +1885,12 @@ int tbz_last_timings(const tbz_ctx* ctx, tbz_timings* out) {
 }
 
 // the pipeline over a batch, in as many passes over consecutive streams as the pool cap asks for (scratch is
-// 20 octets per input octet of a pass's extent; one stream is never split: its segments share one token pool)
+// 9 octets per input octet of a pass's extent; one stream is never split: its segments share one token pool)
 static int inflate_passes(tbz_ctx* ctx, int format, size_t n, const void* d_in, const uint64_t* in_offs,
                           const uint64_t* in_lens, void* d_out, const uint64_t* out_offs, const uint64_t* out_caps,
                           tbz_result* results, bool size_only) {
   if (!ctx || (n && (!in_offs || !in_lens))) return TBZ_E_ARG;
-  auto need = [&](uint64_t lo, uint64_t hi) { return (hi - lo) * 20; };
+  auto need = [&](uint64_t lo, uint64_t hi) { return (hi - lo) * 9; };
   uint64_t lo = ~0ull, hi = 0;
   for (size_t s = 0; s < n; s++)
     if (in_lens[s]) {

@@ -1153,11 +1153,13 @@ static_assert(sizeof(K1Lds) <= 32 * 1024, "five K1 workgroups must fit one CU's 
 struct K1Params {
   const u8* in_base;
   u16* tok;       // token pool: item tokens start at tok[item.start_bit]; words written never exceed bits consumed
+                  // (this kernel's items either live in a pool of one word per bit, or bring their own region: ITEM_EXPLICIT)
   const Item* items;
   SegResult* res;
   const u64* markers;
   u8* scratch;    // n_items * K1_SCRATCH octets
-  RunRec* runs;   // run tables (one run per item here: the lane writes its tokens contiguously)
+  RunRec* runs;   // run tables (one run per item here — the lane writes its tokens contiguously — which is SegResult::run0:
+                  // the table is only named in the result)
   const u32* first_marker;  // [n_streams+1]: a stream's markers are markers[first_marker[s] .. first_marker[s+1])
   u32 n_markers;
   u32 n_items;
@@ -1703,7 +1705,8 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
   st.limit_bit = fixup ? ~0ull : it.limit_bit;
   st.produced = 0;
   st.deficit = 0;
-  st.tok0 = P.tok + (it.start_bit & ~7ull);  // token base: the 8-word granule of the start (fix-up items start mid-octet)
+  // token base: the 8-word granule of the start (fix-up items start mid-octet)
+  st.tok0 = (it.flags & ITEM_EXPLICIT) ? (u16*)it.tok : P.tok + (it.start_bit & ~7ull);
   st.tok = st.tok0;
   st.fail_pos = it.start_bit;
   st.hist0 = it.flags >> ITEM_HIST_SHIFT;
@@ -1827,14 +1830,12 @@ TBZ_KERNEL void tbz_k1_huff_decode(K1Params P) {
   // item consumes at least 7 bits more than it has token words)
   const u64 T8 = (TW + 7) >> 3;
   for (u64 k = TW; k < T8 * 8; k++) st.tok0[k] = (u16)TOK_NOP;
-  if (T8) {
-    RunRec rr;
-    rr.off8 = 0;
-    rr.n8 = (u32)T8;
-    rr.out = r.out_bytes > 0xfffffffeull ? 0xffffffffu : (u32)r.out_bytes;
-    rr.mdef = st.deficit;
-    P.runs[it.start_bit >> RUN_SHIFT] = rr;
-  }
+  r.run0.off8 = 0;
+  r.run0.n8 = (u32)T8;
+  r.run0.out = r.out_bytes > 0xfffffffeull ? 0xffffffffu : (u32)r.out_bytes;
+  r.run0.mdef = st.deficit;
+  r.tok = (u64)st.tok0;
+  r.runs = (u64)(P.runs + (it.start_bit >> RUN_SHIFT));
   r.tok_words = T8 * 8;
   r.n_runs = T8 ? 1u : 0u;
   r.pad = (status == SEG_UNDERRUN && st.fail_pos == blk_pos) ? 1u : status == SEG_UNDERRUN ? cut : 0u;
@@ -1979,6 +1980,7 @@ struct GangState {  // per gang, in LDS; owned by the leader
   i32 status;
   u32 mode, bfinal, deficit, tables, land, tr0, tr1, tr_have;
   u32 nruns, blk_runs;      // runs recorded so far / at the start of the current block
+  RunRec run0;              // the item's first run (the others are in its run table)
   u32 hlit, hdist, fixed;   // GM_BUILD: alphabet sizes; fixed: 1 the lanes write the fixed code lengths first,
                             //   2 they copy the lengths K1h left in the item's scratch
   u32 rounds, valid_lanes;  // diagnostics: rounds run and lanes committed (efficiency = valid_lanes / (G*rounds))
@@ -2006,8 +2008,12 @@ struct KgLds {
 
 struct K1gParams {
   const u8* in_base;
-  u16* tok;       // token pool (as K1Params::tok): lane g of a round writes its run at tok[s_g & ~7 ...]
+  u16* tok;       // token pool: the word index of bit position x is (x >> half) & ~7 — lane g of a round writes its run
+                  // from tok[slot(s_g)]
   RunRec* runs;   // run tables
+  u32 half;       // 1: the pool holds one word per TWO input bits (a token of ordinary data takes far more; a lane whose
+                  // region fills up ends its run early, and an item that does not fit is declined: SEG_REDO); 0: per bit
+  u32 pad0;
   const Item* items;
   SegResult* res;
   const u64* markers;
@@ -2770,6 +2776,22 @@ TBZ_DEV bool kg_periodic(const BitReader& b, u64 x0, u64 x1, u32 T, u64 lim64) {
 
 // run-table slots an item may use once it has consumed the bitstream up to `upto`: the table is
 // position-addressed, so it must not grow into the slots of whatever starts after it
+// where an item's tokens and run table live: in the launch's pools by position, or in a region of its own
+struct ItemPool {
+  u16* tok;      // token base: the 8-word granule of the start's slot (fix-up items start mid-octet)
+  RunRec* runs;  // run table (entry 0 unused: GangState::run0)
+  u32 half;      // log2 of the input bits per token word
+  u64 slot0;     // word index of the item's start; a bit position x lives at tok[((x >> half) & ~7) - slot0]
+};
+TBZ_DEV ItemPool kg_item_pool(const Item& it, const K1gParams& P) {
+  ItemPool ip;
+  const bool own = (it.flags & ITEM_EXPLICIT) != 0;
+  ip.half = own ? 0u : P.half;
+  ip.slot0 = (it.start_bit >> ip.half) & ~7ull;
+  ip.tok = own ? (u16*)it.tok : P.tok + ip.slot0;
+  ip.runs = own ? (RunRec*)it.runs : P.runs + (it.start_bit >> RUN_SHIFT);
+  return ip;
+}
 TBZ_DEV u32 kg_run_slots(const Item& it, u64 upto) {
   const u64 s = (upto - it.start_bit) >> RUN_SHIFT;
   return s < 1 ? 1u : (s > 0x7fffffffull ? 0x7fffffffu : (u32)s);
@@ -2862,8 +2884,11 @@ TBZ_DEV void kg_leader_header(GangTables& gt, GangState& gs, K1State& st, const 
     if (ncopy) {
       // a run of its own: one 8-word piece at the first granule at or after the block header (the block
       // is at least 35 bits long, so the piece ends before anything that follows can start)
-      const u64 x = ((gs.blk_pos - (it.start_bit & ~7ull)) + 7) & ~7ull;
-      if (gs.nruns + 1 > kg_run_slots(it, byte0 * 8)) { gs.status = SEG_REDO; gs.mode = GM_DONE; return; }
+      // (a pool of one word per two bits: a block of a few octets is too short for that — the item is declined)
+      const ItemPool ip = kg_item_pool(it, P);
+      const u64 x = (((gs.blk_pos >> ip.half) - ip.slot0) + 7) & ~7ull;
+      const bool room = x + 8 <= ((((byte0 + ncopy) * 8) >> ip.half) & ~7ull) - ip.slot0;
+      if (!room || gs.nruns + 1 > kg_run_slots(it, byte0 * 8)) { gs.status = SEG_REDO; gs.mode = GM_DONE; return; }
       u16* t = tok0 + x;
       t[0] = (u16)(TOK_STORED | (ncopy & 0x3fff));
       t[1] = (u16)((ncopy >> 14) | ((u32)(byte0 & 0x1fff) << 2));
@@ -2875,7 +2900,7 @@ TBZ_DEV void kg_leader_header(GangTables& gt, GangState& gs, K1State& st, const 
       rr.n8 = 1;
       rr.out = ncopy;
       rr.mdef = 0;
-      (P.runs + (it.start_bit >> RUN_SHIFT))[gs.nruns] = rr;
+      if (gs.nruns == 0) gs.run0 = rr; else ip.runs[gs.nruns] = rr;
       gs.nruns += 1;
       gs.T += 8;
       gs.produced += ncopy;
@@ -2938,7 +2963,10 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
   if (have) it = P.items[idx];
   const u32 fmt = (it.flags >> ITEM_FMT_SHIFT) & 3;
   const bool fixup = (it.flags & ITEM_FIXUP) != 0;
-  u16* tok0 = P.tok + (it.start_bit & ~7ull);  // token base: the 8-word granule of the start (fix-up items start mid-octet)
+  const ItemPool ip = kg_item_pool(it, P);
+  const u32 half = ip.half;
+  const u64 slot0 = ip.slot0;
+  u16* tok0 = ip.tok;
   K1State st;
   br_init(st.br, P.in_base, it.end_byte, S.inbuf);
   st.end_bit = it.end_byte * 8;
@@ -3026,6 +3054,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     gs.tr0 = gs.tr1 = gs.tr_have = 0;
     gs.hlit = gs.hdist = gs.fixed = 0;
     gs.nruns = gs.blk_runs = 0;
+    gs.run0 = RunRec{};
     gs.rounds = gs.valid_lanes = 0;
     gs.inl = gs.noinline = 0;
     gs.ptry = 0;
@@ -3116,7 +3145,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     // consecutive fixed-Huffman blocks are decoded through (not by repair items: they land on a marker after EVERY block)
     const bool inl_on = inblk && gs.tables == 1 && !fixup && !gs.noinline;
     u16* stage = P.tok;
-    u64 s_lo = 0;  // token-pool index of this lane's region
+    u64 s_lo = 0;  // this lane's region: words from the item's token base
     // sub-range per lane: what is left of the item split evenly (the next marker is where it should end)
     u32 sub = P.sub_min;
     if (inblk) {
@@ -3146,12 +3175,12 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     }
     if (inblk) {
       const u64 start = g == 0 ? Pb : pstart ? pstart : (s_g - Pb > P.ovl ? s_g - P.ovl : Pb);
-      s_lo = s_g & ~7ull;
-      stage = P.tok + s_lo;  // private region of the token pool: [s_g & ~7, (s_g + sub) & ~7), 16-octet aligned
+      s_lo = ((s_g >> half) & ~7ull) - slot0;
+      stage = tok0 + s_lo;  // private region of the token pool: [slot(s_g), slot(s_g + sub)), 16-octet aligned
       Inl il;
       il.on = inl_on;
       il.cur_bf = g == 0 ? (i32)gs.bfinal : -1;
-      kg_lane_round(gt, st.br, start, pstart ? pstart : s_g, s_g + sub, lim64, stage, S.tokring + lane * KG_RING_STRIDE, sub - 16, ro, il);
+      kg_lane_round(gt, st.br, start, pstart ? pstart : s_g, s_g + sub, lim64, stage, S.tokring + lane * KG_RING_STRIDE, (sub >> half) - 16, ro, il);
     }
     tr_b = TBZ_TR_NOW();
     tr_round += tr_b - tr_a;
@@ -3232,14 +3261,15 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     // the last run must end before the granule in which the next thing (a round, a stored run) may start,
     // and the table must not outgrow the item's span; else the item is left to the one-lane kernel
     const u64 end_lv = tbz_shfl64(s_lo + nn, (int)lv);
-    const bool fits = !inblk || (end_lv <= (e_last & ~7ull) && gs.nruns + tot_r <= kg_run_slots(it, e_last));
+    const bool fits = !inblk || (end_lv <= ((e_last >> half) & ~7ull) - slot0 && gs.nruns + tot_r <= kg_run_slots(it, e_last));
     if (hasrun && fits) {  // (the lane has padded its run to the granule already)
       RunRec rr;
-      rr.off8 = (u32)((s_lo - (it.start_bit & ~7ull)) >> 3);
+      rr.off8 = (u32)(s_lo >> 3);
       rr.n8 = n8;
       rr.out = ro.out;
       rr.mdef = ro.mdef > 0 ? (u32)ro.mdef : 0u;
-      (P.runs + (it.start_bit >> RUN_SHIFT))[gs.nruns + rank] = rr;
+      const u32 k = gs.nruns + rank;
+      if (k == 0) gs.run0 = rr; else ip.runs[k] = rr;
     }
     // history check material: largest (distance - octets produced before the match) over the round
     u64 hb = gs.produced + PO;
@@ -3329,6 +3359,9 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
       r.n_runs = gs.nruns;
     }
     r.pad = (gs.status == SEG_UNDERRUN && gs.fail_pos == gs.blk_pos) ? 1u : gs.status == SEG_UNDERRUN ? gs.cut : 0u;
+    r.tok = (u64)tok0;
+    r.runs = (u64)ip.runs;
+    r.run0 = gs.run0;
     r.status = gs.status;
     r.max_deficit = gs.deficit;
     r.trailer0 = gs.tr0;
@@ -3413,11 +3446,7 @@ static_assert(K2R_RW % 16 == 0 && K2_SPAN == 2 * K2R_SPAN, "16-octet chunks must
 using K2Ring = K2W<K2R_RW, K2R_HIST>;
 
 struct K2Params {
-  const u16* tok;
-  const RunRec* runs; // run tables (see RunRec)
-  const u16* tok2;    // the repair launches' token pool and run tables (segments with pool = 1)
-  const RunRec* runs2;
-  const Seg* segs;
+  const Seg* segs;    // (a segment names its tokens and run table by address: the call's pools, the repair launches', an item's own)
   const Group* groups;
   const u32* order;   // group indices this launch handles
   const u8* in_base;  // source of stored runs
@@ -3846,15 +3875,15 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
     const u64 npieces = sg.tok_words >> 3;
     // (a repaired segment's tokens live in the repair launches' own pool: a gang that repairs runs past the
     // marker it will land on, and must not scribble over the tokens of the items that start there)
-    const RunRec* rt = (sg.pool ? P.runs2 : P.runs) + (sg.tok_index >> RUN_SHIFT) + sg.run_first;
-    const u16* tbase = (sg.pool ? P.tok2 : P.tok) + (sg.tok_index & ~7ull);  // run offsets count 8-word granules from here
+    const RunRec* rt = (const RunRec*)sg.runs + sg.run_first;  // (the item's run 0 lives in the segment record)
+    const u16* tbase = (const u16*)sg.tok;                     // run offsets count 8-word granules from here
     u32* rE = rcache;
     u32* rO = rcache + 64;
     u32 rbase = 0, ctot = 0;
     u64 cbase = 0;
     auto load_cache = [&]() {
       RunRec rr{};
-      if (rbase + lane < sg.n_runs) rr = rt[rbase + lane];
+      if (rbase + lane < sg.n_runs) rr = (sg.run_first + rbase + lane) ? rt[rbase + lane] : sg.run0;
       const u32 inc = tbz_wave_incl_scan_u32(rr.n8);
       tbz_sync();
       rE[lane] = inc;
@@ -4716,13 +4745,13 @@ TBZ_KERNEL void tbz_k3_emit(K3Params P) {
     const u32 s = im.stream, f = P.first_item[s];
     const u64 rel = P.gscan[i] - P.gscan[f];
     Seg sg;
-    sg.tok_index = im.start_bit;
+    sg.tok = q.tok;
     sg.tok_words = q.tok_words;
     sg.out_bytes = q.out_bytes;
     sg.n_runs = q.n_runs;
-    sg.pool = 0;
     sg.run_first = 0;
-    sg.pad = 0;
+    sg.runs = q.runs;
+    sg.run0 = q.run0;
     P.segs[i] = sg;
     Group g;
     g.out_abs = P.out_off[s] + rel;
@@ -4780,8 +4809,6 @@ struct SliceRec {
 };
 struct K3sParams {
   const BigSeg* big;
-  const RunRec* runs;
-  const RunRec* runs2;
   Seg* segs;
   Group* groups;
   SliceRec* recs;
@@ -4791,7 +4818,7 @@ TBZ_KERNEL void tbz_k3_slice(K3sParams P) {
   const u32 lane = tbz_lane();
   if (tbz_block() >= P.n_big) return;
   const BigSeg bs = P.big[tbz_block()];
-  const RunRec* rt = (bs.seg.pool ? P.runs2 : P.runs) + (bs.seg.tok_index >> RUN_SHIFT);
+  const RunRec* rt = (const RunRec*)bs.seg.runs;
   for (u32 k = lane; k < bs.n_slots; k += 64) {  // slots no run starts in stay empty
     Group g{};
     g.out_abs = bs.out_abs;
@@ -4831,7 +4858,7 @@ TBZ_KERNEL void tbz_k3_slice(K3sParams P) {
   for (u32 base = 0; base < bs.seg.n_runs; base += 64) {  // wave-uniform trip count
     RunRec rr{};
     const bool have = base + lane < bs.seg.n_runs;
-    if (have) rr = rt[base + lane];
+    if (have) rr = (base + lane) ? rt[base + lane] : bs.seg.run0;
     const u64 incl_o = wave_incl_scan_u64(rr.out), incl_w = wave_incl_scan_u64((u64)rr.n8 * 8);
     const u64 Pi = carry + incl_o - rr.out;  // octets of the segment before this run
     const u64 ki = Pi / bs.target;

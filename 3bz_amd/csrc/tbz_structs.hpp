@@ -26,6 +26,8 @@ enum : uint32_t {
   ITEM_RESUME = 8u,  // a session's continuation INSIDE a block: the block's header is parsed where the item starts, then the
                      // token loop is entered at the launch's resume_bit (what deflate.lisp:399-427 achieves by pushing the
                      // bits of an unfinished symbol back)
+  ITEM_EXPLICIT = 16u, // the item brings its own token region (Item::tok, one word per input bit from its start) and run
+                       // table: items decoded AGAIN (SEG_REDO: too dense for a pool of one word per two bits; ITEM_PROBE)
   ITEM_FMT_SHIFT = 8, // format in bits 8..9
   ITEM_HIST_SHIFT = 16 // bits 16..31: octets of the stream before the item (saturated at 65535), for the exact
                        // location of a distance-before-start error (one-lane re-decode of the offending item)
@@ -50,7 +52,24 @@ struct Item {
   uint64_t end_byte;   // end of the stream (relative to in_base)
   uint32_t stream;
   uint32_t flags;
+  uint64_t tok;        // ITEM_EXPLICIT: device address of the item's token region (16-octet aligned) ...
+  uint64_t runs;       // ... and of its run table (gang kernels; (span >> RUN_SHIFT) + 2 entries)
 };
+
+// One contiguous piece of an item's token stream: n8 * 8 words at the item's token base + off8 * 8.
+// Run 0 of an item lives in its SegResult / Seg; runs 1.. in the item's run table, which starts at slot
+// (item.start_bit >> RUN_SHIFT) of the pool's table (position-addressed like the token pool: K1 declines items that
+// would need more runs than their span holds slots, and an item that owns slot k+1.. has consumed k+1 slots' worth of
+// bits, so that tables never overlap however close two short items start).  `out` and `mdef` let K3 cut a large
+// segment into K2 work units at run boundaries without looking at a token (tbz_k3_slice).
+struct RunRec {
+  uint32_t off8;
+  uint32_t n8;
+  uint32_t out;   // octets the run's tokens produce (0xffffffff: more than fits — such a segment is not sliced)
+  uint32_t mdef;  // max over its matches of (distance - octets the RUN produced before the match), 0 if none reaches
+                  // before the run's first octet
+};
+constexpr uint32_t RUN_SHIFT = 7;  // input bits per run-table slot
 
 struct SegResult {
   uint64_t end_bit;      // LANDED/FINAL: bit after the last block (FINAL: after the trailer);
@@ -68,31 +87,19 @@ struct SegResult {
   uint32_t pad;          // UNDERRUN: 1 when the input ended exactly where a block starts (end_bit = that boundary);
                          // 2 when it ended inside a stored block's payload (the reference checks output space first there)
   uint64_t reserved;     // K1g diagnostics: rounds << 32 | committed lanes
+  uint64_t tok;          // device address of the item's token base (what the runs' off8 count from)
+  uint64_t runs;         // device address of the item's run table (entry 0 unused: run0 below)
+  RunRec run0;
 };
-
-// One contiguous piece of an item's token stream: n8 * 8 words at tok[(item.start_bit & ~7) + off8 * 8 ...].
-// An item's table starts at runs[item.start_bit >> RUN_SHIFT] (position-addressed like the token pool:
-// a token-bearing item spans more than 2^RUN_SHIFT bits, and K1 declines items that would need more runs
-// than their span holds slots).  `out` and `mdef` let K3 cut a large segment into K2 work units at run
-// boundaries without looking at a token (tbz_k3_slice).
-struct RunRec {
-  uint32_t off8;
-  uint32_t n8;
-  uint32_t out;   // octets the run's tokens produce (0xffffffff: more than fits — such a segment is not sliced)
-  uint32_t mdef;  // max over its matches of (distance - octets the RUN produced before the match), 0 if none reaches
-                  // before the run's first octet
-};
-constexpr uint32_t RUN_SHIFT = 5;  // items start at least 2^RUN_SHIFT bits apart, so that their tables never share a slot: flush markers
-                                   // are five octets long, and candidates closer than K0C_SPACING to anything are dropped (tbz_k0b_space)
 
 struct Seg {
-  uint64_t tok_index;  // the item's start_bit: base of its token region and (>> RUN_SHIFT) of its run table
+  uint64_t tok;        // device address of the item's token base (SegResult::tok)
   uint64_t tok_words;  // logical token words (multiple of 8)
   uint64_t out_bytes;
   uint32_t n_runs;
-  uint32_t pool;       // 0: the call's token pool / run tables; 1: those of the repair (fix-up) launches
-  uint32_t run_first;  // first entry of the item's run table that belongs to this unit (a slice of a large segment)
-  uint32_t pad;
+  uint32_t run_first;  // first run of the item that belongs to this unit (a slice of a large segment)
+  uint64_t runs;       // device address of the item's run table (SegResult::runs): runs 1..; run 0 is run0
+  RunRec run0;
 };
 
 struct Group {

@@ -393,6 +393,58 @@ def zlib_wrap(raw, plain):
     return b"\x78\x9c" + raw + struct.pack(">I", zlib.adler32(plain))
 
 
+def case_token_density(eng):
+    """The gang kernels' token pool holds one word per TWO input bits (scratch): data whose tokens are denser
+    than that — long runs of one octet cost two or three bits per match, stored blocks of an octet or two — is declined
+    and decoded again into regions of its own; run 0 of an item lives in its result record, so that items a few octets
+    apart (a writer that flushes after every octet) never share a run-table slot.  Same results either way, and the
+    same as with pools of one word per bit (TBZ_TOK_FULL=1)."""
+    text = _mixed_plain(90_000, 77)
+    zeros = bytes(256 << 10)
+    cases = []
+    cases.append(("zlib", zlib.compress(zeros, 6), len(zeros), "zeros"))
+    cases.append(("zlib", zlib.compress(text[:40_000] + bytes(100_000) + text[40_000:] + b"\x55" * 60_000, 6),
+                  len(text) + 160_000, "text, zeros, text, a run"))
+    cases.append(("deflate", K.stored_stream(text[:3000], max_block=1), 3000, "stored blocks of one octet"))
+    cases.append(("deflate", K.stored_stream(text[:5000], max_block=2), 5000, "stored blocks of two octets"))
+    for flush in (zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH):
+        c = zlib.compressobj(6, zlib.DEFLATED, 15)
+        z = bytearray()
+        for i in range(300):       # an octet, a flush: token-bearing items 56 bits apart
+            z += c.compress(text[i:i + 1]) + c.flush(flush)
+        for i in range(40):        # flushes with nothing between them: empty stored blocks back to back
+            z += c.flush(flush) if i else b""
+        z += c.compress(text[300:]) + c.flush()
+        cases.append(("zlib", bytes(z), len(text), "a flush after every octet (%d)" % flush))
+    os.environ["TBZ_TOK_FULL"] = "1"
+    try:
+        e2 = T.Engine(eng.device, lib_path=eng.lib._name)
+    finally:
+        os.environ.pop("TBZ_TOK_FULL", None)
+    os.environ["TBZ_K1_MODE"] = "32"  # a forced flavour hands what it declines straight to the one-lane kernel
+    try:
+        e3 = T.Engine(eng.device, lib_path=eng.lib._name)
+    finally:
+        os.environ.pop("TBZ_K1_MODE", None)
+    try:
+        for k, (fmt, data, n, what) in enumerate(cases):
+            w = assert_same(eng, data, fmt, n, what=what)
+            assert w["flag"] == "finished", what
+            w2 = assert_same(e2, data, fmt, n, what=what + " [one word per bit]")
+            assert w2["bytes"] == w["bytes"]
+            if k in (0, 2, 4):
+                assert_same(e3, data, fmt, n, what=what + " [gangs of 32]")
+            assert_same(eng, data, fmt, n // 2, what=what + ", short buffer")
+            assert_same(eng, data, fmt, n, end=len(data) * 2 // 3, what=what + ", cut")
+        # the zeros went through the second launch (regions of their own), not through a pool of one word per bit
+        out = bytearray(len(zeros))
+        r = eng.inflate(cases[0][1], FMT["zlib"], out)
+        assert r.status == 0 and bytes(out) == zeros and eng.timings().huff_launches >= 2, eng.timings().huff_launches
+    finally:
+        e2.close()
+        e3.close()
+
+
 def case_scratch_bounds(eng):
     """Device scratch is bounded by what a pass decodes: (1) streams far apart in one buffer pay for their own extent
     only (token pool and run tables are addressed relative to the call's first stream octet, not to the base
@@ -1083,7 +1135,7 @@ ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_reference_chunk
              case_noflush_streams, case_block_starts_found, case_close_block_starts, case_fixed_block_chains, case_history_across_groups,
              case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_device_buffers,
              case_checksum_kernels, case_deep_codes, case_chunked_resume, case_gzip_members,
-             case_pointer_contexts, case_container_headers, case_gzip_metadata, case_scratch_bounds, case_fuzz]
+             case_pointer_contexts, case_container_headers, case_gzip_metadata, case_scratch_bounds, case_token_density, case_fuzz]
 # what each engine flavour of the test modules runs.  "auto" runs everything; the others run the cases that can
 # tell them apart (the CPU suite has to stay within minutes: a case costs seconds on the lane emulator)
 FLAVOUR_CASES = {

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TBZ_ABI_VERSION 2
+#define TBZ_ABI_VERSION 3
 
 /* decompress-vector's :format keyword (api.lisp:31-34) */
 enum { TBZ_FORMAT_DEFLATE = 0, TBZ_FORMAT_ZLIB = 1, TBZ_FORMAT_GZIP = 2 };

@@ -1940,10 +1940,10 @@ int tbz_inflate_batch_device(tbz_ctx* ctx, int format, size_t n, const void* d_i
 
 // ====================================================================================================
 // Sessions: 3bz's chunked protocol (deflate.lisp:114-137, :263-269, :705-716; api.lisp:3-21) with the state on the
-// device.  A deflate-state in the reference is resumable at every bit and octet; here the resume point is the start
-// of the block in which the input ran out (a block is where a decode can be entered with no other state than the 32
-// KiB window, deflate.lisp:518-528), so a call costs O(new input + the one block it continues), and what the caller
-// sees — flags, counts, octets, call by call — is what the reference returns:
+// device.  A deflate-state in the reference is resumable at every bit and octet; here the resume point is the TOKEN
+// in which the input ran out (the block's header is parsed again — a block's tables are the only state besides the 32
+// KiB window, deflate.lisp:518-528 — and the token loop entered there), so a call costs O(new input + one block
+// header), and what the caller sees — flags, counts, octets, call by call — is what the reference returns:
 //   * input the caller has given and the decoder has not finished with stays in HBM (d_in, from the resume block on);
 //   * the 32 KiB of output before the resume point are the window (d_hist); K2 / K6 copy from it as from any history;
 //   * octets decoded beyond what the caller's buffer takes wait in HBM (d_dec) for the next buffer (output-overflow);

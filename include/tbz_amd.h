@@ -243,7 +243,11 @@ int tbz_session_stats(const tbz_session* s, uint64_t* n_decodes, uint64_t* in_de
  * metadata — the Lisp shim fills the gzip-state's slots from it — parses the octets it holds with this function.
  * status: 0 = complete header; TBZ_INPUT_UNDERRUN = `in` ends inside the header; TBZ_E_GZIP_MAGIC / _METHOD / _FLAGS
  * / _HCRC = the error the reference signals (gzip.lisp:120-134, :255).  Offsets are into `in`; name / comment
- * lengths exclude the terminating zero octet.  Fields up to `stage` are valid whatever the status. */
+ * lengths exclude the terminating zero octet.  Fields up to `stage` are valid whatever the status.
+ * One deviation, in metadata only: the extra field is taken all or nothing.  The reference allocates `extra` from XLEN and
+ * fills it octet by octet across calls (gzip.lisp:178-196), so a caller that looks at the slot while the input ends
+ * INSIDE the extra field sees a partly filled vector there; here `stage` stays 4 (extra_len unset) until the whole
+ * field has arrived.  Once the header is complete the slots are identical. */
 typedef struct tbz_gzip_header {
   int32_t status;
   uint32_t header_len;   /* octets before the first deflate block */

@@ -2569,6 +2569,9 @@ int tbz_ctx_trim(tbz_ctx* ctx) {
       b->p = nullptr;
       b->cap = 0;
     }
+  for (DevBuf& b : ctx->dense)
+    if (b.p) TBZ_HIP(hipFree(b.p));
+  ctx->dense.clear();
   return 0;
 }
 

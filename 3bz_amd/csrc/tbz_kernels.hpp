@@ -2001,6 +2001,9 @@ struct KgLds {
   GangState gs[64 / G];
   u32 inbuf[K1_INBUF][64];
   u8 tokring[64 * KG_RING_STRIDE];  // per lane: 16 token words on their way to memory (see TokOut)
+#ifdef TBZ_EXP_LDSPAD
+  u8 exp_pad[TBZ_EXP_LDSPAD];       // (occupancy experiment: profiles/README.md)
+#endif
 #ifdef TBZ_WAVE_TRACE
   u32 tr_cnt[4];
 #endif

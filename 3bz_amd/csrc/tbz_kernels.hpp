@@ -4017,7 +4017,16 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
           while (cnt) {
             u32 c = cnt < SPAN ? (u32)cnt : SPAN;  // (the ring holds its history + one span)
             tbz_sync();
-            for (u32 j = lane; j < c; j += 64) win[ring<W>(rpos + j)] = (u8)(P.in_base[src + j] & litmask);
+            // eight octets per lane and trip (octet-addressed accesses on both sides); octet by octet at the chunk's end
+            // and across the ring's seam
+            for (u32 j = lane * 8; j < c; j += 512) {
+              const u32 r = ring<W>(rpos + j);
+              if (j + 8 <= c && (LINEAR || r + 8 <= W::RW)) {
+                k2_st64(win + r, litmask ? k2_ld64(P.in_base + src + j) : 0ull);
+              } else {
+                for (u32 k = 0; k < 8 && j + k < c; k++) win[ring<W>(rpos + j + k)] = (u8)(P.in_base[src + j + k] & litmask);
+              }
+            }
             tbz_sync();
             pos += c;
             rpos = ring<W>(rpos + c);

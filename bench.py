@@ -62,7 +62,35 @@ def parse_args(argv=None):
     ap.add_argument("--gen-only", action="store_true", help="generate (and cache) the workload, then exit")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
     ap.add_argument("--lib", default=None, help="engine library (tests: the CPU lane-emulator build)")
+    ap.add_argument("--no-others", action="store_true", help="the default run also times every other config (one child "
+                    "process each, before this process touches the GPU) and attaches their lines as `other_configs`: skip that")
     return ap.parse_args(argv)
+
+
+OTHER_CONFIGS = ("1", "3", "3u", "2b", "nf", "5", "5f")
+
+
+def run_other_configs():
+    """Every other BASELINE config through this same script, one child process at a time (each generates its workload,
+    decodes it, verifies status / length / checksum / every octet, prints its line), so that their throughput is witnessed
+    by whoever runs the default command — not only the headline's.  Runs BEFORE this process initialises the GPU."""
+    out = []
+    for c in OTHER_CONFIGS:
+        t0 = time.time()
+        rec = {"config": c}
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", c, "--steps", "5", "--warmup", "2",
+                                "--no-cpu-baseline", "--no-others"], capture_output=True, text=True, timeout=300)
+            j = json.loads(r.stdout.strip().split("\n")[-1])
+            rec.update({"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"],
+                        "ms_per_step": j["ms_per_step"], "steps": j["steps"], "verified": True,
+                        "decompressed_bytes": j["config"]["decompressed_bytes"],
+                        "compressed_bytes": j["config"]["compressed_bytes"], "kernel_ms": j["roofline"]["kernel_ms"]})
+        except Exception as e:  # a failing side line must not take the headline with it
+            rec.update({"failed": True, "error": repr(e)[:200]})
+        rec["elapsed_s"] = round(time.time() - t0, 1)
+        out.append(rec)
+    return out
 
 
 # --------------------------------------------------------------------------------------------------
@@ -177,6 +205,10 @@ def main(argv=None):
     import numpy as np
     cfg = args.config
     mib = args.size_mib or DEFAULT_MIB[cfg]
+    others = None
+    if (cfg == "2" and world == 1 and not args.size_mib and not args.lib and not args.corpus_cache and not args.no_cpu_baseline
+            and not args.no_others and not args.gen_only and not args.no_check and args.backend == "nccl"):
+        others = run_other_configs()
     ncpu = os.cpu_count() or 1
     workers = args.gen_workers or max(1, min(16, ncpu // max(1, world)))
     t0 = time.time()
@@ -416,6 +448,8 @@ def main(argv=None):
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        if others is not None:
+            line["other_configs"] = others
         print(json.dumps(line), flush=True)
     eng.free(d_in)
     eng.free(d_out)

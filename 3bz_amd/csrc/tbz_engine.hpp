@@ -776,8 +776,11 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   auto ovl_for = [&](int G) -> u32 {
     if (ctx->tun.ovl) return (u32)std::max(64, ctx->tun.ovl);
     // measured (profiles/README.md): a gang of 64 commits 29 lanes per round at 512 bits of run-up, 59 at 1024 (K1 on
-    // the 64 MiB no-flush stream 2.78 -> 1.56 ms, on config 3 8.96 -> 6.05 ms); gangs of 32 are flat from 512 to 768
-    return G >= 64 ? 1024u : KG_OVL;
+    // the 64 MiB no-flush stream 2.78 -> 1.56 ms, on config 3 8.96 -> 6.05 ms).  Gangs of 32: config 2's text is flat
+    // from 512 to 1024 bits (2.56 - 2.68 ms), but a sync-flush stream — more and longer matches, because history
+    // reaches across the flush points, so two parses take longer to fall into step — needed 3.2 rounds per item at 512
+    // bits (K1 on config 2b 1.28 ms; 0.95 at 768, 0.80 at 1024).  Narrow gangs (K0c's short items, config 5): 768 is best.
+    return G >= 32 ? 1024u : 768u;
   };
   // items the gang kernel declined (SEG_REDO: more token words than the pool has for their bits — long runs of one
   // octet code that way —, run table full) are decoded again into regions of their own: by gangs of 64 where the pool

@@ -1949,7 +1949,7 @@ constexpr u32 KG_SUB_MIN = 1024;        // bits of bitstream per lane per round
 constexpr u32 KG_SUB_MAX = 8192;
 constexpr u64 KG_MULTI_BLOCK_BITS = 512u << 10;  // an item this long is taken to hold several blocks ...
 constexpr u32 KG_BLOCK_GUESS_BITS = 192u << 10;  // ... of about this size (zlib: 16 K symbols of text)
-constexpr u32 KG_OVL = 512;             // run-up bits before a lane's sub-range
+constexpr u32 KG_OVL = 512;             // least run-up bits before a lane's sub-range (the host picks per gang width: 768 / 1024)
 
 // lookup entries (u16).  bits 0-3: code length; 0 = not a symbol:
 //     whole entry 0          unassigned pattern, or a long code without a second-level table -> exact step

@@ -3392,7 +3392,10 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
 TBZ_K1G_KERNEL(8, 3)
 TBZ_K1G_KERNEL(16, 3)
 TBZ_K1G_KERNEL(32, 3)
-TBZ_K1G_KERNEL(64, 3)
+// (gangs of 64 have one gang's tables per workgroup — 9.8 KB of LDS, sixteen workgroups per CU — so four waves per SIMD
+// is theirs to have if the registers allow: 128 instead of 146; config 3's 4 096 members are then ONE generation of
+// workgroups, K1 3.45 -> 2.82 ms.  The narrower gangs are held at three per SIMD by their LDS.)
+TBZ_K1G_KERNEL(64, 4)
 #undef TBZ_K1G_KERNEL
 
 // ================================================================================================

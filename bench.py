@@ -75,6 +75,7 @@ def run_other_configs():
     decodes it, verifies status / length / checksum / every octet, prints its line), so that their throughput is witnessed
     by whoever runs the default command — not only the headline's.  Runs BEFORE this process initialises the GPU."""
     out = []
+    import torch  # noqa: F401  (the first import on a fresh box pages the image in — minutes; it initialises no GPU state)
     t_all = time.time()
     for c in OTHER_CONFIGS:
         t0 = time.time()

@@ -59,7 +59,8 @@ struct tbz_ctx {
                                     // whose streams need more is decoded in several passes over consecutive streams
   // thresholds and diagnostics switches (tests force the rare paths at small sizes): read ONCE, when the context is created
   struct Tun {
-    long find_enough = 2048, find_min_len = 128 << 10;
+    long find_enough = 2048, find_min_len = 48 << 10;  // (128 KiB until round 3: one 256 KiB gzip member — 93 KB — decoded alone
+                                                        // took 2.0 ms as ONE item, 1.3 ms as five: profiles/README.md)
     int k0b_pair = -1;        // -1: by launch size
     int sub_min = 0, ovl = 0; // 0: the defaults
     long wide_bits = -1;      // -1: by gang width
@@ -402,6 +403,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   std::vector<Item> items;
   bool host_tables = false, have_find = false, have_resolve = false;
   uint32_t n_mark = 0, n_fixed_items = 0;  // flush markers; how many of them are followed by a fixed-Huffman block
+  uint32_t n_stored_heads = 0;             // streams that begin with a stored block
   std::vector<uint32_t> first_marker(n + 1, 0);
   if (tiles) {
     if ((r = upload(ctx, ctx->d_str_off, h_off))) return r;
@@ -411,9 +413,9 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if ((r = ensure(ctx, ctx->d_tile_offsets, (tiles + 1) * 4))) return r;
     if ((r = ensure(ctx, ctx->d_k0_slots, tiles * (size_t)K0_SLOTS * 8))) return r;
     if ((r = ensure(ctx, ctx->d_markers, tiles * (size_t)K0_SLOTS * 8 + 16))) return r;
-    if ((r = ensure(ctx, ctx->d_k0_fm, (n + 1) * 4 + 12))) return r;  // [0..1] head, [2..] first_marker, [n+3] fixed-block items
+    if ((r = ensure(ctx, ctx->d_k0_fm, (n + 1) * 4 + 16))) return r;  // [0..1] head, [2..] first_marker, [n+3] fixed-block items, [n+4] stored heads
     if ((r = ensure(ctx, ctx->d_items, (tiles * (size_t)K0_SLOTS + n) * sizeof(Item)))) return r;
-    if ((r = pinned(ctx, (n + 4) * 4 + sizeof(K3Global) + (n + 1) * sizeof(K3Stream)))) return r;
+    if ((r = pinned(ctx, (n + 5) * 4 + 16 + sizeof(K3Global) + (n + 1) * sizeof(K3Stream)))) return r;
     K0Params k0{(const u8*)d_in, (const u64*)ctx->d_str_off.p, (const u64*)ctx->d_str_len.p,
                 (const u32*)ctx->d_tile_first.p, (u32)n, (u32)tiles, (u32*)ctx->d_tile_counts.p,
                 (u32*)ctx->d_tile_offsets.p, (u64*)ctx->d_markers.p, (u64*)ctx->d_k0_slots.p,
@@ -425,10 +427,11 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     TBZ_LAUNCH(tbz_k0_compact, tiles, ctx->stream, k0);
     TBZ_LAUNCH(tbz_k0_items, (max_items + 63) / 64, ctx->stream, k0);
     uint32_t* h_head = (uint32_t*)ctx->h_pin;
-    TBZ_HIP(hipMemcpyAsync(h_head, ctx->d_k0_fm.p, (n + 4) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TBZ_HIP(hipMemcpyAsync(h_head, ctx->d_k0_fm.p, (n + 5) * 4, hipMemcpyDeviceToHost, ctx->stream));
     TBZ_HIP(hipStreamSynchronize(ctx->stream));
     n_mark = h_head[0];
     n_fixed_items = h_head[n + 3];
+    n_stored_heads = h_head[n + 4];
     for (size_t s = 0; s <= n; s++) first_marker[s] = h_head[2 + s];
     if (h_head[1]) {  // a tile with more markers than slots: the second, emitting pass
       if ((r = ensure(ctx, ctx->d_markers, (size_t)n_mark * 8 + 16))) return r;
@@ -453,7 +456,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if ((r = ensure(ctx, ctx->d_k0_fm, (n + 1) * 4 + 8))) return r;
     std::vector<uint32_t> zero(n + 3, 0);
     if ((r = upload(ctx, ctx->d_k0_fm, zero))) return r;
-    if ((r = pinned(ctx, (n + 4) * 4 + sizeof(K3Global) + (n + 1) * sizeof(K3Stream)))) return r;
+    if ((r = pinned(ctx, (n + 5) * 4 + 16 + sizeof(K3Global) + (n + 1) * sizeof(K3Stream)))) return r;
     for (size_t s = 0; s < n; s++) {
       StreamPlan& S = sp[s];
       Item it{};
@@ -481,7 +484,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     constexpr uint64_t FIND_MIN_ITEM_BITS = 8ull * (48u << 10);  // mean compressed octets per item below which it does not pay
     // ... nor when the call already has enough items to fill the chip (a batch of thousands of streams: measured on
     // config 3, 4096 gzip members, splitting them cost more in K2's second plane than it gained in K1)
-    const bool enough = (size_t)n_mark + n >= (size_t)ctx->tun.find_enough;
+    // ... nor when every stream begins with a stored block (stored data: nothing to find; config 1)
+    const bool enough = (size_t)n_mark + n >= (size_t)ctx->tun.find_enough || (n_stored_heads >= n && ctx->find_mode != 2);
     const uint64_t find_min_len = (uint64_t)ctx->tun.find_min_len;
     std::vector<uint32_t> tfb(n + 1);
     uint64_t tiles_b = 0;
@@ -961,7 +965,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   ctx->tim.huff_launches = 1;
   bool simple = false;
   bool fused_adler = false;  // adler32 partials come from K2 (simple path, zlib, all groups in the two-wave kernel)
-  char* pin_k3 = (char*)ctx->h_pin + (((n + 4) * 4 + 15) & ~(size_t)15);
+  char* pin_k3 = (char*)ctx->h_pin + (((n + 5) * 4 + 15) & ~(size_t)15);
   K3Global* h_glob = (K3Global*)pin_k3;
   K3Stream* h_k3s = (K3Stream*)(pin_k3 + sizeof(K3Global));
   if (try_simple) {

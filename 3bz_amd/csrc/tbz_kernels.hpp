@@ -131,7 +131,7 @@ struct K0Params {
   u32 format;
   u32 second_pass;        // items: the marker array was written by the emitting pass
   u32 start_bit_off;      // stream 0's first block header sits at this bit of the stream's first octet (resumed streams)
-  u32* n_fixed;           // items: counts the marker items whose first block is a fixed-Huffman block (nullptr: not wanted) —
+  u32* n_fixed;           // items: [0] counts the marker items whose first block is a fixed-Huffman block (nullptr: not wanted) —
                           // where most are, the streams are fixed-Huffman territory and K0c looks for block chains inside them
   u32 resume;             // items: stream 0's head item carries ITEM_RESUME (a session's continuation inside a block)
 };
@@ -267,7 +267,7 @@ TBZ_KERNEL_WG(1024, 1) void tbz_k0_scan_offsets(K0Params P) {
   if (tid == 0) {
     u32 ov = 0;
     for (u32 k = 0; k < 16; k++) ov += wover[k];
-    if (P.n_fixed) *P.n_fixed = 0;  // (tbz_k0_items, launched after this kernel, counts into it)
+    if (P.n_fixed) P.n_fixed[0] = P.n_fixed[1] = 0;  // (tbz_k0_items, launched after this kernel, counts into them)
     P.tile_offsets[P.n_tiles] = carry;
     P.head[0] = carry;
     P.head[1] = ov;
@@ -308,6 +308,15 @@ TBZ_KERNEL void tbz_k0_items(K0Params P) {
     bool fx = false;
     if (k != 0 && (it.start_bit >> 3) < it.end_byte) fx = ((P.in_base[it.start_bit >> 3] >> 1) & 3) == 1;
     if (fx) tbz_atomic_add_global(P.n_fixed, 1u);  // (lanes past the list have left: no collective here)
+    // n_fixed[1]: the streams that BEGIN with a stored block (raw deflate and zlib: the first block header sits at a known
+    // place) — such a stream is stored data more likely than not, and a search for Huffman block headers in it is wasted
+    if (k == 0 && P.format != 2) {
+      const u64 hb = it.start_bit + (P.format == 1 ? 16u : 0u);
+      if ((hb >> 3) + 1 < it.end_byte) {
+        const u32 v = ((u32)P.in_base[hb >> 3] | ((u32)P.in_base[(hb >> 3) + 1] << 8)) >> (hb & 7);
+        if (((v >> 1) & 3) == 0) tbz_atomic_add_global(P.n_fixed + 1, 1u);
+      }
+    }
   }
 }
 

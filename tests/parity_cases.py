@@ -222,7 +222,7 @@ def case_noflush_streams(eng, n=160_000):
     t = eng.timings()
     assert res.status == 0 and bytes(out) == p and res.adler32 == zlib.adler32(p)
     assert t.n_groups >= 2 and t.n_hgroups >= 1, (t.n_candidates, t.n_groups, t.n_hgroups)
-    if len(s) >= 128 << 10 or os.environ.get("TBZ_FIND") == "always":   # (K0b searches streams of at least 128 KiB)
+    if len(s) >= 128 << 10 or os.environ.get("TBZ_FIND") == "always":   # (K0b searches streams of at least 48 KiB whose items are large)
         assert t.n_candidates >= 2, t.n_candidates
     assert_same(eng, pygzip.compress(p, 6, mtime=0), "gzip", n, what="no-flush gzip")
     # capacities that end inside an H-group, inside its last 32 KiB, at a group seam ...

@@ -4606,6 +4606,56 @@ TBZ_KERNEL void tbz_k6_resolve(K6Params P) {
   }
 }
 
+// The same for LONG ranges (the host picks by their mean length): four wavefronts per workgroup, the 32 KiB that the
+// range's pointers refer to staged in LDS once — tbz_k6_resolve's lookups are sixteen scattered one-octet loads from
+// memory per chunk — then K6R_PIECE octets of the range are walked.  (Short ranges: staging 32 KiB costs more than it saves.)
+constexpr u32 K6R_THREADS = 256;
+constexpr u32 K6R_PIECE = 65536;
+TBZ_KERNEL_WG(256, 2) void tbz_k6_resolve_lds(K6Params P) {
+  TBZ_SHARED __attribute__((aligned(16))) u8 win[K6_W];
+  const u32 tid = tbz_wave() * 64 + tbz_lane();
+  const u32 ri = tbz_block() / P.pieces, piece = tbz_block() % P.pieces;
+  if (ri >= P.n_ranges) return;  // (workgroup-uniform, like the two below: no barrier is left waiting)
+  const K6Range g = P.ranges[ri];
+  if (g.hi <= g.lo) return;
+  const uintptr_t ob = (uintptr_t)P.out_base;
+  const u64 c_lo = g.lo - ((ob + g.lo) & 15);
+  const u64 p_lo = c_lo + (u64)piece * K6R_PIECE;
+  if ((i64)p_lo >= (i64)g.hi) return;
+  // pointer i stands for the octet at base - 32768 + i; an address below the stream's first octet is one that no
+  // pointer of a valid stream means: the first octet stands in for it
+  const i64 w0 = (i64)g.base - (i64)K6_W;
+  for (u32 i = tid * 16; i < K6_W; i += K6R_THREADS * 16) {
+    const i64 y = w0 + (i64)i;
+    if (y >= (i64)g.floor) {
+      *(K2U128*)(win + i) = *(const K2U128*)(P.out_base + y);
+    } else {
+      for (u32 q = 0; q < 16; q++) win[i + q] = P.out_base[y + q < (i64)g.floor ? g.floor : (u64)(y + q)];
+    }
+  }
+  tbz_wg_barrier();
+  for (u32 k = tid; k < K6R_PIECE / 16; k += K6R_THREADS) {
+    const u64 x = p_lo + (u64)k * 16;
+    if ((i64)x >= (i64)g.hi) break;
+    uint4 m = *(const uint4*)(P.mark_base + (x - P.bias));
+    if ((m.x | m.y | m.z | m.w) == 0) continue;
+    uint4 o = *(const uint4*)(P.out_base + x);
+    auto src = [&](u32 idx, u32& a, u32& b) {  // (all sixteen lookups are made, symbolic or not)
+      a = win[idx & (K6_W - 1)];
+      b = 0;
+    };
+    const bool whole = (i64)x >= (i64)g.lo && x + 16 <= g.hi;
+    if (!(whole ? k6_fix16<true>(o, m, x, g.lo, g.hi, src) : k6_fix16<false>(o, m, x, g.lo, g.hi, src))) continue;
+    if (whole) {
+      *(uint4*)(P.out_base + x) = o;
+    } else {  // ragged ends: the octets outside the range are another workgroup's
+      const u32 ow[4] = {o.x, o.y, o.z, o.w};
+      for (u32 q = 0; q < 16; q++)
+        if ((i64)(x + q) >= (i64)g.lo && (i64)(x + q) < (i64)g.hi) P.out_base[x + q] = (u8)(ow[q >> 2] >> (8 * (q & 3)));
+    }
+  }
+}
+
 // ================================================================================================
 // K3 — layout on the device for the common case.  After K1 the host must chain the items of each
 // stream (did item k land exactly on item k+1?), lay the segments out in the output and describe

@@ -105,6 +105,24 @@ def test_emu_k0b_two_tiles_per_wave():
         e.close()
 
 
+def test_emu_k6_resolve_with_the_window_in_lds():
+    """K6's parallel resolve has a flavour for long ranges (mean >= 24 KiB) that stages the 32 KiB its pointers refer to
+    in LDS: forced here for every range, on streams whose groups reach into their predecessors"""
+    T = importlib.import_module("3bz_amd")
+    os.environ["TBZ_K6_LDS_MIN"] = "0"
+    os.environ["TBZ_FIND"] = "always"
+    try:
+        e = T.Engine(0, lib_path=os.path.join(EMU_DIR, "libtbz_emu.so"))
+    finally:
+        os.environ.pop("TBZ_K6_LDS_MIN", None)
+        os.environ.pop("TBZ_FIND", None)
+    try:
+        P.case_noflush_streams(e)
+        P.case_history_across_groups(e)
+    finally:
+        e.close()
+
+
 def test_emu_sanitized():
     """ASan/UBSan are CPU-only on this pool: the kernel + engine sources, compiled with both, run the cases
     that stress addressing (known-answer vectors; false markers incl. crowded tiles and fix-up rounds).  The

@@ -43,6 +43,8 @@ struct DevBuf {
 struct tbz_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;  // the gangs of 64 that take a narrow launch's few LARGE items run beside it (launch_k1)
+  hipEvent_t evw[2] = {};
   hipEvent_t ev[12] = {};
   std::string err;
   tbz_timings tim{};
@@ -77,7 +79,7 @@ struct tbz_ctx {
   tbz::DevBuf d_str_off, d_str_len, d_tile_first, d_tile_counts, d_tile_offsets, d_markers, d_items, d_res,
       d_tok, d_scratch, d_runs, d_segs, d_groups, d_order, d_k3_fi, d_k3_ni, d_k3_oo, d_k3_oc, d_k3_sums, d_k3_flags,
       d_k3_gscan, d_k3_gne, d_k3_streams, d_k3_glob, d_redo_items, d_redo_res, d_k0_slots, d_k0_fm, d_hdr, d_gck, d_gchunks, d_ck_l1, d_tok2, d_runs2, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
-      d_out_stage, d_kb_tf, d_kb_slots, d_kb_counts, d_kb_offsets, d_kb_cands, d_kb_fc, d_kb_head, d_markers2, d_kb_fm2, d_mark, d_hg, d_k6s, d_bigs, d_recs, d_kc_tf, d_kc_slots, d_kc_ends, d_kc_link, d_kc_fm2, d_markers3, d_kb_keep, d_kb_kcounts, d_gz_cands, d_gz_count, d_gz_tmp;
+      d_out_stage, d_kb_tf, d_kb_slots, d_kb_counts, d_kb_offsets, d_kb_cands, d_kb_fc, d_kb_head, d_markers2, d_kb_fm2, d_mark, d_hg, d_k6s, d_bigs, d_recs, d_kc_tf, d_kc_slots, d_kc_ends, d_kc_link, d_kc_fm2, d_markers3, d_kb_keep, d_kb_kcounts, d_gz_cands, d_gz_count, d_gz_tmp, d_wide_res;
   std::vector<tbz::DevBuf> dense;  // token regions of items the one-lane kernel decoded again (SEG_REDO, probes): one word per
                                    // bit of those items only; released when the next call starts
 };
@@ -96,7 +98,7 @@ static std::vector<DevBuf*> all_pools(tbz_ctx* ctx) {
           &ctx->d_kb_counts, &ctx->d_kb_offsets, &ctx->d_kb_cands, &ctx->d_kb_fc, &ctx->d_kb_head, &ctx->d_markers2,
           &ctx->d_kb_fm2, &ctx->d_mark, &ctx->d_hg, &ctx->d_k6s, &ctx->d_bigs, &ctx->d_recs, &ctx->d_kc_tf,
           &ctx->d_kc_slots, &ctx->d_kc_ends, &ctx->d_kc_link, &ctx->d_kc_fm2, &ctx->d_markers3, &ctx->d_kb_keep,
-          &ctx->d_kb_kcounts, &ctx->d_gz_cands, &ctx->d_gz_count, &ctx->d_gz_tmp};
+          &ctx->d_kb_kcounts, &ctx->d_gz_cands, &ctx->d_gz_count, &ctx->d_gz_tmp, &ctx->d_wide_res};
 }
 static uint64_t dense_total(tbz_ctx* ctx) {
   uint64_t t = 0;
@@ -768,15 +770,16 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if (ctx->tun.sub_min) return (u32)std::max(64, ctx->tun.sub_min & ~63);
     return KG_SUB_MIN;
   };
-  // a gang narrower than 64 lanes declines items it would need more than eight full rounds for (the width follows the
-  // launch's mean item size: a batch of many small streams and one large one); the host decodes those with gangs of
-  // 64 (`redo`).  Not lower: where lanes do not fall into step (periodic bitstreams: config 5's 294 Kbit block, 1.8 lanes
-  // committed per round) a wider gang means shorter sub-ranges and MORE rounds — handing that block over cost 2.5 ms.
-  // Forced flavours (tests) keep everything.
+  // a gang narrower than 64 lanes declines items it would need more than two full rounds for (the width follows the
+  // launch's mean item size: a batch of many small streams and one large one, or K0c's short items and one long block
+  // among them); the host decodes those with gangs of 64 (`redo`).  (Eight rounds until late in round 3: config 5's
+  // 294 Kbit block of one repeated match stayed on its 8-lane gang for 2.4 ms while the rest of the launch was done
+  // after 0.8 — a wider gang had been WORSE there as long as lanes could not fall into step on a periodic bitstream;
+  // with kg_periodic they start on a token.)  Forced flavours (tests) keep everything.
   auto wide_for = [&](int G, bool fix) -> u64 {
     if (ctx->tun.wide_bits >= 0) return (u64)ctx->tun.wide_bits;
     if (ctx->k1_mode || fix || G >= 64) return 0;
-    return (u64)G * KG_SUB_MAX * 8;
+    return (u64)G * KG_SUB_MAX * 2;
   };
   auto ovl_for = [&](int G) -> u32 {
     if (ctx->tun.ovl) return (u32)std::max(64, ctx->tun.ovl);
@@ -877,12 +880,33 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     ctx->tim.huff_launches++;
     return 0;
   };
+  bool wide_beside = false;  // the main launch's large items were decoded by gangs of 64 on the second stream (d_wide_res)
   auto launch_k1 = [&](const Item* d_items, SegResult* d_res, size_t n_it, bool fix) -> int {
     int G = k1_gang(n_it);
     if (G == 1 && pool_half(fix)) G = 8;  // (a repair launch of many small items into a pool laid out for gangs)
     if (!fix) ctx->tim.k1_gang = (uint32_t)G;
     if (G == 1) return launch_lane(d_items, d_res, n_it, fix);
     size_t per = 64 / G, nwg = (n_it + per - 1) / per;
+    // A launch of NARROW gangs (short items) declines the few items that are far larger than its mean (SEG_WIDE).
+    // Gangs of 64 take exactly those — a second kernel over the same item list on the second stream, every workgroup of
+    // which leaves at once unless its item is such a one — BESIDE the narrow launch instead of after the host has read
+    // its results (config 5: one 294 Kbit block among 3 548 items: 0.77 + 0.8 ms one after the other).  Their results
+    // go to an array of their own (the narrow gang writes SEG_WIDE into the item's record).
+    if (!fix && G <= 16 && wide_for(G, fix) && ctx->stream2) {
+      int rr = ensure(ctx, ctx->d_wide_res, n_it * sizeof(SegResult));
+      if (rr) return rr;
+      TBZ_HIP(hipEventRecord(ctx->evw[0], ctx->stream));  // (the items are there)
+      TBZ_HIP(hipStreamWaitEvent(ctx->stream2, ctx->evw[0], 0));
+      K1gParams kw{(const u8*)d_in, pool_tok(fix), pool_runs(fix), pool_half(fix), 1, d_items, (SegResult*)ctx->d_wide_res.p,
+                   d_markers_cur, d_first_marker, nullptr, nullptr, (u32)n_mark, (u32)n_it, ovl_for(64), sub_min_for(64),
+                   wide_for(G, fix), resume_abs};
+#ifdef TBZ_WAVE_TRACE
+      kw.trace = nullptr;
+#endif
+      TBZ_LAUNCH(tbz_k1g64_huff_decode, n_it, ctx->stream2, kw);
+      TBZ_HIP(hipEventRecord(ctx->evw[1], ctx->stream2));
+      wide_beside = true;
+    }
     // K1h: every lane parses the first block header of its own item, so that the gangs need not (their leaders
     // would do it with 2 of 64 lanes busy)
     int rr;
@@ -925,6 +949,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       case 32: TBZ_LAUNCH(tbz_k1g32_huff_decode, nwg, ctx->stream, kg); break;
       default: TBZ_LAUNCH(tbz_k1g64_huff_decode, nwg, ctx->stream, kg); break;
     }
+    if (wide_beside && !fix) TBZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->evw[1], 0));  // what follows needs both
     return 0;
   };
   // K3 (layout on the device when every item simply lands on its successor): its stream tables go up before
@@ -1109,6 +1134,18 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
                          ctx->stream));
   TBZ_HIP(hipStreamSynchronize(ctx->stream));
   huff_ms = elapsed(ctx, 2, 3);
+  if (wide_beside) {
+    bool any = false;
+    for (const SegResult& q : res) any = any || q.status == SEG_WIDE;
+    if (any) {
+      std::vector<SegResult> wr(n_items);
+      TBZ_HIP(hipMemcpyAsync(wr.data(), ctx->d_wide_res.p, wr.size() * sizeof(SegResult), hipMemcpyDeviceToHost, ctx->stream));
+      TBZ_HIP(hipStreamSynchronize(ctx->stream));
+      for (size_t i = 0; i < n_items; i++)
+        if (res[i].status == SEG_WIDE) res[i] = wr[i];
+      ctx->tim.huff_launches++;
+    }
+  }
   if ((r = redo(items, res, false))) return r;
 
   // ---------------------------------------------------------------- chain walk (+ fix-up rounds)
@@ -1831,7 +1868,10 @@ int tbz_ctx_create(int device_id, tbz_ctx** out_ctx) {
   hipError_t e;
   if ((e = hipSetDevice(device_id)) != hipSuccess) return fail(e, "hipSetDevice");
   if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess) return fail(e, "hipStreamCreate");
+  if ((e = hipStreamCreate(&ctx->stream2)) != hipSuccess) return fail(e, "hipStreamCreate");
   for (auto& ev : ctx->ev)
+    if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
+  for (auto& ev : ctx->evw)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
   std::vector<uint32_t> t;
   tbz::build_crc_tables(t);
@@ -1889,6 +1929,9 @@ void tbz_ctx_destroy(tbz_ctx* ctx) {
   if (ctx->h_pin) hipHostFree(ctx->h_pin);
   for (auto& ev : ctx->ev)
     if (ev) hipEventDestroy(ev);
+  for (auto& ev : ctx->evw)
+    if (ev) hipEventDestroy(ev);
+  if (ctx->stream2) hipStreamDestroy(ctx->stream2);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -2025,7 +2025,7 @@ struct K1gParams {
   RunRec* runs;   // run tables
   u32 half;       // 1: the pool holds one word per TWO input bits (a token of ordinary data takes far more; a lane whose
                   // region fills up ends its run early, and an item that does not fit is declined: SEG_REDO); 0: per bit
-  u32 pad0;
+  u32 only_wide;  // 1 (gangs of 64 beside a narrow launch): decode the items longer than wide_bits and nothing else
   const Item* items;
   SegResult* res;
   const u64* markers;
@@ -2975,6 +2975,12 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
   if (have) it = P.items[idx];
   const u32 fmt = (it.flags >> ITEM_FMT_SHIFT) & 3;
   const bool fixup = (it.flags & ITEM_FIXUP) != 0;
+  // (a launch of gangs of 64 BESIDE a narrow one — P.only_wide — takes the items longer than wide_bits and nothing else:
+  // one item per wave, so the whole workgroup leaves)
+  if (G == 64 && P.only_wide) {
+    const u64 lim = (it.end_byte * 8 < it.limit_bit) ? it.end_byte * 8 : it.limit_bit;
+    if (!have || (it.flags & ITEM_FIXUP) || !(lim > it.start_bit && lim - it.start_bit > P.wide_bits)) return;
+  }
   const ItemPool ip = kg_item_pool(it, P);
   const u32 half = ip.half;
   const u64 slot0 = ip.slot0;

@@ -892,7 +892,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     // which leaves at once unless its item is such a one — BESIDE the narrow launch instead of after the host has read
     // its results (config 5: one 294 Kbit block among 3 548 items: 0.77 + 0.8 ms one after the other).  Their results
     // go to an array of their own (the narrow gang writes SEG_WIDE into the item's record).
-    if (!fix && G <= 16 && wide_for(G, fix) && ctx->stream2) {
+    if (!fix && G <= 16 && wide_for(G, fix) && ctx->stream2) {  // (gangs of 32: the 65 536 workgroups of config 2 that leave at once cost K1 1 - 2 %: measured)
       int rr = ensure(ctx, ctx->d_wide_res, n_it * sizeof(SegResult));
       if (rr) return rr;
       TBZ_HIP(hipEventRecord(ctx->evw[0], ctx->stream));  // (the items are there)

@@ -40,6 +40,20 @@ struct DevBuf {
 
 }  // namespace tbz
 
+// every grow-only device pool of a context, ONCE: the members of tbz_ctx and the list all_pools() walks (destroy, trim,
+// scratch accounting) are both generated from this list, so that a pool cannot be forgotten in one of them
+// (d_cold / d_cold2: the gang kernels' parked canonical lists — tbz::GangCold — of the main launch / of the gangs of 64 beside it)
+#define TBZ_CTX_POOLS(X) \
+  X(d_str_off) X(d_str_len) X(d_tile_first) X(d_tile_counts) X(d_tile_offsets) X(d_markers) X(d_items) X(d_res) \
+  X(d_tok) X(d_scratch) X(d_runs) X(d_segs) X(d_groups) X(d_order) X(d_k3_fi) X(d_k3_ni) \
+  X(d_k3_oo) X(d_k3_oc) X(d_k3_sums) X(d_k3_flags) X(d_k3_gscan) X(d_k3_gne) X(d_k3_streams) X(d_k3_glob) \
+  X(d_redo_items) X(d_redo_res) X(d_k0_slots) X(d_k0_fm) X(d_hdr) X(d_gck) X(d_gchunks) X(d_ck_l1) \
+  X(d_tok2) X(d_runs2) X(d_ck_chunks) X(d_ck_parts) X(d_ck_streams) X(d_ck_out) X(d_crc_tab) X(d_in_stage) \
+  X(d_out_stage) X(d_kb_tf) X(d_kb_slots) X(d_kb_counts) X(d_kb_offsets) X(d_kb_cands) X(d_kb_fc) X(d_kb_head) \
+  X(d_markers2) X(d_kb_fm2) X(d_mark) X(d_hg) X(d_k6s) X(d_bigs) X(d_recs) X(d_kc_tf) \
+  X(d_kc_slots) X(d_kc_ends) X(d_kc_link) X(d_kc_fm2) X(d_markers3) X(d_kb_keep) X(d_kb_kcounts) X(d_gz_cands) \
+  X(d_gz_count) X(d_gz_tmp) X(d_wide_res) X(d_cold) X(d_cold2)
+
 struct tbz_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -75,11 +89,10 @@ struct tbz_ctx {
   } tun;
   int find_mode = 1;  // K0b block-start finder: 0 never, 1 for streams whose items are large (default), 2 for every stream
                       // of at least one finder tile (env TBZ_FIND=off|auto|always; tests force it at small sizes)
-  // device pools (grow-only)
-  tbz::DevBuf d_str_off, d_str_len, d_tile_first, d_tile_counts, d_tile_offsets, d_markers, d_items, d_res,
-      d_tok, d_scratch, d_runs, d_segs, d_groups, d_order, d_k3_fi, d_k3_ni, d_k3_oo, d_k3_oc, d_k3_sums, d_k3_flags,
-      d_k3_gscan, d_k3_gne, d_k3_streams, d_k3_glob, d_redo_items, d_redo_res, d_k0_slots, d_k0_fm, d_hdr, d_gck, d_gchunks, d_ck_l1, d_tok2, d_runs2, d_ck_chunks, d_ck_parts, d_ck_streams, d_ck_out, d_crc_tab, d_in_stage,
-      d_out_stage, d_kb_tf, d_kb_slots, d_kb_counts, d_kb_offsets, d_kb_cands, d_kb_fc, d_kb_head, d_markers2, d_kb_fm2, d_mark, d_hg, d_k6s, d_bigs, d_recs, d_kc_tf, d_kc_slots, d_kc_ends, d_kc_link, d_kc_fm2, d_markers3, d_kb_keep, d_kb_kcounts, d_gz_cands, d_gz_count, d_gz_tmp, d_wide_res;
+  // device pools (grow-only): TBZ_CTX_POOLS above
+#define TBZ_X(name) tbz::DevBuf name;
+  TBZ_CTX_POOLS(TBZ_X)
+#undef TBZ_X
   std::vector<tbz::DevBuf> dense;  // token regions of items the one-lane kernel decoded again (SEG_REDO, probes): one word per
                                    // bit of those items only; released when the next call starts
 };
@@ -88,17 +101,11 @@ namespace tbz {
 
 // every device pool of a context (destroy, trim, accounting)
 static std::vector<DevBuf*> all_pools(tbz_ctx* ctx) {
-  return {&ctx->d_str_off, &ctx->d_str_len, &ctx->d_tile_first, &ctx->d_tile_counts, &ctx->d_tile_offsets,
-          &ctx->d_markers, &ctx->d_items, &ctx->d_res, &ctx->d_tok, &ctx->d_scratch, &ctx->d_runs, &ctx->d_order,
-          &ctx->d_segs, &ctx->d_groups, &ctx->d_ck_chunks, &ctx->d_ck_parts, &ctx->d_ck_streams, &ctx->d_ck_out,
-          &ctx->d_crc_tab, &ctx->d_in_stage, &ctx->d_out_stage, &ctx->d_k3_fi, &ctx->d_k3_ni, &ctx->d_k3_oo,
-          &ctx->d_k3_oc, &ctx->d_k3_sums, &ctx->d_k3_flags, &ctx->d_k3_gscan, &ctx->d_k3_gne, &ctx->d_k3_streams,
-          &ctx->d_k3_glob, &ctx->d_redo_items, &ctx->d_redo_res, &ctx->d_k0_slots, &ctx->d_k0_fm, &ctx->d_hdr,
-          &ctx->d_gck, &ctx->d_gchunks, &ctx->d_ck_l1, &ctx->d_tok2, &ctx->d_runs2, &ctx->d_kb_tf, &ctx->d_kb_slots,
-          &ctx->d_kb_counts, &ctx->d_kb_offsets, &ctx->d_kb_cands, &ctx->d_kb_fc, &ctx->d_kb_head, &ctx->d_markers2,
-          &ctx->d_kb_fm2, &ctx->d_mark, &ctx->d_hg, &ctx->d_k6s, &ctx->d_bigs, &ctx->d_recs, &ctx->d_kc_tf,
-          &ctx->d_kc_slots, &ctx->d_kc_ends, &ctx->d_kc_link, &ctx->d_kc_fm2, &ctx->d_markers3, &ctx->d_kb_keep,
-          &ctx->d_kb_kcounts, &ctx->d_gz_cands, &ctx->d_gz_count, &ctx->d_gz_tmp, &ctx->d_wide_res};
+  return {
+#define TBZ_X(name) &ctx->name,
+      TBZ_CTX_POOLS(TBZ_X)
+#undef TBZ_X
+  };
 }
 static uint64_t dense_total(tbz_ctx* ctx) {
   uint64_t t = 0;
@@ -812,9 +819,10 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         int rr;
         if ((rr = upload(ctx, ctx->d_redo_items, wide))) return rr;
         if ((rr = ensure(ctx, ctx->d_redo_res, wide.size() * sizeof(SegResult)))) return rr;
+        if ((rr = ensure(ctx, ctx->d_cold, wide.size() * (size_t)KG_COLD_STRIDE))) return rr;
         K1gParams kg{(const u8*)d_in, pool_tok(fix), pool_runs(fix), pool_half(fix), 0, (const Item*)ctx->d_redo_items.p,
                      (SegResult*)ctx->d_redo_res.p, d_markers_cur, d_first_marker, nullptr, nullptr, (u32)n_mark,
-                     (u32)wide.size(), ovl_for(64), sub_min_for(64), 0, resume_abs};
+                     (u32)wide.size(), ovl_for(64), sub_min_for(64), 0, resume_abs, (u8*)ctx->d_cold.p};
 #ifdef TBZ_WAVE_TRACE
         kg.trace = nullptr;
 #endif
@@ -841,9 +849,10 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       if ((rr = make_explicit(sub))) return rr;
       if ((rr = upload(ctx, ctx->d_redo_items, sub))) return rr;
       if ((rr = ensure(ctx, ctx->d_redo_res, sub.size() * sizeof(SegResult)))) return rr;
+      if ((rr = ensure(ctx, ctx->d_cold, sub.size() * (size_t)KG_COLD_STRIDE))) return rr;
       K1gParams kg{(const u8*)d_in, nullptr, nullptr, 0, 0, (const Item*)ctx->d_redo_items.p,
                    (SegResult*)ctx->d_redo_res.p, d_markers_cur, d_first_marker, nullptr, nullptr, (u32)n_mark,
-                   (u32)sub.size(), ovl_for(64), sub_min_for(64), 0, resume_abs};
+                   (u32)sub.size(), ovl_for(64), sub_min_for(64), 0, resume_abs, (u8*)ctx->d_cold.p};
 #ifdef TBZ_WAVE_TRACE
       kg.trace = nullptr;
 #endif
@@ -895,11 +904,12 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     if (!fix && G <= 16 && wide_for(G, fix) && ctx->stream2) {  // (gangs of 32: the 65 536 workgroups of config 2 that leave at once cost K1 1 - 2 %: measured)
       int rr = ensure(ctx, ctx->d_wide_res, n_it * sizeof(SegResult));
       if (rr) return rr;
+      if ((rr = ensure(ctx, ctx->d_cold2, n_it * (size_t)KG_COLD_STRIDE))) return rr;  // (only the large items' slots are touched)
       TBZ_HIP(hipEventRecord(ctx->evw[0], ctx->stream));  // (the items are there)
       TBZ_HIP(hipStreamWaitEvent(ctx->stream2, ctx->evw[0], 0));
       K1gParams kw{(const u8*)d_in, pool_tok(fix), pool_runs(fix), pool_half(fix), 1, d_items, (SegResult*)ctx->d_wide_res.p,
                    d_markers_cur, d_first_marker, nullptr, nullptr, (u32)n_mark, (u32)n_it, ovl_for(64), sub_min_for(64),
-                   wide_for(G, fix), resume_abs};
+                   wide_for(G, fix), resume_abs, (u8*)ctx->d_cold2.p};
 #ifdef TBZ_WAVE_TRACE
       kw.trace = nullptr;
 #endif
@@ -912,11 +922,13 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     int rr;
     if ((rr = ensure(ctx, ctx->d_scratch, n_it * (size_t)K1_SCRATCH))) return rr;
     if ((rr = ensure(ctx, ctx->d_hdr, n_it * sizeof(HdrRec)))) return rr;
+    if (G >= 32 && (rr = ensure(ctx, ctx->d_cold, n_it * (size_t)KG_COLD_STRIDE))) return rr;  // (narrower gangs keep their lists in LDS)
     K1hParams kh{(const u8*)d_in, d_items, (u8*)ctx->d_scratch.p, (HdrRec*)ctx->d_hdr.p, (u32)n_it};
     if (ctx->k1h) TBZ_LAUNCH(tbz_k1h_headers, (n_it + 63) / 64, ctx->stream, kh);
     K1gParams kg{(const u8*)d_in, pool_tok(fix), pool_runs(fix), pool_half(fix), 0, d_items, d_res,
                  d_markers_cur, d_first_marker, ctx->k1h ? (const HdrRec*)ctx->d_hdr.p : nullptr,
-                 (const u8*)ctx->d_scratch.p, (u32)n_mark, (u32)n_it, ovl_for(G), sub_min_for(G), wide_for(G, fix), resume_abs};
+                 (const u8*)ctx->d_scratch.p, (u32)n_mark, (u32)n_it, ovl_for(G), sub_min_for(G), wide_for(G, fix), resume_abs,
+                 (u8*)ctx->d_cold.p};
 #ifdef TBZ_WAVE_TRACE
     {
       static int n_launch = 0;
@@ -2441,11 +2453,13 @@ static int gzip_members_core(tbz_ctx* ctx, const void* d_in, size_t in_len, void
     oo[i] = pos_out;
     oc[i] = cap;
     pos_out += (cap + 15) & ~15ull;
+    if (!own_out && pos_out > out_cap) pos_out = out_cap;  // (the last range that got room ends inside the final 16 octets)
   }
   if (own_out) {
     if ((r = ensure(ctx, ctx->d_out_stage, pos_out + 64))) return r;
     d_out = ctx->d_out_stage.p;
   }
+  if (out_used) *out_used = pos_out;  // (place() must know what the ranges hold before the walk asks it for room)
   std::vector<tbz_result> res(nc);
   if ((r = inflate_passes(ctx, TBZ_FORMAT_GZIP, nc, d_in, io.data(), il.data(), d_out, oo.data(), oc.data(), res.data(), false)))
     return r;
@@ -2456,11 +2470,16 @@ static int gzip_members_core(tbz_ctx* ctx, const void* d_in, size_t in_len, void
   // member's own ISIZE: every such pair is decoded again as one stream [c_i, c_i+2) into that buffer, in ONE batch call;
   // `merged[i]` = it finished there, consuming exactly the two ranges.  Whatever else is wrong takes the one-stream
   // path of the walk below.
-  std::vector<uint8_t> merged(nc, 0);
+  std::vector<uint8_t> merged(nc, 0), dirty(nc, 0);
   {
     std::vector<size_t> idx;
+    auto whole = [&](size_t j) { return res[j].status == TBZ_FINISHED && res[j].in_consumed == il[j]; };
     for (size_t i = 0; i < nc;) {
-      if (res[i].status == TBZ_FINISHED && res[i].in_consumed == il[i]) { i++; continue; }
+      if (whole(i)) { i++; continue; }
+      // (never into the buffer of a range that decoded as a whole member itself: c_i+1 is a true member then — the
+      // pair cannot be one —, its octets are in place, and a failed merge would leave them overwritten under a result
+      // that still says "finished, checksum verified": a member whose ISIZE understates, followed by good ones)
+      if (i + 1 < nc && whole(i + 1)) { i++; continue; }
       if (i + 1 < nc && oc[i + 1] != 0) idx.push_back(i);
       i += 2;
     }
@@ -2483,6 +2502,8 @@ static int gzip_members_core(tbz_ctx* ctx, const void* d_in, size_t in_len, void
         if (rres[q].status == TBZ_FINISHED && rres[q].in_consumed == ril[q]) {
           merged[idx[q]] = 1;
           res[idx[q]] = rres[q];
+        } else {
+          dirty[idx[q] + 1] = 1;  // that range's buffer holds the failed attempt now
         }
     }
   }
@@ -2496,7 +2517,7 @@ static int gzip_members_core(tbz_ctx* ctx, const void* d_in, size_t in_len, void
       i += 2;
       continue;
     }
-    if (res[i].status == TBZ_FINISHED && res[i].in_consumed == il[i]) {
+    if (res[i].status == TBZ_FINISHED && res[i].in_consumed == il[i] && !dirty[i]) {
       if ((r = done(k, (const uint8_t*)d_out + oo[i], res[i], lo))) return r;
       k++;
       i++;
@@ -2566,9 +2587,12 @@ int tbz_inflate_gzip_members_device(tbz_ctx* ctx, const void* d_in, size_t in_le
   // the candidate ranges take [0, out_used) of d_out in candidate order (16-octet aligned, sized by their ISIZE); a member
   // that has to be decoded on its own is placed from the END of the buffer downwards
   uint64_t top = out_cap;
+  uint64_t out_used = 0;  // set by the core before its walk: the candidate ranges hold [0, out_used)
   auto place = [&](size_t, uint64_t n) -> void* {
     if (n > top) return nullptr;
-    top = (top - n) & ~15ull;
+    const uint64_t t = (top - n) & ~15ull;
+    if (t < out_used) return nullptr;  // would run into a range (whose member may have been delivered already): no room
+    top = t;
     return (uint8_t*)d_out + top;
   };
   auto done = [&](size_t k, const void* d_ptr, const tbz_result& r, uint64_t in_off) -> int {
@@ -2577,16 +2601,7 @@ int tbz_inflate_gzip_members_device(tbz_ctx* ctx, const void* d_in, size_t in_le
     member_out_off[k] = d_ptr ? (uint64_t)((const uint8_t*)d_ptr - (const uint8_t*)d_out) : 0;
     return 0;
   };
-  uint64_t out_used = 0;
-  int rc = gzip_members_core(ctx, d_in, in_len, d_out, out_cap, false, max_members, place, done, n_members, &out_used);
-  if (rc) return rc;
-  if (top < out_used)  // a member placed from the top ran into the ranges: it does not count as delivered
-    for (size_t k = 0; k < *n_members; k++)
-      if (results[k].status >= 0 && results[k].out_len && member_out_off[k] >= top && member_out_off[k] < out_used) {
-        results[k].status = TBZ_OUTPUT_OVERFLOW;
-        results[k].out_len = 0;
-      }
-  return 0;
+  return gzip_members_core(ctx, d_in, in_len, d_out, out_cap, false, max_members, place, done, n_members, &out_used);
 }
 
 int tbz_inflate_gzip_members(tbz_ctx* ctx, const uint8_t* in, size_t in_len, tbz_alloc_fn alloc, void* user,

@@ -1189,6 +1189,7 @@ struct BitReader {
   u64 wi;
   u64 bw;          // word index held in buf[0]; 2^62 (never within the window of a real index) when invalid
   u32 lo, hi, nx, o;
+  u32 nw;          // words per lane in the window (K1_INBUF; the gang kernels: KG_INBUF); multiple of 4
 };
 TBZ_DEV u32 br_word_global(const BitReader& b, u64 i) {
   u32 v = 0;
@@ -1202,7 +1203,7 @@ TBZ_DEV u32 br_word_global(const BitReader& b, u64 i) {
 // correctness never depends on when the window was loaded
 TBZ_DEV u32 br_word(const BitReader& b, u64 i) {
   u64 k = i - b.bw;
-  if (k < K1_INBUF) return b.buf[k][tbz_lane()];
+  if (k < b.nw) return b.buf[k][tbz_lane()];
   return br_word_global(b, i);
 }
 struct __attribute__((packed, aligned(4))) U32x4 {
@@ -1212,9 +1213,10 @@ struct __attribute__((packed, aligned(4))) U32x4 {
 TBZ_DEV void br_refill(BitReader& b) {
   const u32 lane = tbz_lane();
   const u64 w0 = b.wi;
-  if (w0 + K1_INBUF < b.nwords) {  // whole window inside the stream, no tail masking: 16-octet loads
+  if (w0 + b.nw < b.nwords) {  // whole window inside the stream, no tail masking: 16-octet loads
 #pragma unroll
     for (u32 k = 0; k < K1_INBUF; k += 4) {
+      if (k >= b.nw) break;
       U32x4 v = *(const U32x4*)(b.w + w0 + k);
       b.buf[k][lane] = v.a;
       b.buf[k + 1][lane] = v.b;
@@ -1222,12 +1224,13 @@ TBZ_DEV void br_refill(BitReader& b) {
       b.buf[k + 3][lane] = v.d;
     }
   } else {
-    for (u32 k = 0; k < K1_INBUF; k++) b.buf[k][lane] = br_word_global(b, w0 + k);
+    for (u32 k = 0; k < b.nw; k++) b.buf[k][lane] = br_word_global(b, w0 + k);
   }
   b.bw = w0;
 }
-TBZ_DEV void br_init(BitReader& b, const u8* in_base, u64 end_byte, u32 (*buf)[64]) {
+TBZ_DEV void br_init(BitReader& b, const u8* in_base, u64 end_byte, u32 (*buf)[64], u32 nw = K1_INBUF) {
   b.buf = buf;
+  b.nw = nw;
   b.bw = 1ull << 62;
   uintptr_t base = (uintptr_t)in_base;
   u32 mis = (u32)(base & 3);
@@ -1595,7 +1598,7 @@ TBZ_DEV u32 crc_bitwise(u32 crc, u32 byte) {
 // keep the reader's LDS window over the position (a loop of k1_byte over a long field would otherwise fetch every word
 // from memory on its own: one round trip per four octets)
 TBZ_DEV void k1_window(BitReader& b) {
-  if (b.wi + 4 > b.bw + K1_INBUF) br_refill(b);
+  if (b.wi + 4 > b.bw + b.nw) br_refill(b);
 }
 TBZ_DEV i32 k1_byte(K1State& st, u32* out, u64 p0) {
   *out = br_peek(st.br) & 0xff;
@@ -1951,8 +1954,11 @@ TBZ_KERNEL void tbz_k1h_headers(K1hParams P) {
 // ================================================================================================
 constexpr u32 KG_TBL = 9;               // index bits of the literal/length lookup table (first level)
 constexpr u32 KG_TBD = 8;               // index bits of the distance lookup table (first level)
-constexpr u32 KG_LPOOL = 352;           // second-level entries (codes longer than the index); zlib's ENOUGH bound is 340
-constexpr u32 KG_DPOOL = 128;           //   … if a code needs more, its long codes take the exact (slow) step instead
+constexpr u32 KG_LPOOL = 288;           // second-level entries (codes longer than the index).  zlib's ENOUGH bound is 340 and 352
+constexpr u32 KG_DPOOL = 64;            //   entries stood here until round 4: text blocks need 60 - 200 / 8 - 40, and the 768 octets are
+                                        //   what lets sixteen workgroups of two gangs share a CU's LDS.  If a code needs more, its
+                                        //   long codes take the exact (slow) step instead (case_deep_codes)
+constexpr u32 KG_INBUF = 12;            // words of the per-lane input window in the gang kernels (K1_INBUF in the others)
 constexpr u32 KG_RING_STRIDE = 36;     // LDS octets per lane of the token output ring (16 words + one dword of skew)
 constexpr u32 KG_SUB_MIN = 1024;        // bits of bitstream per lane per round
 constexpr u32 KG_SUB_MAX = 8192;
@@ -1970,6 +1976,13 @@ struct GangTables {  // per gang, in LDS
   u16 lfast[(1u << KG_TBL) + KG_LPOOL];
   u16 dfast[(1u << KG_TBD) + KG_DPOOL];  // while a header is parsed: octets 0-127 the code-length code's 7-bit
                                          // table, octets 128-447 the code lengths (the table is filled last)
+};
+// The canonical lists of a gang's two codes: what the BUILD works on and, afterwards, only the exact step reads (a handful
+// of times per lane and round: end of block, a code without a second-level table, the limit).  Round 4: gangs of 32 and 64
+// build them in the LDS of their input windows — dead while a code is built — and park them in the item's scratch in
+// memory (K1gParams::cold), so that the workgroup's LDS falls from 13.3 to 9.9 KB: sixteen workgroups per CU, four waves
+// per SIMD.  Narrower gangs (four or eight sets of tables per workgroup: LDS-bound anyway) keep them in LDS.
+struct GangCold {
   u16 lsym[288];            // lit/len symbols in canonical order
   u8 dsym[32];
   u32 llim[16];             // [0..14] left-aligned limits, [15] shortest code length
@@ -1977,6 +1990,8 @@ struct GangTables {  // per gang, in LDS
   u16 ldlt[16];             // slot in canonical order = (code of length L) + dlt[L]  (mod 2^16)
   u16 ddlt[16];
 };
+constexpr u32 KG_COLD_STRIDE = 1024;  // octets of scratch per item for its GangCold
+static_assert(sizeof(GangCold) == 800 && sizeof(GangCold) <= KG_COLD_STRIDE && sizeof(GangCold) % 4 == 0, "GangCold");
 static_assert(((1u << KG_TBD) + KG_DPOOL) * 2 >= 448, "dfast doubles as header scratch");
 TBZ_DEV u8* kg_lens(GangTables& gt) { return (u8*)gt.dfast + 128; }
 enum { GM_HEADER = 0, GM_BUILD = 1, GM_BLOCK = 2, GM_DONE = 3 };
@@ -2001,15 +2016,24 @@ struct GangState {  // per gang, in LDS; owned by the leader
                             //   block's.  A round is sized to what is left of the BLOCK, not of the item: the lanes
                             //   beyond an end-of-block code decode nothing that counts (measured on 256 KiB gzip members
                             //   of five blocks each: 17 of 64 lanes committed in a block's first round)
+  u32 min_len;              // shortest code length of the current lit/len code | of the distance code << 8 (GangCold::llim[15], dlim[15])
   u32 ptry;                 // 1: the round before committed next to nothing (lanes do not fall into step: a PERIODIC bitstream —
                             //   a run of one repeated match, zeros in a file, config 5): the next round tries kg_periodic
 };
+template <int G, bool COLD_IN_LDS>
+struct KgColdLds {
+  GangCold cold[64 / G];
+};
+template <int G>
+struct KgColdLds<G, false> {};
 template <int G>
 struct KgLds {
+  static constexpr bool COLD_IN_LDS = G < 32;  // (a gang's share of the windows must hold a GangCold while it builds)
   GangTables gt[64 / G];
   GangState gs[64 / G];
-  u32 inbuf[K1_INBUF][64];
+  u32 inbuf[KG_INBUF][64];
   u8 tokring[64 * KG_RING_STRIDE];  // per lane: 16 token words on their way to memory (see TokOut)
+  KgColdLds<G, COLD_IN_LDS> c;
 #ifdef TBZ_EXP_LDSPAD
   u8 exp_pad[TBZ_EXP_LDSPAD];       // (occupancy experiment: profiles/README.md)
 #endif
@@ -2039,6 +2063,7 @@ struct K1gParams {
   u32 sub_min;              // least sub-range per lane (bits, multiple of 64): what the rounds after the first one run at
   u64 wide_bits;            // gangs narrower than 64 decline items longer than this (SEG_WIDE; 0: never)
   u64 resume_bit;           // ITEM_RESUME: where the token loop of the item's first block is entered
+  u8* cold;                 // n_items * KG_COLD_STRIDE octets: where gangs of 32 / 64 keep their canonical lists (GangCold)
 #ifdef TBZ_WAVE_TRACE
   u64* trace;               // experiment builds only: 8 words per workgroup (tools/exp/wave_trace.py)
 #endif
@@ -2057,7 +2082,7 @@ TBZ_DEV void br_seek_fill(BitReader& b, u64 pos) {
 }
 // keep the words br_skip will want inside the window
 TBZ_DEV void br_ensure(BitReader& b) {
-  if (b.wi + 4 > b.bw + K1_INBUF) br_refill(b);
+  if (b.wi + 4 > b.bw + b.nw) br_refill(b);
 }
 
 TBZ_DEV u32 kg_lit_entry(u32 sym, u32 L) {
@@ -2312,7 +2337,7 @@ TBZ_DEV i32 kg_dynamic_header(GangTables& gt, GangState& gs, K1State& st) {
       u32 lo = B.lo, hi = B.hi, nx = B.nx, o = B.o, k = 3, rel = 0;
       i32 rem = lim64 <= B.pos ? 0 : ((lim64 - B.pos) > 0x7fffff00ull ? 0x7fffff00 : (i32)(lim64 - B.pos));
       const u32* wp = &B.buf[3][lane];
-      while (i < n && k + 1 <= K1_INBUF) {
+      while (i < n && k + 1 <= B.nw) {
         const u32 x1 = wp[0];
         const u32 pk = tbz_alignbit(hi, lo, o);
         const u32 e = cl[pk & 127];
@@ -2474,10 +2499,17 @@ struct __attribute__((packed, aligned(2))) U32at2 {  // two token words stored a
 
 // The hot loop.  Decodes tokens from the reader's position until a token starts at or after `target`
 // (returns 0), or the next token is anything but a plain literal / valid match inside the limit
-// (returns 1 with the reader AT that token; kg_exact_step sorts it out).  Same phase structure as
-// k1_decode_block (window reload, then at most K1_PHASE tokens out of LDS with 32-bit state), but the
-// iteration is straight-line code: both table lookups, the window advance and one 32-bit token store
-// are unconditional, only second-level lookups (long codes) branch.
+// (returns 1 with the reader AT that token; kg_exact_step sorts it out).  Phases as in k1_decode_block: the lane's
+// LDS window is reloaded, then at most K1_PHASE trips run out of LDS with no global load in between (vmcnt is one
+// in-order counter per wave).
+//
+// Round 4: the loop is priced in VECTOR instructions — tools/issue_roof.hip: a gfx950 SIMD retires ~0.57 integer VALU
+// wave-instructions per ns chip-wide whatever the occupancy (the clock gives way under load), scalar and LDS
+// instructions ride along nearly free, and this kernel sat at 0.38.  So the trip keeps NO shifting register window
+// (three words + two prefetched + a three-way select per advance: 11 VALU): the position is ONE register `p`, bits from
+// the window's first word, and every trip reads its three words straight from the lane's LDS column (conflict-free:
+// word k of lane l is bank l); target and limit are kept in the same coordinates (no rel / rem counters); the distance
+// code's bits come from one funnel shift of the 64 bits at p (`pk2:pk` >> n1, n1 <= 20) instead of two shifts and a select.
 template <bool REC>
 TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, TokOut& to, u32 cap, u32& out_,
                     i32& mdef_) {
@@ -2486,19 +2518,21 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, T
   u32& n = to.n;
   i32 mdef = mdef_;
   u32 ret;
+  const u8* wcol = (const u8*)&B.buf[0][lane];  // word k of this lane's window: wcol + 256 * k
   for (;;) {
     br_refill(B);
-    u32 lo = B.lo, hi = B.hi, nx = B.nx, o = B.o;
-    u32 k = 3;
-    i32 rem = lim64 <= B.pos ? 0 : ((lim64 - B.pos) > 0x7fffff00ull ? 0x7fffff00 : (i32)(lim64 - B.pos));
-    u32 tgt = target <= B.pos ? 0u : ((target - B.pos) > 0x7fffff00ull ? 0x7fffff00u : (u32)(target - B.pos));
-    if (REC && n + 2 * K1_PHASE > cap) tgt = 0;  // staging region nearly full: end the lane's run here
-    u32 rel = 0, it = 0;
+    const u32 o0 = B.o;
+    const u32 remb = lim64 <= B.pos ? 0u : ((lim64 - B.pos) > 0x7fffff00ull ? 0x7fffff00u : (u32)(lim64 - B.pos));
+    u32 tgtb = target <= B.pos ? 0u : ((target - B.pos) > 0x7fffff00ull ? 0x7fffff00u : (u32)(target - B.pos));
+    if (REC && n + 2 * K1_PHASE > cap) tgtb = 0;  // staging region nearly full: end the lane's run here
+    const u32 limp = remb + o0, tgtp = tgtb + o0;  // (window coordinates: bit 0 = bit 0 of the window's first word)
+    // a trip reads the words (p >> 5) .. (p >> 5) + 2 of the KG_INBUF in the window
+    const u32 stop_p = tgtp < (KG_INBUF - 2) * 32 ? tgtp : (KG_INBUF - 2) * 32;
+    u32 p = o0, it = 0;
     bool bad = false;
-    const u32* wp = &B.buf[3][lane];  // next window word (64 words = one slot apart)
     // NOTE: conditions are combined with & and | on purpose — && / || / ?: on side-effect-free terms
     // become exec-mask branches here, and every branch costs the whole wave scalar work
-    bool go = (K1_INBUF >= 5) & (rel < tgt);
+    bool go = p < stop_p;
 #ifdef TBZ_WAVE_TRACE
     if (lane == (u32)__builtin_ctzll(tbz_ballot(true))) atomicAdd(&to.cnt[1], 1u);
 #endif
@@ -2507,74 +2541,61 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, T
       if (lane == (u32)__builtin_ctzll(tbz_ballot(true))) atomicAdd(&to.cnt[0], 1u);
       to.li++;
 #endif
-      const u32 x1 = wp[0], x2 = wp[64];
-      const u32 pk = tbz_alignbit(hi, lo, o);
+      const u32* w = (const u32*)(wcol + ((p >> 5) << 8));
+      const u32 w0 = w[0], w1 = w[64], w2 = w[128];
+      const u32 pk = tbz_alignbit(w1, w0, p & 31), pk2 = tbz_alignbit(w2, w1, p & 31);  // bits p .. p+63
       u32 e = gt.lfast[pk & ((1u << KG_TBL) - 1)];
       if (((e & 15) == 0) & (e != 0)) e = gt.lfast[(1u << KG_TBL) + (e >> 7) + tbz_bfe(pk, KG_TBL, (e >> 4) & 7)];
       const u32 L = e & 15;
       const bool isM = e >= 0x8000u;
       const u32 X = tbz_bfe(e, 12, 3);  // literals carry 0 here; end-of-block / invalid entries are not `good` below
-      const u32 lenx = ((e >> 4) & 0xffu) + tbz_bfe(pk, L, X);  // literal octet, or match length - 3
-      const u32 n1 = L + X, o2 = o + n1;
-      const u32 pa = tbz_alignbit(hi, lo, o2 & 31), pb = tbz_alignbit(nx, hi, o2 & 31);
-      const u32 pd = o2 < 32 ? pa : pb;
+      const u32 n1 = L + X;             // <= 20
+      const u32 pd = tbz_alignbit(pk2, pk, n1);  // the 32 bits after the length code and its extra bits
       // both speculative lookups go out together: the distance code of a match, and the code after a literal
-      const u32 e2 = gt.lfast[(pk >> L) & ((1u << KG_TBL) - 1)];
+      const u32 e2 = gt.lfast[tbz_bfe(pk, L, KG_TBL)];
       u32 ed = gt.dfast[pd & ((1u << KG_TBD) - 1)];
       if (isM & ((ed & 15) == 0) & (ed != 0)) ed = gt.dfast[(1u << KG_TBD) + (ed >> 7) + tbz_bfe(pd, KG_TBD, (ed >> 4) & 7)];
-      const u32 DL = ed & 15, DX = tbz_bfe(ed, 9, 4);                      // kg_dist_entry
-      const u32 dm1 = (tbz_bfe(ed, 13, 2) << DX) + tbz_bfe(pd, DL, DX);  // distance - 1
-      const u32 nb1 = isM ? n1 + DL + DX : L;
+      const u32 DL = ed & 15, DX = tbz_bfe(ed, 9, 4);  // kg_dist_entry
+      const u32 pe = p + (isM ? n1 + DL + DX : L);     // where the token ends
       const bool okm = ed >= 0x8000u, okl = e < 0x1000u;
-      const i32 rem1 = rem - (i32)nb1;
       // (a token that is not `good` consumes nothing, records nothing and ends the lane's loop — by predication, not by
       // a break: every exit from a divergent loop costs the whole wave exec-mask bookkeeping on the scalar unit)
-      const bool good = (L != 0) & (isM ? okm : okl) & (rem1 >= 0);
+      const bool good = (L != 0) & (isM ? okm : okl) & (pe <= limp);
       bad = !good;
       // a second literal rides along when the code after a literal is a first-level literal too (it must
       // start before the target and end inside the limit): literal-dense sub-ranges are the slow lanes
       const u32 L2 = e2 & 15;
-      const bool pair = good & !isM & (L2 != 0) & (e2 < 0x1000u) & (rel + L < tgt) & (rem1 >= (i32)L2);
-      const u32 nbits = good ? nb1 + (pair ? L2 : 0u) : 0u;
-      const i32 rem2 = rem - (i32)nbits;
-      rem = rem2;
-      rel += nbits;
-      o += nbits;  // < 96: the window advances by up to two words
-      const u32 adv = o >> 5;
-      o &= 31;
-      const u32 nlo = adv == 0 ? lo : adv == 1 ? hi : nx;
-      const u32 nhi = adv == 0 ? hi : adv == 1 ? nx : x1;
-      const u32 nnx = adv == 0 ? nx : adv == 1 ? x1 : x2;
-      lo = nlo;
-      hi = nhi;
-      nx = nnx;
-      k += adv;
-      wp += adv * 64;
+      const bool pair = good & !isM & (L2 != 0) & (e2 < 0x1000u) & (pe < tgtp) & (pe + L2 <= limp);
+      p = good ? pe + (pair ? L2 : 0u) : p;
       if (REC) {
+        const u32 lenx = ((e >> 4) & 0xffu) + tbz_bfe(pk, L, X);           // literal octet, or match length - 3
+        const u32 dm1 = (tbz_bfe(ed, 13, 2) << DX) + tbz_bfe(pd, DL, DX);  // distance - 1
         // literal: 0x00bb (the high half is the second literal of a pair, or overwritten by the next token);
         // match: head | payload << 16
         tok_put2(to, isM ? (TOK_MATCH | lenx | (dm1 << 16)) : (lenx | (((e2 >> 4) & 0xffu) << 16)));
         const i32 d = (i32)dm1 + 1 - (i32)out;
         mdef = (good & isM & (d > mdef)) ? d : mdef;
-        n += good ? ((isM | pair) ? 2u : 1u) : 0u;
-        out += good ? (isM ? lenx + 3 : (pair ? 2u : 1u)) : 0u;
+        const u32 cnt = good ? ((isM | pair) ? 2u : 1u) : 0u;
+        n += cnt;
+        out += (good & isM) ? lenx + 3 : cnt;
       }
       if (REC && (it & 1)) {  // every other token: a whole 16-octet piece leaves the ring (at most 4 words came in)
         if (to.n - to.nf >= 8) tok_flush_piece(to);
       }
       it++;
-      go = good & (it < K1_PHASE) & (k + 2 <= K1_INBUF) & (rel < tgt);
+      go = good & (it < K1_PHASE) & (p < stop_p);
     }
-    B.pos += rel;
-    B.wi += k - 3;
-    B.lo = lo;
-    B.hi = hi;
-    B.nx = nx;
-    B.o = o;
+    // the reader, at p (words beyond the window come from memory)
+    B.pos += p - o0;
+    B.wi += p >> 5;
+    B.o = p & 31;
+    B.lo = br_word(B, B.wi);
+    B.hi = br_word(B, B.wi + 1);
+    B.nx = br_word(B, B.wi + 2);
     // (a span of ONE token never reaches the flush above: blocks of a single literal, decoded through)
     if (REC && to.n - to.nf >= 8) tok_flush_piece(to);
     if (bad) { ret = 1; break; }
-    if (rel >= tgt) { ret = 0; break; }
+    if (p >= tgtp) { ret = 0; break; }
   }
   out_ = out;
   mdef_ = mdef;
@@ -2585,8 +2606,8 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, T
 TBZ_DEV u32 kg_canon_lds(u32 pk, const u32* lim, const u16* dlt, u32 cap, u32& slot) {
   const u32 r16 = tbz_brev32(pk) >> 16;
   u32 L = 1;
-  for (int k = 0; k < 15; k++) L += r16 >= lim[k] ? 1u : 0u;
-  u32 sl = ((r16 >> (16 - (L & 15))) + dlt[L & 15]) & 0xffffu;
+  for (int k = 0; k < 15; k++) L += r16 >= tbz_ld_agent(lim + k) ? 1u : 0u;  // (the lists may live in memory: GangCold)
+  u32 sl = ((r16 >> (16 - (L & 15))) + tbz_ld_agent(dlt + (L & 15))) & 0xffffu;
   slot = sl < cap ? sl : 0;
   return L;
 }
@@ -2594,20 +2615,20 @@ TBZ_DEV u32 kg_canon_lds(u32 pk, const u32* lim, const u16* dlt, u32 cap, u32& s
 // The exact step: decode ONE token at the reader's position the long way (no lookup tables), with the
 // reference's failure rules.  Returns 0 if it was a literal or match inside the limit (consumed, and
 // recorded when `rec`); otherwise fills ro.flag / ro.e / ro.aux and returns 1.
-TBZ_DEV u32 kg_exact_step(const GangTables& gt, BitReader& B, u64 lim64, bool rec, TokOut& to, u32& out, i32& mdef,
+TBZ_DEV u32 kg_exact_step(const GangCold& gc, BitReader& B, u64 lim64, bool rec, TokOut& to, u32& out, i32& mdef,
                           RoundOut& ro, Inl& il) {
   const u64 p0 = B.pos;
   br_seek_fill(B, p0);
   const u32 pk = br_peek(B);
   u32 slot;
-  const u32 L = kg_canon_lds(pk, gt.llim, gt.ldlt, 288, slot);
+  const u32 L = kg_canon_lds(pk, gc.llim, gc.ldlt, 288, slot);
   ro.e = p0;
   if (L > 15) {
     ro.flag = RF_CODE_LIT;
     ro.aux = p0;
     return 1;
   }
-  const u32 sym = gt.lsym[slot];
+  const u32 sym = tbz_ld_agent(gc.lsym + slot);
   if (sym <= 256 || sym > 285) {
     br_skip(B, L);
     ro.aux = B.pos;
@@ -2651,13 +2672,13 @@ TBZ_DEV u32 kg_exact_step(const GangTables& gt, BitReader& B, u64 lim64, bool re
   const u32 len = base + tbz_bfe(pk, L, X);
   br_skip(B, L + X);
   const u32 pd = br_peek(B);
-  const u32 DL = kg_canon_lds(pd, gt.dlim, gt.ddlt, 32, slot);
+  const u32 DL = kg_canon_lds(pd, gc.dlim, gc.ddlt, 32, slot);
   ro.aux = B.pos;
   if (DL > 15) {
     ro.flag = RF_CODE_DIST;
     return 1;
   }
-  const u32 ds = gt.dsym[slot];
+  const u32 ds = tbz_ld_agent(gc.dsym + slot);
   if (ds > 29) {  // 30/31 (huffman-tree.lisp:172-175)
     br_skip(B, DL);
     ro.aux = B.pos;
@@ -2686,7 +2707,7 @@ TBZ_DEV u32 kg_exact_step(const GangTables& gt, BitReader& B, u64 lim64, bool re
 
 // One lane's share of a round: decode from `start`; tokens that start before rec_from are the run-up
 // (not recorded), the ones from there to the first token start >= stop are staged.
-TBZ_DEV void kg_lane_round(const GangTables& gt, BitReader& B, u64 start, u64 rec_from, u64 stop, u64 lim64,
+TBZ_DEV void kg_lane_round(const GangTables& gt, const GangCold& gc, BitReader& B, u64 start, u64 rec_from, u64 stop, u64 lim64,
                            u16* stage, u8* ring, u32 cap, RoundOut& ro, Inl il) {
   TokOut to;
   to.ring = ring;
@@ -2703,7 +2724,7 @@ TBZ_DEV void kg_lane_round(const GangTables& gt, BitReader& B, u64 start, u64 re
   while (B.pos < rec_from) {  // run-up
     if (kg_span<false>(gt, B, rec_from, lim64, to, cap, out, mdef) == 0) break;
     const u64 q = B.pos;  // (the reader is AT the token the fast loop would not take)
-    if (kg_exact_step(gt, B, lim64, false, to, out, mdef, ro, il)) {
+    if (kg_exact_step(gc, B, lim64, false, to, out, mdef, ro, il)) {
       // An invalid code or an end-of-block code met during the run-up says the lane is not on the true token sequence
       // (or that the block ends before its sub-range: nothing of it will count then).  Giving up costs the round its
       // chain; starting over ONE BIT FURTHER ON is a new draw.  Measured on 32 KiB of random octets as fixed-Huffman
@@ -2737,7 +2758,7 @@ TBZ_DEV void kg_lane_round(const GangTables& gt, BitReader& B, u64 start, u64 re
       ro.aux = B.pos;
       break;
     }
-    if (kg_exact_step(gt, B, lim64, true, to, out, mdef, ro, il)) break;
+    if (kg_exact_step(gc, B, lim64, true, to, out, mdef, ro, il)) break;
   }
   // the run is stored in whole 8-word granules: pad with no-ops and let the last pieces out
   ro.n = to.n;
@@ -2986,7 +3007,20 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
   const u64 slot0 = ip.slot0;
   u16* tok0 = ip.tok;
   K1State st;
-  br_init(st.br, P.in_base, it.end_byte, S.inbuf);
+  br_init(st.br, P.in_base, it.end_byte, S.inbuf, KG_INBUF);
+  // the gang's canonical lists: built in `bc` (LDS: the gang's share of the input windows, dead while a code is built —
+  // or a place of their own for narrow gangs), read by the exact step from `gc` (the item's scratch in memory, or `bc`)
+  constexpr bool COLD_IN_LDS = KgLds<G>::COLD_IN_LDS;
+  GangCold* bc;
+  const GangCold* gc;
+  if constexpr (COLD_IN_LDS) {
+    bc = &S.c.cold[gang];
+    gc = bc;
+  } else {
+    static_assert(sizeof(S.inbuf) / NG >= sizeof(GangCold), "a gang's share of the windows holds its canonical lists");
+    bc = (GangCold*)((u8*)S.inbuf + gang * (sizeof(S.inbuf) / NG));
+    gc = (const GangCold*)(P.cold + (u64)(have ? idx : 0) * KG_COLD_STRIDE);
+  }
   st.end_bit = it.end_byte * 8;
   st.limit_bit = fixup ? ~0ull : it.limit_bit;
   st.produced = 0;
@@ -3076,6 +3110,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
     gs.rounds = gs.valid_lanes = 0;
     gs.inl = gs.noinline = 0;
     gs.ptry = 0;
+    gs.min_len = 0;
     // (an item far larger than any block an encoder emits holds several: a first guess, replaced after the first block)
     gs.est = (have && !fixup && lim64 > it.start_bit && lim64 - it.start_bit >= KG_MULTI_BLOCK_BITS) ? KG_BLOCK_GUESS_BITS : 0u;
     if (G < 64 && have && !fixup && P.wide_bits && lim64 > it.start_bit && lim64 - it.start_bit > P.wide_bits) {
@@ -3124,9 +3159,22 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
 #pragma nounroll
         for (u32 i = g; i < 320; i += G) kg_lens(gt)[i] = (u8)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5);
       tbz_sync();
-      const i32 e1 = kg_build<G, KG_TBL, KG_LPOOL, true, u16>(kg_lens(gt), nl, gt.lsym, gt.llim, gt.ldlt, gt.lfast, g, base);
-      const i32 e2 = kg_build<G, KG_TBD, KG_DPOOL, false, u8>(kg_lens(gt) + nl, nd, gt.dsym, gt.dlim, gt.ddlt, gt.dfast, g, base);
+      st.br.bw = 1ull << 62;  // (the windows are the builders' scratch: whoever reads next reloads)
+      const i32 e1 = kg_build<G, KG_TBL, KG_LPOOL, true, u16>(kg_lens(gt), nl, bc->lsym, bc->llim, bc->ldlt, gt.lfast, g, base);
+      const i32 e2 = kg_build<G, KG_TBD, KG_DPOOL, false, u8>(kg_lens(gt) + nl, nd, bc->dsym, bc->dlim, bc->ddlt, gt.dfast, g, base);
       tbz_sync();
+      if constexpr (!COLD_IN_LDS) {  // park the lists in the item's scratch (the gang's lanes, a dword each)
+        if (building) {
+          const u32* src = (const u32*)bc;
+          u32* dst = (u32*)(P.cold + (u64)idx * KG_COLD_STRIDE);
+#pragma nounroll
+          for (u32 i = g; i < sizeof(GangCold) / 4; i += G) dst[i] = src[i];
+          if (leader) gs.min_len = bc->llim[15] | (bc->dlim[15] << 8);
+        }
+        tbz_sync();
+      } else if (leader && building) {
+        gs.min_len = bc->llim[15] | (bc->dlim[15] << 8);
+      }
       if (leader && building) {
         const i32 e = e1 ? e1 : e2;
         if (e) {
@@ -3198,7 +3246,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
       Inl il;
       il.on = inl_on;
       il.cur_bf = g == 0 ? (i32)gs.bfinal : -1;
-      kg_lane_round(gt, st.br, start, pstart ? pstart : s_g, s_g + sub, lim64, stage, S.tokring + lane * KG_RING_STRIDE, (sub >> half) - 16, ro, il);
+      kg_lane_round(gt, *gc, st.br, start, pstart ? pstart : s_g, s_g + sub, lim64, stage, S.tokring + lane * KG_RING_STRIDE, (sub >> half) - 16, ro, il);
     }
     tr_b = TBZ_TR_NOW();
     tr_round += tr_b - tr_a;
@@ -3332,7 +3380,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
         gs.status = E_INVALID_CODE;
         gs.mode = GM_DONE;
       } else {  // unassigned bit pattern: error unless the input ends inside the bits the reference needs
-        u32 need = flag_last == RF_CODE_LIT ? gt.llim[15] : gt.dlim[15];
+        u32 need = flag_last == RF_CODE_LIT ? (gs.min_len & 0xffu) : (gs.min_len >> 8);
         if (aux_last + need > st.end_bit) {
           gs.fail_pos = e_last;
           gs.status = SEG_UNDERRUN;
@@ -3406,7 +3454,8 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
   }
 TBZ_K1G_KERNEL(8, 3)
 TBZ_K1G_KERNEL(16, 3)
-TBZ_K1G_KERNEL(32, 3)
+// (round 4: the gangs of 32 too — 9.9 KB since their canonical lists left the LDS and the windows are twelve words)
+TBZ_K1G_KERNEL(32, 4)
 // (gangs of 64 have one gang's tables per workgroup — 9.8 KB of LDS, sixteen workgroups per CU — so four waves per SIMD
 // is theirs to have if the registers allow: 128 instead of 146; config 3's 4 096 members are then ONE generation of
 // workgroups, K1 3.45 -> 2.82 ms.  The narrower gangs are held at three per SIMD by their LDS.)

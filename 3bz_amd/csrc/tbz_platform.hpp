@@ -132,7 +132,7 @@ TBZ_DEV void tbz_gload128x2(const u8* p0, const u8* p1, u64 m1, tbz_u32x4& a, tb
       "global_load_dwordx4 %1, %4, off sc1\n\ts_mov_b64 exec, %2\n\ts_waitcnt vmcnt(0)"
       : "=&v"(a), "=&v"(b), "=&s"(keep)
       : "v"(p0), "v"(p1), "s"(m1)
-      : "memory");
+      : "memory", "scc");  // (s_and_b64 writes SCC; EXEC is saved and restored inside the statement)
 }
 // the same over two planes (p: octets, q: marks)
 TBZ_DEV void tbz_gload128x4(const u8* p0, const u8* p1, const u8* q0, const u8* q1, u64 m1, tbz_u32x4& a, tbz_u32x4& b,
@@ -145,7 +145,7 @@ TBZ_DEV void tbz_gload128x4(const u8* p0, const u8* p1, const u8* q0, const u8* 
       "s_mov_b64 exec, %4\n\ts_waitcnt vmcnt(0)"
       : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&s"(keep)
       : "v"(p0), "v"(p1), "v"(q0), "v"(q1), "s"(m1)
-      : "memory");
+      : "memory", "scc");
 }
 // eight octets of each of two addresses
 TBZ_DEV void tbz_gload64x2(const u8* p0, const u8* p1, u64& a, u64& b) {
@@ -160,6 +160,12 @@ TBZ_DEV void tbz_gload8x2(const u8* p0, const u8* p1, u32& a, u32& b) {
                : "v"(p0), "v"(p1)
                : "memory");
 }
+// loads that see what ANOTHER lane of this workgroup stored to memory earlier in the kernel (the gang kernels' parked
+// canonical lists: stored once per block, read back by the exact step): agent-scope loads are served by L2, past the CU's
+// vector L1, which a store does not refresh — a line read while it held the previous block's lists would be served stale
+TBZ_DEV u32 tbz_ld_agent(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+TBZ_DEV u32 tbz_ld_agent(const u16* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+TBZ_DEV u32 tbz_ld_agent(const u8* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // every vector-memory operation this wave has issued (stores too) is complete
 TBZ_DEV void tbz_vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 

@@ -328,6 +328,9 @@ TBZ_DEV u32 tbz_dot4_u8(u32 x, u32 w, u32 acc) {
   for (int k = 0; k < 4; k++) acc += ((x >> (8 * k)) & 0xff) * ((w >> (8 * k)) & 0xff);
   return acc;
 }
+TBZ_DEV u32 tbz_ld_agent(const u32* p) { return *p; }
+TBZ_DEV u32 tbz_ld_agent(const u16* p) { return *p; }
+TBZ_DEV u32 tbz_ld_agent(const u8* p) { return *p; }
 TBZ_DEV u32 tbz_alignbit(u32 hi, u32 lo, u32 o) { return (u32)(((((u64)hi) << 32) | lo) >> (o & 31)); }
 TBZ_DEV u32 tbz_bfe(u32 v, u32 off, u32 n) { return n ? ((v >> (off & 31)) & (n >= 32 ? ~0u : ((1u << n) - 1))) : 0; }
 TBZ_DEV u32 tbz_readlane(u32 v, u32 i) { return (u32)tbz_emu::xchg(v, i); }

@@ -1034,6 +1034,35 @@ def case_gzip_members(eng, n_members=8, max_len=12_000, n_false=300):
         eng.free(d_out)
     assert [bytes(m) for m in A.decompress_gzip_members(blob + b"\x00trailing", engine=eng)] == plains
     assert [bytes(m) for m in A.decompress_gzip_members(b"xx" + blob, start=2, engine=eng)] == plains
+    # a member whose ISIZE understates (3bz does not check ISIZE, gzip.lisp:277-286; members over 4 GiB do it by
+    # construction), followed by good members: its range overflows the buffer sized by the lie, and the second chance
+    # must not be taken in the NEXT member's buffer — that member has decoded correctly there (it was
+    # delivered with status 0 and a verified crc over octets the failed merge had overwritten)
+    lp = [K.enwik_like(9000, seed=301), K.enwik_like(7000, seed=302), K.enwik_like(5000, seed=303)]
+    lparts = [pygzip.compress(q, 6, mtime=0) for q in lp]
+    lparts[0] = lparts[0][:-4] + struct.pack("<I", 1500)
+    lblob = b"".join(lparts)
+    got = A.decompress_gzip_members(lblob, engine=eng)
+    assert [bytes(m) for m in got] == lp, "lying ISIZE: host variant"
+    room = sum(len(q) for q in lp) * 2 + 4096
+    d_in, d_out = eng.malloc(len(lblob) + 64), eng.malloc(room + 64)
+    try:
+        eng.h2d(d_in, lblob)
+        res, ioffs, ooffs = eng.inflate_gzip_members_device(d_in, len(lblob), d_out, room, 64)
+        host = bytearray(room)
+        eng.d2h(host, d_out)
+        assert len(res) == 3
+        for r, oo_, q in zip(res, ooffs, lp):
+            assert r.status == 0 and r.out_len == len(q) and r.crc32 == zlib.crc32(q), (r.status, r.out_len)
+            assert bytes(host[oo_:oo_ + len(q)]) == q, "lying ISIZE: device variant"
+        # no room above the ranges for the member that must be decoded on its own: it says so, and the members already
+        # delivered keep their octets (place() handed out space inside the ranges)
+        tight = 1500 + 16 + len(lp[1]) + 16 + len(lp[2]) + 16 + 2000
+        res, ioffs, ooffs = eng.inflate_gzip_members_device(d_in, len(lblob), d_out, tight, 64)
+        assert res[0].status == 2 and len(res) == 1, [r.status for r in res]
+    finally:
+        eng.free(d_in)
+        eng.free(d_out)
     # a damaged / truncated member raises what the one-member call at its offset raises
     for bad, start in ((blob[:-3], len(blob) - len(parts[-1])), (blob[:len(parts[0]) - 8] + b"\x00" + blob[len(parts[0]) - 7:], 0),
                        (b"\x1f\x8c" + blob[2:], 0)):

@@ -37,7 +37,8 @@ class Timings(C.Structure):
                 ("token_words", C.c_uint64), ("n_segments", C.c_uint64), ("n_groups", C.c_uint64),
                 ("find_ms", C.c_float), ("resolve_ms", C.c_float), ("k1_gang", C.c_uint32), ("k2_kinds", C.c_uint32),
                 ("n_candidates", C.c_uint64), ("n_hgroups", C.c_uint64), ("scratch_bytes", C.c_uint64),
-                ("h2d_copies", C.c_uint32), ("passes", C.c_uint32)]
+                ("h2d_copies", C.c_uint32), ("passes", C.c_uint32),
+                ("h2d_ms", C.c_float), ("host_decode_ms", C.c_float), ("d2h_ms", C.c_float), ("reserved4", C.c_uint32)]
 
 
 assert C.sizeof(Result) == 64

@@ -19,6 +19,10 @@
 // from that block's start by a fix-up item that ignores markers it crosses.
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -54,6 +58,100 @@ struct DevBuf {
   X(d_kc_slots) X(d_kc_ends) X(d_kc_link) X(d_kc_fm2) X(d_markers3) X(d_kb_keep) X(d_kb_kcounts) X(d_gz_cands) \
   X(d_gz_count) X(d_gz_tmp) X(d_wide_res) X(d_cold) X(d_cold2)
 
+namespace tbz {
+// A few host threads that copy between a caller's (pageable) buffer and the pinned staging buffers: one thread moves
+// ~10 GB/s, PCIe Gen5 x16 ~55 — the staging copy must not be what a host-to-host call waits for.  Created on the first
+// large staged copy of a context, parked on a condition variable between jobs.
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#else
+  std::this_thread::yield();
+#endif
+}
+struct CopySeg {
+  uint8_t* dst;
+  const uint8_t* src;
+  size_t len;
+};
+struct CopyPool {
+  static constexpr size_t PIECE = 256u << 10;
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::atomic<uint64_t> gen{0};
+  bool stop = false;
+  // the job (written under `mu`, and only while no worker is inside work())
+  const CopySeg* segs = nullptr;
+  size_t nsegs = 0;
+  std::atomic<size_t> next{0};
+  std::atomic<size_t> left{0};   // segments not yet copied
+  std::atomic<int> inside{0};    // workers between taking a job and leaving work()
+  std::vector<CopySeg> tmp;
+  void work() {
+    for (;;) {
+      const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= nsegs) return;
+      memcpy(segs[i].dst, segs[i].src, segs[i].len);
+      left.fetch_sub(1, std::memory_order_release);
+    }
+  }
+  void start(int nthreads) {
+    for (int t = 0; t < nthreads; t++)
+      th.emplace_back([this]() {
+        uint64_t seen = 0;
+        for (;;) {
+          // a staged copy is a run of jobs a fraction of a millisecond apart: look for the next one for a while before
+          // going to sleep (a condition-variable wake-up costs as much as copying a megabyte)
+          for (int spin = 0; spin < 20000 && gen.load(std::memory_order_acquire) == seen; spin++) cpu_relax();
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&]() { return stop || gen.load() != seen; });
+            if (stop) return;
+            seen = gen.load();
+            inside.fetch_add(1);  // (under the lock: the job cannot change until this worker has left work())
+          }
+          work();
+          inside.fetch_sub(1, std::memory_order_release);
+        }
+      });
+  }
+  // copy every segment (any sizes); the calling thread works too
+  void run(const CopySeg* sg, size_t ns) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      while (inside.load(std::memory_order_acquire)) std::this_thread::yield();  // a late waker of the job before
+      segs = sg;
+      nsegs = ns;
+      next.store(0);
+      left.store(ns);
+      gen.fetch_add(1, std::memory_order_release);
+    }
+    cv.notify_all();
+    work();
+    while (left.load(std::memory_order_acquire)) cpu_relax();
+  }
+  void copy(void* d, const void* s_, size_t bytes) {
+    if (bytes < 4 * PIECE || th.empty()) {
+      memcpy(d, s_, bytes);
+      return;
+    }
+    tmp.clear();
+    for (size_t off = 0; off < bytes; off += PIECE)
+      tmp.push_back(CopySeg{(uint8_t*)d + off, (const uint8_t*)s_ + off, std::min(PIECE, bytes - off)});
+    run(tmp.data(), tmp.size());
+  }
+  ~CopyPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    for (auto& t : th) t.join();
+  }
+};
+}  // namespace tbz
+
 struct tbz_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -68,6 +166,13 @@ struct tbz_ctx {
   bool host_layout = false;  // env TBZ_HOST_LAYOUT=1: always chain / lay out on the host (tests force both paths)
   void* h_pin = nullptr;     // pinned host scratch for small read-backs
   size_t h_pin_cap = 0;
+  // host <-> device staging of the host-buffer entry points (stage_in / stage_out below): two pinned buffers per
+  // direction, an event per buffer, a pool of copying threads
+  void* h_stage[4] = {};     // [0], [1]: towards the device; [2], [3]: from it
+  hipEvent_t ev_stage[4] = {};
+  tbz::CopyPool* copy_pool = nullptr;
+  int copy_threads = 8;      // env TBZ_COPY_THREADS (1: the calling thread alone)
+  size_t stage_chunk = 16u << 20;  // env TBZ_STAGE_CHUNK_KIB
   int k1_mode = 0;  // 0 auto, 1 lane-per-item, 4..64 gang of that many lanes (env TBZ_K1_MODE; tests force each)
   bool sym_hist = true;  // groups that need history they do not hold run against symbolic history + K6 (env TBZ_HIST=off:
                          // they join their predecessors' group instead, one workgroup per chain, as in round 1)
@@ -161,6 +266,132 @@ static int pinned(tbz_ctx* ctx, size_t bytes) {
   TBZ_HIP(hipHostMalloc(&ctx->h_pin, bytes * 2));
   ctx->h_pin_cap = bytes * 2;
   return 0;
+}
+
+// ---- host <-> device staging for the host-buffer entry points (the path a 3bz caller takes: a Lisp vector in, a Lisp
+// vector out — api.lisp:23-65, bench.lisp:90-120).  A caller's buffer is ordinary pageable memory: handing it to
+// hipMemcpyAsync makes the runtime stage it through its own pinned bounce buffer at a fraction of the link's rate.  Here
+// it goes through two pinned buffers of the context: while the DMA engine moves one, the copy pool fills (or drains) the
+// other, so that the link is busy all the time and the host copy costs nothing on top.
+static double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static int stage_setup(tbz_ctx* ctx) {
+  if (ctx->h_stage[0]) return 0;
+  for (int k = 0; k < 4; k++) {
+    TBZ_HIP(hipHostMalloc(&ctx->h_stage[k], ctx->stage_chunk));
+    TBZ_HIP(hipEventCreate(&ctx->ev_stage[k]));
+  }
+  if (ctx->copy_threads > 1) {
+    ctx->copy_pool = new CopyPool();
+    ctx->copy_pool->start(ctx->copy_threads - 1);
+  }
+  return 0;
+}
+static void stage_memcpy(tbz_ctx* ctx, void* d, const void* s, size_t n) {
+  if (ctx->copy_pool) ctx->copy_pool->copy(d, s, n); else memcpy(d, s, n);
+}
+constexpr size_t STAGE_MIN = 1u << 20;  // smaller transfers are left to the runtime (one bounce, no pipeline to fill)
+// one piece of a staged transfer: `len` octets between host memory and device offset `dev_off` of the transfer's device
+// buffer.  Pieces are in ascending device order and do not overlap (the streams of a batch, 16-octet aligned).
+struct StagePiece {
+  uint8_t* host;
+  uint64_t dev_off;
+  uint64_t len;
+};
+// the parts of pieces[*cursor ...] that fall into device range [lo, hi): copy segments between host and a pinned buffer
+// whose octet 0 corresponds to device offset lo
+static void stage_segments(const std::vector<StagePiece>& ps, size_t& cursor, uint64_t lo, uint64_t hi, uint8_t* pin, bool to_pin,
+                           std::vector<CopySeg>& out) {
+  out.clear();
+  while (cursor < ps.size() && ps[cursor].dev_off + ps[cursor].len <= lo) cursor++;
+  for (size_t i = cursor; i < ps.size() && ps[i].dev_off < hi; i++) {
+    const uint64_t a = std::max(lo, ps[i].dev_off), b = std::min(hi, ps[i].dev_off + ps[i].len);
+    for (uint64_t x = a; x < b; x += CopyPool::PIECE) {
+      const size_t n = (size_t)std::min<uint64_t>(CopyPool::PIECE, b - x);
+      uint8_t* h = ps[i].host + (x - ps[i].dev_off);
+      uint8_t* p = pin + (x - lo);
+      out.push_back(to_pin ? CopySeg{p, h, n} : CopySeg{h, p, n});
+    }
+  }
+}
+static void stage_run(tbz_ctx* ctx, const std::vector<CopySeg>& sg) {
+  if (sg.empty()) return;
+  if (ctx->copy_pool && sg.size() > 1) {
+    ctx->copy_pool->run(sg.data(), sg.size());
+  } else {
+    for (const CopySeg& c : sg) memcpy(c.dst, c.src, c.len);
+  }
+}
+// host -> device: the pieces go to d_base + dev_off, enqueued on the context's stream (what follows on the stream sees
+// the octets; the caller's buffers are free when this returns).  The gaps between pieces are transferred as they are.
+static int stage_in(tbz_ctx* ctx, void* d_base, const std::vector<StagePiece>& ps) {
+  if (ps.empty()) return 0;
+  const uint64_t lo0 = ps.front().dev_off, hi0 = ps.back().dev_off + ps.back().len;
+  if (hi0 - lo0 < STAGE_MIN) {
+    for (const StagePiece& q : ps)
+      if (q.len) TBZ_HIP(hipMemcpyAsync((uint8_t*)d_base + q.dev_off, q.host, q.len, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+  }
+  int r = stage_setup(ctx);
+  if (r) return r;
+  const uint64_t ch = ctx->stage_chunk;
+  std::vector<CopySeg> sg;
+  size_t cursor = 0, k = 0;
+  for (uint64_t off = lo0; off < hi0; off += ch, k++) {
+    const uint64_t len = std::min(ch, hi0 - off);
+    const int b = (int)(k & 1);
+    if (k >= 2) TBZ_HIP(hipEventSynchronize(ctx->ev_stage[b]));  // the buffer's previous chunk has left
+    stage_segments(ps, cursor, off, off + len, (uint8_t*)ctx->h_stage[b], true, sg);
+    stage_run(ctx, sg);
+    TBZ_HIP(hipMemcpyAsync((uint8_t*)d_base + off, ctx->h_stage[b], len, hipMemcpyHostToDevice, ctx->stream));
+    TBZ_HIP(hipEventRecord(ctx->ev_stage[b], ctx->stream));
+  }
+  // the staging buffers are reused by the next call: nothing may still be reading them then
+  for (int b = 0; b < 2; b++)
+    if (k > (size_t)b) TBZ_HIP(hipEventSynchronize(ctx->ev_stage[b]));
+  return 0;
+}
+// device -> host after everything enqueued on the context's stream; complete when this returns
+static int stage_out(tbz_ctx* ctx, const void* d_base, const std::vector<StagePiece>& ps) {
+  if (ps.empty()) return 0;
+  const uint64_t lo0 = ps.front().dev_off, hi0 = ps.back().dev_off + ps.back().len;
+  if (hi0 - lo0 < STAGE_MIN) {
+    for (const StagePiece& q : ps)
+      if (q.len) TBZ_HIP(hipMemcpyAsync(q.host, (const uint8_t*)d_base + q.dev_off, q.len, hipMemcpyDeviceToHost, ctx->stream));
+    TBZ_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+  }
+  int r = stage_setup(ctx);
+  if (r) return r;
+  const uint64_t ch = ctx->stage_chunk;
+  const size_t nch = (size_t)((hi0 - lo0 + ch - 1) / ch);
+  std::vector<CopySeg> sg;
+  size_t cursor = 0;
+  for (size_t k = 0; k <= nch; k++) {
+    if (k < nch) {  // chunk k on its way (its buffer was drained two chunks ago)
+      const int b = 2 + (int)(k & 1);
+      const uint64_t off = lo0 + k * ch;
+      TBZ_HIP(hipMemcpyAsync(ctx->h_stage[b], (const uint8_t*)d_base + off, std::min(ch, hi0 - off), hipMemcpyDeviceToHost, ctx->stream));
+      TBZ_HIP(hipEventRecord(ctx->ev_stage[b], ctx->stream));
+    }
+    if (k >= 1) {  // chunk k - 1 has arrived: to the callers' buffers while chunk k moves
+      const int b = 2 + (int)((k - 1) & 1);
+      const uint64_t off = lo0 + (k - 1) * ch;
+      TBZ_HIP(hipEventSynchronize(ctx->ev_stage[b]));
+      stage_segments(ps, cursor, off, std::min(off + ch, hi0), (uint8_t*)ctx->h_stage[b], false, sg);
+      stage_run(ctx, sg);
+    }
+  }
+  return 0;
+}
+static int stage_in(tbz_ctx* ctx, void* d_dst, const void* h_src, size_t n) {
+  if (!n) return 0;
+  return stage_in(ctx, d_dst, std::vector<StagePiece>{StagePiece{(uint8_t*)h_src, 0, n}});
+}
+static int stage_out(tbz_ctx* ctx, void* h_dst, const void* d_src, size_t n) {
+  if (!n) return 0;
+  return stage_out(ctx, d_src, std::vector<StagePiece>{StagePiece{(uint8_t*)h_dst, 0, n}});
 }
 
 // ---- CRC constant tables (host side of K5) ---------------------------------------------------
@@ -1913,6 +2144,9 @@ int tbz_ctx_create(int device_id, tbz_ctx** out_ctx) {
     t.debug2 = getenv("TBZ_DEBUG2") != nullptr;
     if (const char* m = getenv("TBZ_DEBUG_CANDS")) t.debug_cands = m;
   }
+  if (const char* m = getenv("TBZ_COPY_THREADS")) ctx->copy_threads = std::max(1, std::min(64, atoi(m)));
+  if (const char* m = getenv("TBZ_STAGE_CHUNK_KIB")) ctx->stage_chunk = (size_t)std::max(64, atoi(m)) << 10;
+  ctx->copy_threads = std::min<int>(ctx->copy_threads, std::max(1u, std::thread::hardware_concurrency()));
   if (const char* m = getenv("TBZ_HOST_LAYOUT")) ctx->host_layout = m[0] == '1';
   if (const char* m = getenv("TBZ_K2_MODE")) ctx->k2_single = !strcmp(m, "single");
   if (const char* m = getenv("TBZ_K1H")) ctx->k1h = m[0] != '0';
@@ -1939,6 +2173,11 @@ void tbz_ctx_destroy(tbz_ctx* ctx) {
   for (auto& b : ctx->dense)
     if (b.p) hipFree(b.p);
   if (ctx->h_pin) hipHostFree(ctx->h_pin);
+  delete ctx->copy_pool;
+  for (int k = 0; k < 4; k++) {
+    if (ctx->h_stage[k]) hipHostFree(ctx->h_stage[k]);
+    if (ctx->ev_stage[k]) hipEventDestroy(ctx->ev_stage[k]);
+  }
   for (auto& ev : ctx->ev)
     if (ev) hipEventDestroy(ev);
   for (auto& ev : ctx->evw)
@@ -2611,7 +2850,7 @@ int tbz_inflate_gzip_members(tbz_ctx* ctx, const uint8_t* in, size_t in_len, tbz
   TBZ_HIP(hipSetDevice(ctx->device));
   int r;
   if ((r = ensure(ctx, ctx->d_in_stage, in_len + 64))) return r;
-  if (in_len) TBZ_HIP(hipMemcpyAsync(ctx->d_in_stage.p, in, in_len, hipMemcpyHostToDevice, ctx->stream));
+  if ((r = stage_in(ctx, ctx->d_in_stage.p, in, in_len))) return r;
   auto place = [&](size_t, uint64_t n) -> void* {
     if (ensure(ctx, ctx->d_gz_tmp, n + 64)) return nullptr;
     return ctx->d_gz_tmp.p;
@@ -2623,7 +2862,8 @@ int tbz_inflate_gzip_members(tbz_ctx* ctx, const uint8_t* in, size_t in_len, tbz
       uint8_t* out = alloc(user, (size_t)res.out_len);
       if (res.out_len) {
         if (!out) return TBZ_E_NOMEM;
-        TBZ_HIP(hipMemcpy(out, d_ptr, res.out_len, hipMemcpyDeviceToHost));
+        int rr = stage_out(ctx, out, d_ptr, res.out_len);
+        if (rr) return rr;
       }
     }
     return 0;
@@ -2675,27 +2915,39 @@ static int stage_batch(tbz_ctx* ctx, int format, size_t n, const uint8_t* const*
   int r;
   if ((r = ensure(ctx, ctx->d_in_stage, it + 64))) return r;
   if (!size_only && (r = ensure(ctx, ctx->d_out_stage, ot + 64))) return r;
-  for (size_t i = 0; i < n; i++)
-    if (in_lens[i]) {
-      if (!ins[i]) return TBZ_E_ARG;
-      TBZ_HIP(hipMemcpyAsync((uint8_t*)ctx->d_in_stage.p + io[i], ins[i], in_lens[i], hipMemcpyHostToDevice,
-                             ctx->stream));
-    }
+  const double t_in = now_ms();
+  {
+    std::vector<StagePiece> ps;
+    for (size_t i = 0; i < n; i++)
+      if (in_lens[i]) {
+        if (!ins[i]) return TBZ_E_ARG;
+        ps.push_back(StagePiece{(uint8_t*)ins[i], io[i], in_lens[i]});
+      }
+    if ((r = stage_in(ctx, ctx->d_in_stage.p, ps))) return r;
+  }
+  const double t_dec = now_ms();
   uint32_t n_h2d = 0;
   for (size_t i = 0; i < n; i++) n_h2d += in_lens[i] ? 1u : 0u;
   r = inflate_passes(ctx, format, n, ctx->d_in_stage.p, io.data(), il.data(), size_only ? nullptr : ctx->d_out_stage.p,
                      oo.data(), oc.data(), results, size_only);
   ctx->tim.h2d_copies = n_h2d;
   if (r) return r;
+  const double t_out = now_ms();
   if (!size_only) {
+    std::vector<StagePiece> ps;
     for (size_t i = 0; i < n; i++)
       if (results[i].status >= 0 && results[i].out_len) {
         if (!outs[i]) return TBZ_E_ARG;
-        TBZ_HIP(hipMemcpyAsync(outs[i], (const uint8_t*)ctx->d_out_stage.p + oo[i], results[i].out_len,
-                               hipMemcpyDeviceToHost, ctx->stream));
+        ps.push_back(StagePiece{outs[i], oo[i], results[i].out_len});
       }
+    if ((r = stage_out(ctx, ctx->d_out_stage.p, ps))) return r;
     TBZ_HIP(hipStreamSynchronize(ctx->stream));
   }
+  // host wall-clock of the three legs of a host-to-host call (the first leg ends when the last input chunk has been
+  // handed to the DMA engine: its tail overlaps the decode)
+  ctx->tim.h2d_ms = (float)(t_dec - t_in);
+  ctx->tim.host_decode_ms = (float)(t_out - t_dec);
+  ctx->tim.d2h_ms = (float)(now_ms() - t_out);
   return 0;
 }
 
@@ -2783,7 +3035,7 @@ int tbz_inflate_alloc(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len
   TBZ_HIP(hipSetDevice(ctx->device));
   int r;
   if ((r = ensure(ctx, ctx->d_in_stage, in_len + 64))) return r;
-  if (in_len) TBZ_HIP(hipMemcpyAsync(ctx->d_in_stage.p, in, in_len, hipMemcpyHostToDevice, ctx->stream));
+  if ((r = stage_in(ctx, ctx->d_in_stage.p, in, in_len))) return r;
   CoreOpts opt;
   int alloc_err = 0;
   opt.alloc = [&](uint64_t total) -> void* {
@@ -2798,8 +3050,7 @@ int tbz_inflate_alloc(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len
     uint8_t* out = alloc(user, (size_t)res->out_len);
     if (res->out_len) {
       if (!out) return TBZ_E_NOMEM;
-      TBZ_HIP(hipMemcpyAsync(out, ctx->d_out_stage.p, res->out_len, hipMemcpyDeviceToHost, ctx->stream));
-      TBZ_HIP(hipStreamSynchronize(ctx->stream));
+      if ((r = stage_out(ctx, out, ctx->d_out_stage.p, res->out_len))) return r;
     }
   }
   return 0;
@@ -2814,7 +3065,7 @@ int tbz_inflate_to_device(tbz_ctx* ctx, int format, const uint8_t* in, size_t in
   TBZ_HIP(hipSetDevice(ctx->device));
   int r;
   if ((r = ensure(ctx, ctx->d_in_stage, in_len + 64))) return r;
-  if (in_len) TBZ_HIP(hipMemcpyAsync(ctx->d_in_stage.p, in, in_len, hipMemcpyHostToDevice, ctx->stream));
+  if ((r = stage_in(ctx, ctx->d_in_stage.p, in, in_len))) return r;
   CoreOpts opt;
   void* buf = nullptr;
   opt.alloc = [&](uint64_t total) -> void* {

@@ -1142,6 +1142,10 @@ constexpr u32 K1_SCRATCH = 512;   // octets of global scratch per item: lens[320
 constexpr u32 K1_SC_LENS = 0;
 constexpr u32 K1_INBUF = 16;      // 32-bit words of compressed input windowed per lane (64 octets); multiple of 4
 constexpr u32 K1_PHASE = 32;      // tokens decoded per phase between window reloads
+#ifndef TBZ_EXP_PHASE
+#define TBZ_EXP_PHASE 32
+#endif
+constexpr u32 KG_PHASE = TBZ_EXP_PHASE;  // the same for the gang kernels' trips
 constexpr u32 K1_LCAP = 288;      // every lit/len symbol (canonical order) is held in LDS per lane
 
 // Per-workgroup LDS, every array LANE-INTERLEAVED ([index][lane]): the bank depends on the lane only, so
@@ -1954,11 +1958,29 @@ TBZ_KERNEL void tbz_k1h_headers(K1hParams P) {
 // ================================================================================================
 constexpr u32 KG_TBL = 9;               // index bits of the literal/length lookup table (first level)
 constexpr u32 KG_TBD = 8;               // index bits of the distance lookup table (first level)
-constexpr u32 KG_LPOOL = 288;           // second-level entries (codes longer than the index).  zlib's ENOUGH bound is 340 and 352
-constexpr u32 KG_DPOOL = 64;            //   entries stood here until round 4: text blocks need 60 - 200 / 8 - 40, and the 768 octets are
-                                        //   what lets sixteen workgroups of two gangs share a CU's LDS.  If a code needs more, its
-                                        //   long codes take the exact (slow) step instead (case_deep_codes)
-constexpr u32 KG_INBUF = 12;            // words of the per-lane input window in the gang kernels (K1_INBUF in the others)
+// second-level entries (codes longer than the index); zlib's ENOUGH bound is 340.  If a code needs more, ALL its long codes
+// take the exact (slow) step instead (case_deep_codes).  Gangs of 32 — two gangs' tables per workgroup — have smaller pools
+// since round 4: the 16 KiB segments they decode have shallow codes (60 - 200 / 8 - 40 entries), and the 768 octets are what
+// lets sixteen workgroups share a CU's LDS; the gangs of 64 decode whole zlib blocks (codes of up to 15 bits) and keep 352 / 128
+#ifndef TBZ_EXP_LPOOL32
+#define TBZ_EXP_LPOOL32 288
+#endif
+#ifndef TBZ_EXP_DPOOL32
+#define TBZ_EXP_DPOOL32 64
+#endif
+template <int G>
+struct KgPools {
+  static constexpr u32 L = G == 32 ? TBZ_EXP_LPOOL32 : 352, D = G == 32 ? TBZ_EXP_DPOOL32 : 128;
+};
+// words of the per-lane input window: twelve for the gangs of 32 (with their canonical lists parked in memory: 9.9 KB,
+// sixteen workgroups per CU), K1_INBUF for the others.  Measured (round 4, K1 ms on config 3 / the 64 MiB no-flush stream,
+// gangs of 64): 12 words + lists in memory 2.80 / 0.71; 16 words 2.59 / 0.70; lists in LDS 2.62 / 0.70; both 2.53 / 0.70 —
+// a gang of 64 has ONE set of tables per workgroup and fits sixteen per CU either way
+template <int G>
+struct KgShape {
+  static constexpr u32 INBUF = G == 32 ? 12 : K1_INBUF;
+  static constexpr bool COLD_IN_LDS = G != 32;  // (else: a gang's share of the windows must hold a GangCold while it builds)
+};
 constexpr u32 KG_RING_STRIDE = 36;     // LDS octets per lane of the token output ring (16 words + one dword of skew)
 constexpr u32 KG_SUB_MIN = 1024;        // bits of bitstream per lane per round
 constexpr u32 KG_SUB_MAX = 8192;
@@ -1972,10 +1994,13 @@ constexpr u32 KG_OVL = 512;             // least run-up bits before a lane's sub
 //   lit/len:  bits 4-11 literal octet | (length base - 3);  bits 12-15: 0 literal, 8+X match with X extra
 //             bits, 7 end of block, 6 symbol 286/287
 //   distance: bits 4-8 distance symbol
-struct GangTables {  // per gang, in LDS
-  u16 lfast[(1u << KG_TBL) + KG_LPOOL];
-  u16 dfast[(1u << KG_TBD) + KG_DPOOL];  // while a header is parsed: octets 0-127 the code-length code's 7-bit
-                                         // table, octets 128-447 the code lengths (the table is filled last)
+template <u32 LPOOL, u32 DPOOL>
+struct GangTablesT {  // per gang, in LDS
+  u16 lfast[(1u << KG_TBL) + LPOOL];
+  u16 dfast[(1u << KG_TBD) + DPOOL];  // while a header is parsed: octets 0-127 the code-length code's 7-bit
+                                      // table, octets 128-447 the code lengths (the table is filled last)
+  static_assert(((1u << KG_TBD) + DPOOL) * 2 >= 448, "dfast doubles as header scratch");
+  static_assert(((1u << KG_TBL) + LPOOL) * 2 >= 1024, "lfast doubles as the gzip header's CRC table");
 };
 // The canonical lists of a gang's two codes: what the BUILD works on and, afterwards, only the exact step reads (a handful
 // of times per lane and round: end of block, a code without a second-level table, the limit).  Round 4: gangs of 32 and 64
@@ -1992,8 +2017,8 @@ struct GangCold {
 };
 constexpr u32 KG_COLD_STRIDE = 1024;  // octets of scratch per item for its GangCold
 static_assert(sizeof(GangCold) == 800 && sizeof(GangCold) <= KG_COLD_STRIDE && sizeof(GangCold) % 4 == 0, "GangCold");
-static_assert(((1u << KG_TBD) + KG_DPOOL) * 2 >= 448, "dfast doubles as header scratch");
-TBZ_DEV u8* kg_lens(GangTables& gt) { return (u8*)gt.dfast + 128; }
+template <class GT>
+TBZ_DEV u8* kg_lens(GT& gt) { return (u8*)gt.dfast + 128; }
 enum { GM_HEADER = 0, GM_BUILD = 1, GM_BLOCK = 2, GM_DONE = 3 };
 struct GangState {  // per gang, in LDS; owned by the leader
   u64 P;            // GM_BLOCK: bit position of the next token; GM_HEADER: of the next block header
@@ -2028,10 +2053,11 @@ template <int G>
 struct KgColdLds<G, false> {};
 template <int G>
 struct KgLds {
-  static constexpr bool COLD_IN_LDS = G < 32;  // (a gang's share of the windows must hold a GangCold while it builds)
-  GangTables gt[64 / G];
+  static constexpr bool COLD_IN_LDS = KgShape<G>::COLD_IN_LDS;
+  using GT = GangTablesT<KgPools<G>::L, KgPools<G>::D>;
+  GT gt[64 / G];
   GangState gs[64 / G];
-  u32 inbuf[KG_INBUF][64];
+  u32 inbuf[KgShape<G>::INBUF][64];
   u8 tokring[64 * KG_RING_STRIDE];  // per lane: 16 token words on their way to memory (see TokOut)
   KgColdLds<G, COLD_IN_LDS> c;
 #ifdef TBZ_EXP_LDSPAD
@@ -2277,7 +2303,8 @@ TBZ_DEV i32 kg_build(const u8* lens, u32 n, SymT* sorted, u32* lim, u16* dlt, u1
 
 // leader: :dynamic-huffman-block … :dht-len-table-data (deflate.lisp:577-669): leaves the code lengths
 // in kg_lens(gt) and the alphabet sizes in gs.hlit / gs.hdist
-TBZ_DEV i32 kg_dynamic_header(GangTables& gt, GangState& gs, K1State& st) {
+template <class GT>
+TBZ_DEV i32 kg_dynamic_header(GT& gt, GangState& gs, K1State& st) {
   const u64 p0 = st.br.pos;
   u32 pk = br_peek(st.br);
   const u32 hlit = (pk & 31) + 257, hdist = ((pk >> 5) & 31) + 1, hclen = ((pk >> 10) & 15) + 4;
@@ -2510,8 +2537,8 @@ struct __attribute__((packed, aligned(2))) U32at2 {  // two token words stored a
 // the window's first word, and every trip reads its three words straight from the lane's LDS column (conflict-free:
 // word k of lane l is bank l); target and limit are kept in the same coordinates (no rel / rem counters); the distance
 // code's bits come from one funnel shift of the 64 bits at p (`pk2:pk` >> n1, n1 <= 20) instead of two shifts and a select.
-template <bool REC>
-TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, TokOut& to, u32 cap, u32& out_,
+template <bool REC, class GT>
+TBZ_DEV u32 kg_span(const GT& gt, BitReader& B, u64 target, u64 lim64, TokOut& to, u32 cap, u32& out_,
                     i32& mdef_) {
   const u32 lane = tbz_lane();
   u32 out = out_;
@@ -2524,10 +2551,11 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, T
     const u32 o0 = B.o;
     const u32 remb = lim64 <= B.pos ? 0u : ((lim64 - B.pos) > 0x7fffff00ull ? 0x7fffff00u : (u32)(lim64 - B.pos));
     u32 tgtb = target <= B.pos ? 0u : ((target - B.pos) > 0x7fffff00ull ? 0x7fffff00u : (u32)(target - B.pos));
-    if (REC && n + 2 * K1_PHASE > cap) tgtb = 0;  // staging region nearly full: end the lane's run here
+    if (REC && n + 2 * KG_PHASE > cap) tgtb = 0;  // staging region nearly full: end the lane's run here
     const u32 limp = remb + o0, tgtp = tgtb + o0;  // (window coordinates: bit 0 = bit 0 of the window's first word)
-    // a trip reads the words (p >> 5) .. (p >> 5) + 2 of the KG_INBUF in the window
-    const u32 stop_p = tgtp < (KG_INBUF - 2) * 32 ? tgtp : (KG_INBUF - 2) * 32;
+    // a trip reads the words (p >> 5) .. (p >> 5) + 2 of the window
+    const u32 wend = (B.nw - 2) * 32;
+    const u32 stop_p = tgtp < wend ? tgtp : wend;
     u32 p = o0, it = 0;
     bool bad = false;
     // NOTE: conditions are combined with & and | on purpose — && / || / ?: on side-effect-free terms
@@ -2583,15 +2611,14 @@ TBZ_DEV u32 kg_span(const GangTables& gt, BitReader& B, u64 target, u64 lim64, T
         if (to.n - to.nf >= 8) tok_flush_piece(to);
       }
       it++;
-      go = good & (it < K1_PHASE) & (p < stop_p);
+      go = good & (it < KG_PHASE) & (p < stop_p);
     }
-    // the reader, at p (words beyond the window come from memory)
+    // the reader's POSITION, at p.  Its three words of lookahead (lo / hi / nx) are left stale: whoever reads next —
+    // the next phase, kg_exact_step, a header parse — reloads the window and seeks first (br_refill / br_seek_fill), and
+    // fetching them here would be up to three words from beyond the window, i.e. a memory round trip per phase
     B.pos += p - o0;
     B.wi += p >> 5;
     B.o = p & 31;
-    B.lo = br_word(B, B.wi);
-    B.hi = br_word(B, B.wi + 1);
-    B.nx = br_word(B, B.wi + 2);
     // (a span of ONE token never reaches the flush above: blocks of a single literal, decoded through)
     if (REC && to.n - to.nf >= 8) tok_flush_piece(to);
     if (bad) { ret = 1; break; }
@@ -2707,7 +2734,8 @@ TBZ_DEV u32 kg_exact_step(const GangCold& gc, BitReader& B, u64 lim64, bool rec,
 
 // One lane's share of a round: decode from `start`; tokens that start before rec_from are the run-up
 // (not recorded), the ones from there to the first token start >= stop are staged.
-TBZ_DEV void kg_lane_round(const GangTables& gt, const GangCold& gc, BitReader& B, u64 start, u64 rec_from, u64 stop, u64 lim64,
+template <class GT>
+TBZ_DEV void kg_lane_round(const GT& gt, const GangCold& gc, BitReader& B, u64 start, u64 rec_from, u64 stop, u64 lim64,
                            u16* stage, u8* ring, u32 cap, RoundOut& ro, Inl il) {
   TokOut to;
   to.ring = ring;
@@ -2778,7 +2806,8 @@ TBZ_DEV void kg_lane_round(const GangTables& gt, const GangCold& gc, BitReader& 
 // parse is known without decoding: if the token at P is T bits long and the raw bits from P to x are T-periodic, the
 // decoder is at a token start at every P + kT up to x (same bits, same state: same token).  kg_token_bits: length of
 // the plain literal / valid match at `pos`, 0 for anything else; kg_periodic: bits[x] == bits[x + T] over [x0, x1).
-TBZ_DEV u32 kg_token_bits(const GangTables& gt, BitReader& B, u64 pos, u64 lim64) {
+template <class GT>
+TBZ_DEV u32 kg_token_bits(const GT& gt, BitReader& B, u64 pos, u64 lim64) {
   br_seek_fill(B, pos);
   const u32 pk = br_peek(B);
   u32 e = gt.lfast[pk & ((1u << KG_TBL) - 1)];
@@ -2888,7 +2917,8 @@ TBZ_DEV void kg_block_end(GangState& gs, K1State& st, const Item& it, const K1gP
 
 // leader: block header at gs.P (deflate.lisp:518-573); stored blocks are handled completely here,
 // Huffman blocks leave the gang in GM_BUILD (or GM_BLOCK when the fixed code is already loaded)
-TBZ_DEV void kg_leader_header(GangTables& gt, GangState& gs, K1State& st, const Item& it, const K1gParams& P,
+template <class GT>
+TBZ_DEV void kg_leader_header(GT& gt, GangState& gs, K1State& st, const Item& it, const K1gParams& P,
                               u16* tok0, u32 fmt, bool fixup, u32 idx) {
   br_seek_fill(st.br, gs.P);
   gs.blk_pos = gs.P;
@@ -2990,7 +3020,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
   const bool leader = g == 0;
   const u32 idx = tbz_block() * NG + gang;
   const bool have = idx < P.n_items;
-  GangTables& gt = S.gt[gang];
+  typename KgLds<G>::GT& gt = S.gt[gang];
   GangState& gs = S.gs[gang];
   Item it{};
   if (have) it = P.items[idx];
@@ -3007,7 +3037,7 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
   const u64 slot0 = ip.slot0;
   u16* tok0 = ip.tok;
   K1State st;
-  br_init(st.br, P.in_base, it.end_byte, S.inbuf, KG_INBUF);
+  br_init(st.br, P.in_base, it.end_byte, S.inbuf, KgShape<G>::INBUF);
   // the gang's canonical lists: built in `bc` (LDS: the gang's share of the input windows, dead while a code is built —
   // or a place of their own for narrow gangs), read by the exact step from `gc` (the item's scratch in memory, or `bc`)
   constexpr bool COLD_IN_LDS = KgLds<G>::COLD_IN_LDS;
@@ -3160,8 +3190,8 @@ TBZ_DEV void k1g_body(const K1gParams& P, KgLds<G>& S) {
         for (u32 i = g; i < 320; i += G) kg_lens(gt)[i] = (u8)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5);
       tbz_sync();
       st.br.bw = 1ull << 62;  // (the windows are the builders' scratch: whoever reads next reloads)
-      const i32 e1 = kg_build<G, KG_TBL, KG_LPOOL, true, u16>(kg_lens(gt), nl, bc->lsym, bc->llim, bc->ldlt, gt.lfast, g, base);
-      const i32 e2 = kg_build<G, KG_TBD, KG_DPOOL, false, u8>(kg_lens(gt) + nl, nd, bc->dsym, bc->dlim, bc->ddlt, gt.dfast, g, base);
+      const i32 e1 = kg_build<G, KG_TBL, KgPools<G>::L, true, u16>(kg_lens(gt), nl, bc->lsym, bc->llim, bc->ldlt, gt.lfast, g, base);
+      const i32 e2 = kg_build<G, KG_TBD, KgPools<G>::D, false, u8>(kg_lens(gt) + nl, nd, bc->dsym, bc->dlim, bc->ddlt, gt.dfast, g, base);
       tbz_sync();
       if constexpr (!COLD_IN_LDS) {  // park the lists in the item's scratch (the gang's lanes, a dword each)
         if (building) {

@@ -62,6 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--gen-only", action="store_true", help="generate (and cache) the workload, then exit")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
     ap.add_argument("--lib", default=None, help="engine library (tests: the CPU lane-emulator build)")
+    ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host leg (pageable host buffers through tbz_inflate)")
     ap.add_argument("--no-others", action="store_true", help="the default run also times every other config (one child "
                     "process each, before this process touches the GPU) and attaches their lines as `other_configs`: skip that")
     return ap.parse_args(argv)
@@ -410,6 +411,58 @@ def main(argv=None):
         except Exception:
             pass
 
+    # ---- the path a 3bz caller takes ("report host-to-host separately"; api.lisp:23-65, bench.lisp:90-120):
+    # input in an ordinary (pageable) host buffer, output into a preallocated ordinary host buffer, through tbz_inflate /
+    # tbz_inflate_batch.  Never `value`.  The ceiling beside it: what hipMemcpy moves on this box between PINNED host
+    # memory and the device (torch's pinned tensors), each direction alone.
+    h2h = None
+    if rank == 0 and world == 1 and n and blob is None and not emu and not args.no_h2h:
+        h_ins = [s for s, _, _ in wl.streams]
+        h_outs = [bytearray(len(p)) for _, p, _ in wl.streams]
+        def h2h_step():
+            if n == 1:
+                return [eng.inflate(h_ins[0], fmt, h_outs[0])]
+            return eng.inflate_batch(h_ins, fmt, h_outs)
+        hres = h2h_step()  # warm-up: staging buffers, copy threads, first touch of the output pages
+        legs = {"h2d_ms": 0.0, "decode_ms": 0.0, "d2h_ms": 0.0}
+        hs = max(1, min(5, args.steps))
+        t1 = time.perf_counter()
+        for _ in range(hs):
+            hres = h2h_step()
+            ht = eng.timings()
+            legs["h2d_ms"] += ht.h2d_ms / hs
+            legs["decode_ms"] += ht.host_decode_ms / hs
+            legs["d2h_ms"] += ht.d2h_ms / hs
+        hdt = (time.perf_counter() - t1) / hs
+        for (s, p, _), r, o in zip(wl.streams, hres, h_outs):
+            assert r.status == 0 and r.out_len == len(p), (r.status, r.out_len)
+            if not args.no_verify:
+                assert np.array_equal(np.frombuffer(o, dtype=np.uint8), np.frombuffer(p, dtype=np.uint8)), "host-to-host output differs"
+        # the link's rate, each direction alone, pinned memory, 256 MiB
+        nb = 256 << 20
+        hp = torch.empty(nb, dtype=torch.uint8).pin_memory()
+        dp = torch.empty(nb, dtype=torch.uint8, device=dev)
+        rates = {}
+        for name, fn in (("h2d", lambda: dp.copy_(hp, non_blocking=True)), ("d2h", lambda: hp.copy_(dp, non_blocking=True))):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            rates[name] = 4 * nb / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del hp, dp
+        slower = min(rates.values())
+        h2h = {"value": wl.U / hdt / 1e6, "unit": "MB/s", "ms_per_step": hdt * 1e3, "steps": hs, **{k: round(v, 3) for k, v in legs.items()},
+               "bytes_up": wl.C, "bytes_down": wl.U,
+               "hipMemcpy_pinned_GBs": {k: round(v, 2) for k, v in rates.items()},
+               "frac_of_slower_copy_rate": (wl.U / hdt / 1e9) / slower,
+               "what": "tbz_inflate%s on pageable host buffers: chunks through two pinned buffers per direction (copy threads fill one "
+                       "while the DMA engine moves the other); h2d_ms / decode_ms / d2h_ms are the call's three legs (host wall clock)"
+                       % ("_batch" if n > 1 else "")}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and n:
         from oracle import oracle as O
@@ -453,6 +506,7 @@ def main(argv=None):
                        "gen_seconds": round(gen_s, 1), "backend": args.backend},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "host_to_host": h2h,
         }
         if others is not None:
             line["other_configs"] = others

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TBZ_ABI_VERSION 3
+#define TBZ_ABI_VERSION 4
 
 /* decompress-vector's :format keyword (api.lisp:31-34) */
 enum { TBZ_FORMAT_DEFLATE = 0, TBZ_FORMAT_ZLIB = 1, TBZ_FORMAT_GZIP = 2 };
@@ -120,6 +120,12 @@ typedef struct tbz_timings {
   uint32_t h2d_copies;   /* host->device input copies of the call (tbz_inflate / _size: 1 per staging) */
   uint32_t passes;       /* 0/1: one pass; otherwise the batch was decoded in this many passes over consecutive streams
                             because its scratch would have exceeded the pool cap */
+  /* ---- ABI 4: the three legs of a host-buffer call (tbz_inflate / _batch / _size), host wall-clock ms; 0 after a
+   * device-buffer call.  h2d_ms ends when the last input chunk has been handed to the DMA engine. */
+  float h2d_ms;
+  float host_decode_ms;
+  float d2h_ms;
+  uint32_t reserved4;
 } tbz_timings;
 
 typedef struct tbz_ctx tbz_ctx;

@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_strerror(lib):
-    assert lib.tbz_abi_version() == 3
+    assert lib.tbz_abi_version() == 4
     assert lib.tbz_strerror(0) == b"finished"
     assert lib.tbz_strerror(1) == b"input underrun"
     assert lib.tbz_strerror(2) == b"output overflow"

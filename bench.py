@@ -388,26 +388,32 @@ def main(argv=None):
             pass
 
     # the issue roof of the decode stage: a kernel of table lookups and bit arithmetic is bound by how many instructions
-    # the SIMDs can issue long before it is bound by HBM.  Like `traffic`, the figure is the last committed counter pass
-    # over the SAME config (tools/pmc_sq.sh -> tools/pmc_issue.py), stamped; null for any other config
+    # the SIMDs can issue long before it is bound by HBM.  The roof is CALIBRATED (tools/issue_roof.hip -> profiles/
+    # issue_roof.json: what a SIMD retires per ns for the decoders' own instruction mixes at 1 .. 8 waves per SIMD); a kernel's
+    # roof is that table at its own SALU : VALU ratio and occupancy (tools/pmc_issue.py), so frac <= 1 by construction.
+    # Like `traffic`, the counters are the last committed pass over the SAME config (tools/pmc_sq.sh), stamped; null otherwise
     roof["issue"] = None
     pmi = os.path.join(ROOT, "profiles", "pmc_issue.json")
     if os.path.exists(pmi) and world == 1:
         try:
             j = json.load(open(pmi))
-            if str(j.get("config", "2")) == cfg and (mib == DEFAULT_MIB[cfg]):
-                ks = {k: v for k, v in j["kernels"].items() if k.startswith(("tbz_k1g", "tbz_k1_huff", "tbz_k2_"))}
-                ins = sum(v["valu"] + v["salu"] + v["lds"] for v in ks.values())
-                slots = sum(v["issue_slots"] for v in ks.values())
+            if str(j.get("config", "2")) == cfg and (mib == DEFAULT_MIB[cfg]) and j.get("unit"):
+                ks = {k: v for k, v in j["kernels"].items() if k.startswith(("tbz_k1g", "tbz_k1_huff", "tbz_k2_")) and v.get("issue_roof")}
+                tot = sum(v["duration_ns"] for v in ks.values())
                 roof["issue"] = {
-                    "bound": "issue", "unit": "wave-instructions per launch",
-                    "achieved": ins, "peak": slots, "frac": ins / slots if slots else None,
-                    "valu_frac": sum(v["valu"] for v in ks.values()) / slots if slots else None,
-                    "what": "VALU + SALU + LDS wave-instructions issued by the decode-stage kernels / (1024 SIMDs x busy cycles / 4): "
-                            "one instruction per SIMD per quad-cycle; valu_frac = the vector pipe's share alone",
-                    "kernels": {k: {q: v[q] for q in ("issue_frac", "valu_frac", "waves_per_simd", "parked", "issuing")} for k, v in ks.items()},
+                    "bound": "issue", "unit": j["unit"],
+                    # stage figures: the kernels' own, weighted by their durations
+                    "achieved": sum(v["issue_achieved"] * v["duration_ns"] for v in ks.values()) / tot,
+                    "peak": sum(v["issue_roof"] * v["duration_ns"] for v in ks.values()) / tot,
+                    "what": "VALU + SALU + LDS wave-instructions per SIMD per ns of the decode-stage kernels against the MEASURED rate "
+                            "of a stream of the same SALU : VALU mix at the kernel's own waves per SIMD (tools/issue_roof.hip); "
+                            "valu_frac: the vector pipe alone against a pure vector stream",
+                    "kernels": {k: {q: v[q] for q in ("issue_achieved", "issue_roof", "issue_frac", "valu_frac", "salu_per_valu",
+                                                       "waves_per_simd", "parked", "issuing", "lds_bank_conflict_share", "lanes_active")}
+                                for k, v in ks.items()},
                     "source": {q: j.get(q) for q in ("commit", "date", "config", "how")},
                 }
+                roof["issue"]["frac"] = roof["issue"]["achieved"] / roof["issue"]["peak"]
         except Exception:
             pass
 

@@ -76,6 +76,12 @@ __device__ __forceinline__ uint32_t hwid() {
               "v_cndmask_b32 %4, %4, %4, vcc\n\tv_cndmask_b32 %5, %5, %5, vcc\n\t" S1 "v_cndmask_b32 %6, %6, %6, vcc\n\tv_cndmask_b32 %7, %7, %7, vcc\n\t" S2
 #define VS60 VS8_1 VS8_2 VS8_3 VS8_1 VS8_2
 
+// the same 40 VALU with an SALU after EVERY one (40 SALU): K2's mix
+#define VT(i) "v_alignbit_b32 %" #i ", %" #i ", %" #i ", 3\n\t" S1 "v_bfe_u32 %" #i ", %" #i ", 1, 31\n\t" S2 \
+              "v_cndmask_b32 %" #i ", %" #i ", %" #i ", vcc\n\t" S1 "v_alignbit_b32 %" #i ", %" #i ", %" #i ", 9\n\t" S2 \
+              "v_bfe_u32 %" #i ", %" #i ", 1, 31\n\t" S1
+#define VS80 VT(0) VT(1) VT(2) VT(3) VT(4) VT(5) VT(6) VT(7)
+
 #define REGS "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
 #define SCLOB "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "scc"
 
@@ -100,6 +106,8 @@ __global__ __launch_bounds__(1024) void k_issue(Rec* rec, int iters, uint32_t se
                    : REGS, "=&v"(l0)
                    : "v"(la)
                    : "vcc", SCLOB, "memory");
+    } else if (MIX == 6) {  // VS11: 80 VALU + 80 SALU
+      asm volatile(VS80 VS80 : REGS : : "vcc", SCLOB);
     } else if (MIX == 3) {  // D: one dependent chain, 80 VALU
       asm volatile(V8_A V8_A V8_A V8_A V8_A V8_A V8_A V8_A V8_A V8_A : REGS : : "vcc");
     }
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(1024) void k_ldslat(Rec* rec, int iters, uint32_t s
 struct Row {
   std::string mix;
   int waves;
-  double cyc_per_wave, inst_per_wave, rate, valu_rate, ticks_per_ns;
+  double cyc_per_wave, inst_per_wave, rate, valu_rate, ticks_per_ns, rate_ns, valu_rate_ns;
   int simds_used, max_per_simd;
 };
 
@@ -168,7 +176,7 @@ int main(int argc, char** argv) {
   printf("device: %s, %d CUs (%d SIMDs), clockRate %d kHz\n", p.gcnArchName, cus, simds, p.clockRate);
   printf("placement: ONE workgroup of 256*w threads per CU (150 KB of dynamic LDS: a second one does not fit), its 4*w waves\n"
          "           round-robin over the CU's 4 SIMDs -> exactly w waves per SIMD; W = 6, 8: TWO workgroups of 768 / 1024 threads (75 KB each)\n");
-  const int iters = 2000;
+  const int iters = 4000;
   std::vector<Row> rows;
   Rec* d_rec;
   const int maxw = simds * 8;
@@ -184,6 +192,7 @@ int main(int argc, char** argv) {
     double inst, valu;  // per iteration per wave
   } mixes[] = {{"V   (80 independent VALU)", 0, 80, 80},
                {"VS  (80 VALU + 40 SALU)", 1, 120, 80},
+               {"VS11 (80 VALU + 80 SALU)", 6, 160, 80},
                {"VSL (80 VALU + 40 SALU + 2 ds_read_u16)", 2, 122, 80},
                {"D   (80 VALU, one dependent chain)", 3, 80, 80},
                {"L0  (16 x {v_lshlrev, ds_read_u16, wait}, dependent, broadcast)", 4, 32, 16},
@@ -200,6 +209,7 @@ int main(int argc, char** argv) {
           case 1: launch(k_issue<1>, grid, sh.threads, lds, d_rec, iters); break;
           case 2: launch(k_issue<2>, grid, sh.threads, lds, d_rec, iters); break;
           case 3: launch(k_issue<3>, grid, sh.threads, lds, d_rec, iters); break;
+          case 6: launch(k_issue<6>, grid, sh.threads, lds, d_rec, iters); break;
           case 4: launch(k_ldslat<false>, grid, sh.threads, lds, d_rec, iters); break;
           default: launch(k_ldslat<true>, grid, sh.threads, lds, d_rec, iters); break;
         }
@@ -232,11 +242,15 @@ int main(int argc, char** argv) {
       r.rate = sh.W * r.inst_per_wave / r.cyc_per_wave;
       r.valu_rate = sh.W * m.valu * iters / r.cyc_per_wave;
       r.ticks_per_ns = r.cyc_per_wave / (ms * 1e6);  // (the kernel is its waves' lifetime: all start together)
+      // the same rates on the WALL clock (HIP events around the launch): the shader clock gives way under load — 2.4 GHz
+      // with one wave per SIMD, 1.1 - 1.5 GHz with every SIMD full of vector work — and a kernel's duration is wall time
+      r.rate_ns = sh.W * r.inst_per_wave / (ms * 1e6);
+      r.valu_rate_ns = sh.W * m.valu * iters / (ms * 1e6);
       r.simds_used = used;
       r.max_per_simd = mx;
       rows.push_back(r);
-      printf("%-66s W=%d  ticks/wave %9.0f  ticks/inst/wave %6.2f  wave-inst/SIMD/tick %6.3f  (first type alone %6.3f)  kernel %.3f ms -> %.2f ticks/ns  HW_ID keys %d, most waves on one %d\n",
-             m.name, sh.W, r.cyc_per_wave, r.cyc_per_wave / r.inst_per_wave, r.rate, r.valu_rate, ms, r.ticks_per_ns, used, mx);
+      printf("%-66s W=%d  ticks/inst/wave %6.2f  wave-inst/SIMD/tick %6.3f  kernel %.3f ms -> %.2f ticks/ns  wave-inst/SIMD/ns %6.3f (first type alone %6.3f)  HW_ID keys %d, most waves on one %d\n",
+             m.name, sh.W, r.cyc_per_wave / r.inst_per_wave, r.rate, ms, r.ticks_per_ns, r.rate_ns, r.valu_rate_ns, used, mx);
     }
   }
   if (argc > 1) {
@@ -244,9 +258,9 @@ int main(int argc, char** argv) {
     if (f) {
       fprintf(f, "{\"device\": \"%s\", \"cus\": %d, \"tick\": \"s_memtime\", \"rows\": [\n", p.gcnArchName, cus);
       for (size_t i = 0; i < rows.size(); i++)
-        fprintf(f, "  {\"mix\": \"%s\", \"waves_per_simd\": %d, \"ticks_per_wave\": %.0f, \"inst_per_wave\": %.0f, \"wave_inst_per_simd_tick\": %.4f, \"first_type_per_simd_tick\": %.4f, \"ticks_per_ns\": %.3f}%s\n",
+        fprintf(f, "  {\"mix\": \"%s\", \"waves_per_simd\": %d, \"ticks_per_wave\": %.0f, \"inst_per_wave\": %.0f, \"wave_inst_per_simd_tick\": %.4f, \"first_type_per_simd_tick\": %.4f, \"ticks_per_ns\": %.3f, \"wave_inst_per_simd_ns\": %.4f, \"first_type_per_simd_ns\": %.4f}%s\n",
                 rows[i].mix.c_str(), rows[i].waves, rows[i].cyc_per_wave, rows[i].inst_per_wave, rows[i].rate, rows[i].valu_rate, rows[i].ticks_per_ns,
-                i + 1 < rows.size() ? "," : "");
+                rows[i].rate_ns, rows[i].valu_rate_ns, i + 1 < rows.size() ? "," : "");
       fprintf(f, "]}\n");
       fclose(f);
     }

@@ -8,6 +8,7 @@ the ctypes binding and the host-side mirror of the reference's API.
 from .api import (Engine, EngineError, ThreeBzError, decompress, decompress_gzip_members, decompress_vector,  # noqa: F401
                   default_engine,
                   finished, input_underrun, make_deflate_state, make_gzip_state, make_octet_pointer_context,
-                  make_octet_vector_context, valid_octet_pointer, with_octet_pointer,
+                  make_octet_stream_context, make_octet_vector_context, resync_file_stream, valid_octet_pointer,
+                  valid_octet_stream, with_octet_pointer,
                   make_zlib_state, output_overflow, replace_output_buffer, set_default_engine)
 from ._lib import FORMATS, Result, Timings  # noqa: F401

@@ -52,7 +52,8 @@ SYMBOLS = [
     "tbz_device_free", "tbz_memcpy_h2d", "tbz_memcpy_d2h", "tbz_last_timings",
     "tbz_session_create", "tbz_session_destroy", "tbz_session_feed", "tbz_session_decompress", "tbz_session_stats",
     "tbz_gzip_header_parse", "tbz_inflate_gzip_members", "tbz_inflate_gzip_members_device",
-    "tbz_inflate_to_device", "tbz_assign_streams", "tbz_inflate_batch_multi",
+    "tbz_inflate_to_device", "tbz_assign_streams", "tbz_inflate_batch_multi", "tbz_inflate_batch_multi_device",
+    "tbz_inflate_sharded_plan", "tbz_inflate_sharded_verdict",
 ]
 
 
@@ -110,6 +111,12 @@ def load(path=None):
     L.tbz_assign_streams.argtypes = [C.POINTER(sz), sz, sz, C.POINTER(C.c_uint32)]
     L.tbz_inflate_batch_multi.argtypes = [C.POINTER(vp), sz, C.c_int, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz),
                                           C.POINTER(Result)]
+    u64pp, vpp = C.POINTER(u64p), C.POINTER(vp)
+    L.tbz_inflate_batch_multi_device.argtypes = [C.POINTER(vp), sz, C.c_int, C.POINTER(sz), vpp, u64pp, u64pp, vpp, u64pp, u64pp,
+                                                 C.POINTER(C.POINTER(Result))]
+    L.tbz_inflate_sharded_plan.argtypes = [vp, sz, sz, u64p]
+    L.tbz_inflate_sharded_verdict.argtypes = [C.c_int, vp, sz, sz, u64p, C.POINTER(Result), C.POINTER(C.c_uint32), u64p, u64p,
+                                              C.POINTER(C.c_uint32), u64p, C.POINTER(C.c_int)]
     for s in SYMBOLS:
         getattr(L, s)  # AttributeError if the ABI is incomplete
     return L

@@ -142,6 +142,24 @@ class Engine:
         engines[0]._check(lib.tbz_inflate_batch_multi(ctxs, k, fmt, n, ins, il, os_, ol, res))
         return list(res)
 
+    @staticmethod
+    def inflate_batch_multi_device(engines, parts, fmt):
+        """streams already resident on the devices: parts[k] = (d_in, in_offs, in_lens, d_out, out_offs, out_caps) for
+        engines[k] — per context the arguments of inflate_batch_device — all contexts at once (tbz_inflate_batch_multi_device).
+        Returns one list of results per context."""
+        k = len(engines)
+        lib = engines[0].lib
+        u64p, vp = C.POINTER(C.c_uint64), C.c_void_p
+        ctxs = (vp * k)(*[e._ctx for e in engines])
+        ns = (C.c_size_t * k)(*[len(q[1]) for q in parts])
+        arrs = [[(C.c_uint64 * max(1, len(q[j])))(*q[j]) for j in (1, 2, 4, 5)] for q in parts]
+        col = lambda j: (u64p * k)(*[C.cast(a[j], u64p) for a in arrs])
+        res = [(_lib.Result * max(1, len(q[1])))() for q in parts]
+        rp = (C.POINTER(_lib.Result) * k)(*[C.cast(r, C.POINTER(_lib.Result)) for r in res])
+        engines[0]._check(lib.tbz_inflate_batch_multi_device(ctxs, k, fmt, ns, (vp * k)(*[q[0] for q in parts]), col(0), col(1),
+                                                             (vp * k)(*[q[3] for q in parts]), col(2), col(3), rp))
+        return [list(r)[:len(q[1])] for r, q in zip(res, parts)]
+
     def assign_streams(self, sizes, parts):
         """tbz_assign_streams: owner[i] of stream i among `parts` contexts / ranks"""
         n = len(sizes)
@@ -342,6 +360,44 @@ def make_octet_pointer_context(octet_pointer, start=0, offset=0, end=None):
     return OctetPointerContext(octet_pointer, start, offset, end)
 
 
+class OctetStreamContext:
+    """make-octet-stream-context (io-common.lisp:47-63): a binary input file stream + context-boxes.  The reference
+    reads such a context octet by octet ("very slow", README.md); here what the boxes span, from offset to end, is read
+    in one go and handed to the state's session (the Lisp shim does the same with one READ-SEQUENCE)."""
+
+    def __init__(self, octet_stream, start=0, offset=0, end=None):
+        if not valid_octet_stream(octet_stream):   # (assert (valid-octet-stream file-stream)) io-common.lisp:55
+            raise ThreeBzError(-22, "not an open binary input stream")
+        self.octet_stream = octet_stream
+        self.start = start
+        self.offset = offset
+        if end is None:   # (file-length file-stream)
+            here = octet_stream.tell()
+            end = octet_stream.seek(0, 2)
+            octet_stream.seek(here)
+        self.end = end
+
+
+def valid_octet_stream(os_):
+    """io-common.lisp:65-69: an open input stream of octets"""
+    try:
+        return (not os_.closed) and os_.readable() and os_.seekable() and isinstance(os_.read(0), (bytes, bytearray))
+    except Exception:
+        return False
+
+
+def make_octet_stream_context(file_stream, start=0, offset=0, end=None):
+    return OctetStreamContext(file_stream, start, offset, end)
+
+
+def resync_file_stream(context):
+    """%resync-file-stream (io-common.lisp:57-63): put the stream's file position where the context stands — after a
+    finished stream that is just behind its trailer, so that the caller can go on reading what follows.  A no-op for
+    contexts that are not streams, as the reference's default method is."""
+    if isinstance(context, OctetStreamContext):
+        context.octet_stream.seek(context.offset)
+
+
 def _context_octets(eng, context):
     """the octets [offset, end) of a context as bytes (a copy: the states keep their input for resuming)"""
     if isinstance(context, OctetPointerContext):
@@ -539,6 +595,18 @@ def decompress(context, state, engine=None):
                 else:
                     hb = C.string_at(context.pointer + context.offset, head)
                 _note_gzip_header(eng, state, bytes(hb))
+    elif isinstance(context, OctetStreamContext):
+        if not valid_octet_stream(context.octet_stream):   # (assert (valid-octet-stream …)) io.lisp:71
+            raise ThreeBzError(-22, "not an open binary input stream")
+        data = b""
+        if n_in > 0:
+            context.octet_stream.seek(context.offset)
+            data = context.octet_stream.read(n_in)
+            n_in = len(data)   # (a file shorter than the boxes say: what is there)
+        if n_in > 0:
+            eng.session_feed(state._sess, _addr(data), n_in)
+            if isinstance(state, GzipState):
+                _note_gzip_header(eng, state, data)
     elif n_in > 0:
         mv = memoryview(context.octet_vector)[context.offset:context.end]
         data = bytes(mv)   # (pinned for the duration of the call, as cffi:with-pointer-to-vector-data does)
@@ -547,7 +615,7 @@ def decompress(context, state, engine=None):
             _note_gzip_header(eng, state, data)
     if n_in > 0:
         state._fed += n_in
-        context.offset = context.end
+        context.offset = context.offset + n_in if isinstance(context, OctetStreamContext) else context.end
     out = state.output_buffer
     off = state.output_offset
     res = eng.session_decompress(state._sess, _out_addr(out, off), max(0, len(out) - off))
@@ -561,6 +629,7 @@ def decompress(context, state, engine=None):
     if state.finished:
         # the context stands just behind the stream (its trailer included), as the reference leaves it
         context.offset = start_offset + max(0, int(res.in_consumed) - fed_before)
+        resync_file_stream(context)   # (io.lisp:102-104: the stream's position follows the boxes)
     # the reference's early return: gzip's final block decoded but crc32 / ISIZE cut off -> (return-from decompress-gzip 0)
     if state.input_underrun and state.format == FORMATS["gzip"] and (res.flags & 2):
         return 0

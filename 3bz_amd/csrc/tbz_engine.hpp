@@ -171,6 +171,10 @@ struct tbz_ctx {
   void* h_stage[4] = {};     // [0], [1]: towards the device; [2], [3]: from it
   hipEvent_t ev_stage[4] = {};
   tbz::CopyPool* copy_pool = nullptr;
+  tbz::CopyPool* copy_pool2 = nullptr;  // the pipelined path drains the output while the input is still arriving
+  hipStream_t stream_in = nullptr, stream_out = nullptr;  // ... on streams of their own
+  size_t pipe_min = 64u << 20;  // host inputs from this size on are decoded part by part (env TBZ_PIPE_MIN_KIB; 0: never)
+  size_t pipe_part = 32u << 20; // ... of about this many input octets (env TBZ_PIPE_PART_KIB)
   int copy_threads = 8;      // env TBZ_COPY_THREADS (1: the calling thread alone)
   size_t stage_chunk = 16u << 20;  // env TBZ_STAGE_CHUNK_KIB
   int k1_mode = 0;  // 0 auto, 1 lane-per-item, 4..64 gang of that many lanes (env TBZ_K1_MODE; tests force each)
@@ -282,15 +286,24 @@ static int stage_setup(tbz_ctx* ctx) {
     TBZ_HIP(hipHostMalloc(&ctx->h_stage[k], ctx->stage_chunk));
     TBZ_HIP(hipEventCreate(&ctx->ev_stage[k]));
   }
+  TBZ_HIP(hipStreamCreate(&ctx->stream_in));
+  TBZ_HIP(hipStreamCreate(&ctx->stream_out));
   if (ctx->copy_threads > 1) {
     ctx->copy_pool = new CopyPool();
     ctx->copy_pool->start(ctx->copy_threads - 1);
+    ctx->copy_pool2 = new CopyPool();
+    ctx->copy_pool2->start(ctx->copy_threads - 1);
   }
   return 0;
 }
-static void stage_memcpy(tbz_ctx* ctx, void* d, const void* s, size_t n) {
-  if (ctx->copy_pool) ctx->copy_pool->copy(d, s, n); else memcpy(d, s, n);
-}
+// which stream, which pair of pinned buffers and which copy pool a staged transfer uses: the context's own stream for
+// the plain calls (the transfer is ordered with the decode by the stream); streams of their own in the pipelined path,
+// where the input of part k+1, the decode of part k and the output of part k-1 move at the same time
+struct StageLane {
+  hipStream_t stream;
+  int b0;  // h_stage[b0], h_stage[b0 + 1]
+  CopyPool* pool;
+};
 constexpr size_t STAGE_MIN = 1u << 20;  // smaller transfers are left to the runtime (one bounce, no pipeline to fill)
 // one piece of a staged transfer: `len` octets between host memory and device offset `dev_off` of the transfer's device
 // buffer.  Pieces are in ascending device order and do not overlap (the streams of a batch, 16-octet aligned).
@@ -315,48 +328,51 @@ static void stage_segments(const std::vector<StagePiece>& ps, size_t& cursor, ui
     }
   }
 }
-static void stage_run(tbz_ctx* ctx, const std::vector<CopySeg>& sg) {
+static void stage_run(CopyPool* pool, const std::vector<CopySeg>& sg) {
   if (sg.empty()) return;
-  if (ctx->copy_pool && sg.size() > 1) {
-    ctx->copy_pool->run(sg.data(), sg.size());
+  if (pool && sg.size() > 1) {
+    pool->run(sg.data(), sg.size());
   } else {
     for (const CopySeg& c : sg) memcpy(c.dst, c.src, c.len);
   }
 }
 // host -> device: the pieces go to d_base + dev_off, enqueued on the context's stream (what follows on the stream sees
 // the octets; the caller's buffers are free when this returns).  The gaps between pieces are transferred as they are.
-static int stage_in(tbz_ctx* ctx, void* d_base, const std::vector<StagePiece>& ps) {
+static int stage_in(tbz_ctx* ctx, void* d_base, const std::vector<StagePiece>& ps, const StageLane* lane = nullptr) {
   if (ps.empty()) return 0;
   const uint64_t lo0 = ps.front().dev_off, hi0 = ps.back().dev_off + ps.back().len;
-  if (hi0 - lo0 < STAGE_MIN) {
+  if (hi0 - lo0 < STAGE_MIN && !lane) {
     for (const StagePiece& q : ps)
       if (q.len) TBZ_HIP(hipMemcpyAsync((uint8_t*)d_base + q.dev_off, q.host, q.len, hipMemcpyHostToDevice, ctx->stream));
     return 0;
   }
   int r = stage_setup(ctx);
   if (r) return r;
+  const StageLane own{ctx->stream, 0, ctx->copy_pool};
+  const StageLane& L = lane ? *lane : own;
   const uint64_t ch = ctx->stage_chunk;
   std::vector<CopySeg> sg;
   size_t cursor = 0, k = 0;
   for (uint64_t off = lo0; off < hi0; off += ch, k++) {
     const uint64_t len = std::min(ch, hi0 - off);
-    const int b = (int)(k & 1);
+    const int b = L.b0 + (int)(k & 1);
     if (k >= 2) TBZ_HIP(hipEventSynchronize(ctx->ev_stage[b]));  // the buffer's previous chunk has left
     stage_segments(ps, cursor, off, off + len, (uint8_t*)ctx->h_stage[b], true, sg);
-    stage_run(ctx, sg);
-    TBZ_HIP(hipMemcpyAsync((uint8_t*)d_base + off, ctx->h_stage[b], len, hipMemcpyHostToDevice, ctx->stream));
-    TBZ_HIP(hipEventRecord(ctx->ev_stage[b], ctx->stream));
+    stage_run(L.pool, sg);
+    TBZ_HIP(hipMemcpyAsync((uint8_t*)d_base + off, ctx->h_stage[b], len, hipMemcpyHostToDevice, L.stream));
+    TBZ_HIP(hipEventRecord(ctx->ev_stage[b], L.stream));
   }
-  // the staging buffers are reused by the next call: nothing may still be reading them then
+  // the staging buffers are reused by the next transfer: nothing may still be reading them then (and with a lane of
+  // its own: the octets are on the device when this returns)
   for (int b = 0; b < 2; b++)
-    if (k > (size_t)b) TBZ_HIP(hipEventSynchronize(ctx->ev_stage[b]));
+    if (k > (size_t)b) TBZ_HIP(hipEventSynchronize(ctx->ev_stage[L.b0 + b]));
   return 0;
 }
 // device -> host after everything enqueued on the context's stream; complete when this returns
-static int stage_out(tbz_ctx* ctx, const void* d_base, const std::vector<StagePiece>& ps) {
+static int stage_out(tbz_ctx* ctx, const void* d_base, const std::vector<StagePiece>& ps, const StageLane* lane = nullptr) {
   if (ps.empty()) return 0;
   const uint64_t lo0 = ps.front().dev_off, hi0 = ps.back().dev_off + ps.back().len;
-  if (hi0 - lo0 < STAGE_MIN) {
+  if (hi0 - lo0 < STAGE_MIN && !lane) {
     for (const StagePiece& q : ps)
       if (q.len) TBZ_HIP(hipMemcpyAsync(q.host, (const uint8_t*)d_base + q.dev_off, q.len, hipMemcpyDeviceToHost, ctx->stream));
     TBZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -364,23 +380,25 @@ static int stage_out(tbz_ctx* ctx, const void* d_base, const std::vector<StagePi
   }
   int r = stage_setup(ctx);
   if (r) return r;
+  const StageLane own{ctx->stream, 2, ctx->copy_pool};
+  const StageLane& L = lane ? *lane : own;
   const uint64_t ch = ctx->stage_chunk;
   const size_t nch = (size_t)((hi0 - lo0 + ch - 1) / ch);
   std::vector<CopySeg> sg;
   size_t cursor = 0;
   for (size_t k = 0; k <= nch; k++) {
     if (k < nch) {  // chunk k on its way (its buffer was drained two chunks ago)
-      const int b = 2 + (int)(k & 1);
+      const int b = L.b0 + (int)(k & 1);
       const uint64_t off = lo0 + k * ch;
-      TBZ_HIP(hipMemcpyAsync(ctx->h_stage[b], (const uint8_t*)d_base + off, std::min(ch, hi0 - off), hipMemcpyDeviceToHost, ctx->stream));
-      TBZ_HIP(hipEventRecord(ctx->ev_stage[b], ctx->stream));
+      TBZ_HIP(hipMemcpyAsync(ctx->h_stage[b], (const uint8_t*)d_base + off, std::min(ch, hi0 - off), hipMemcpyDeviceToHost, L.stream));
+      TBZ_HIP(hipEventRecord(ctx->ev_stage[b], L.stream));
     }
     if (k >= 1) {  // chunk k - 1 has arrived: to the callers' buffers while chunk k moves
-      const int b = 2 + (int)((k - 1) & 1);
+      const int b = L.b0 + (int)((k - 1) & 1);
       const uint64_t off = lo0 + (k - 1) * ch;
       TBZ_HIP(hipEventSynchronize(ctx->ev_stage[b]));
       stage_segments(ps, cursor, off, std::min(off + ch, hi0), (uint8_t*)ctx->h_stage[b], false, sg);
-      stage_run(ctx, sg);
+      stage_run(L.pool, sg);
     }
   }
   return 0;
@@ -2146,6 +2164,8 @@ int tbz_ctx_create(int device_id, tbz_ctx** out_ctx) {
   }
   if (const char* m = getenv("TBZ_COPY_THREADS")) ctx->copy_threads = std::max(1, std::min(64, atoi(m)));
   if (const char* m = getenv("TBZ_STAGE_CHUNK_KIB")) ctx->stage_chunk = (size_t)std::max(64, atoi(m)) << 10;
+  if (const char* m = getenv("TBZ_PIPE_MIN_KIB")) ctx->pipe_min = (size_t)std::max(0, atoi(m)) << 10;
+  if (const char* m = getenv("TBZ_PIPE_PART_KIB")) ctx->pipe_part = (size_t)std::max(16, atoi(m)) << 10;
   ctx->copy_threads = std::min<int>(ctx->copy_threads, std::max(1u, std::thread::hardware_concurrency()));
   if (const char* m = getenv("TBZ_HOST_LAYOUT")) ctx->host_layout = m[0] == '1';
   if (const char* m = getenv("TBZ_K2_MODE")) ctx->k2_single = !strcmp(m, "single");
@@ -2174,6 +2194,9 @@ void tbz_ctx_destroy(tbz_ctx* ctx) {
     if (b.p) hipFree(b.p);
   if (ctx->h_pin) hipHostFree(ctx->h_pin);
   delete ctx->copy_pool;
+  delete ctx->copy_pool2;
+  if (ctx->stream_in) hipStreamDestroy(ctx->stream_in);
+  if (ctx->stream_out) hipStreamDestroy(ctx->stream_out);
   for (int k = 0; k < 4; k++) {
     if (ctx->h_stage[k]) hipHostFree(ctx->h_stage[k]);
     if (ctx->ev_stage[k]) hipEventDestroy(ctx->ev_stage[k]);
@@ -2896,6 +2919,182 @@ int tbz_inflate_device(tbz_ctx* ctx, int format, const void* d_in, size_t in_len
   return tbz_inflate_batch_device(ctx, format, 1, d_in, &io, &il, d_out, &oo, &oc, res);
 }
 
+// ---- ONE large stream, host to host, part by part: the input of part k+1 on its way to the device, part k being decoded
+// and the output of part k-1 on its way back, all at the same time (PCIe is full duplex, and the decode is a quarter of
+// either transfer).  The parts are tbz_inflate_sharded_plan's — cut at flush markers, part 0 in the stream's format, the
+// rest as raw deflate — and tbz_inflate_sharded_verdict proves the seams from the parts' own results, exactly as for a
+// stream sharded across GPUs.  Whatever is not a clean chain (no markers, history across a cut, any error, a buffer that
+// is too small) is NOT decided here: *handled = false, the whole input is on the device by then (*uploaded), and the
+// caller decodes it by the ordinary path, whose statuses are the answer.
+static int inflate_host_pipelined(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap,
+                                  tbz_result* res, bool* handled, bool* uploaded) {
+  using namespace tbz;
+  *handled = *uploaded = false;
+  const size_t S = std::min<size_t>(64, std::max<size_t>(2, (in_len + ctx->pipe_part - 1) / ctx->pipe_part));
+  std::vector<uint64_t> cuts(S + 1);
+  int r;
+  if ((r = tbz_inflate_sharded_plan(in, in_len, S, cuts.data()))) return r;
+  size_t live = 0;
+  for (size_t k = 0; k < S; k++) live += cuts[k + 1] > cuts[k];
+  if (live < 2) return 0;  // (no flush markers: nothing to cut at)
+  if ((r = stage_setup(ctx))) return r;
+  // the two transfers are CONTINUOUS chunk pipelines over the whole input / the whole output, not one per part (a
+  // pipeline per part pays its fill and its drain eighteen times: measured 38 GB/s where the link does 57): the input
+  // thread publishes how many octets have arrived, the output thread follows how many have been decoded
+  std::atomic<uint64_t> arrived{0}, avail{0};
+  std::atomic<bool> all_decoded{false};
+  std::atomic<int> in_err{0}, out_err{0};
+  std::atomic<bool> abort_out{false};
+  std::vector<uint64_t> off(S + 1, 0);  // where part k's output starts
+  std::vector<tbz_result> recs(S);
+  std::vector<uint32_t> cks(S, 0);
+  for (auto& q : recs) memset(&q, 0, sizeof q);
+  const uint64_t ch = ctx->stage_chunk;
+  auto hip_ok = [](hipError_t e) { return e == hipSuccess ? 0 : (int)TBZ_E_HIP; };
+  std::thread t_in([&]() {
+    hipSetDevice(ctx->device);
+    const size_t nch = (size_t)((in_len + ch - 1) / ch);
+    int e = 0;
+    for (size_t j = 0; j < nch && !e; j++) {
+      const int b = (int)(j & 1);
+      const uint64_t o = j * ch, n = std::min<uint64_t>(ch, in_len - o);
+      if (j >= 2) e = hip_ok(hipEventSynchronize(ctx->ev_stage[b]));
+      if (!e) {
+        if (ctx->copy_pool) ctx->copy_pool->copy(ctx->h_stage[b], in + o, n); else memcpy(ctx->h_stage[b], in + o, n);
+        e = hip_ok(hipMemcpyAsync((uint8_t*)ctx->d_in_stage.p + o, ctx->h_stage[b], n, hipMemcpyHostToDevice, ctx->stream_in));
+      }
+      if (!e) e = hip_ok(hipEventRecord(ctx->ev_stage[b], ctx->stream_in));
+      // the chunk before this one moved while this one was being filled: it has (all but) arrived
+      if (!e && j >= 1) {
+        e = hip_ok(hipEventSynchronize(ctx->ev_stage[b ^ 1]));
+        if (!e) arrived.store(j * ch, std::memory_order_release);
+      }
+    }
+    if (!e && nch) e = hip_ok(hipEventSynchronize(ctx->ev_stage[(nch - 1) & 1]));
+    if (e) in_err.store(e);
+    arrived.store(in_len, std::memory_order_release);
+  });
+  std::thread t_out([&]() {
+    hipSetDevice(ctx->device);
+    int e = 0;
+    uint64_t issued = 0;        // octets whose transfer has been issued
+    uint64_t pend_o[2] = {0, 0}, pend_n[2] = {0, 0};
+    size_t j = 0;
+    auto drain = [&](int b) {   // the chunk in pinned buffer b: to the caller's buffer
+      if (!pend_n[b] || e) return;
+      e = hip_ok(hipEventSynchronize(ctx->ev_stage[2 + b]));
+      if (!e) {
+        if (ctx->copy_pool2) ctx->copy_pool2->copy(out + pend_o[b], ctx->h_stage[2 + b], pend_n[b]);
+        else memcpy(out + pend_o[b], ctx->h_stage[2 + b], pend_n[b]);
+      }
+      pend_n[b] = 0;
+    };
+    for (;;) {
+      // the next chunk: a whole one as soon as that much has been decoded, the rest when everything has
+      uint64_t n = 0;
+      for (;;) {
+        if (abort_out.load()) return;
+        const uint64_t av = avail.load(std::memory_order_acquire);
+        const bool fin = all_decoded.load(std::memory_order_acquire);
+        if (av - issued >= ch) { n = ch; break; }
+        if (fin) { n = avail.load(std::memory_order_acquire) - issued; break; }
+        std::this_thread::yield();
+      }
+      const int b = (int)(j & 1);
+      drain(b);  // (its buffer is about to be reused)
+      if (n && !e) {
+        e = hip_ok(hipMemcpyAsync(ctx->h_stage[2 + b], (const uint8_t*)ctx->d_out_stage.p + issued, n, hipMemcpyDeviceToHost, ctx->stream_out));
+        if (!e) e = hip_ok(hipEventRecord(ctx->ev_stage[2 + b], ctx->stream_out));
+        pend_o[b] = issued;
+        pend_n[b] = n;
+        issued += n;
+        j++;
+      }
+      drain((int)(j & 1));  // the chunk before the one just issued, while that one moves
+      if (e || (all_decoded.load(std::memory_order_acquire) && issued == avail.load(std::memory_order_acquire))) break;
+    }
+    drain(0);
+    drain(1);
+    if (e) out_err.store(e);
+  });
+  size_t last = 0;
+  for (size_t k = 0; k < S; k++)
+    if (cuts[k + 1] > cuts[k] || k == 0) last = k;
+  bool clean = true;
+  int rc = 0;
+  tbz_timings acc{};
+  for (size_t k = 0; k <= last && clean; k++) {
+    while (arrived.load(std::memory_order_acquire) < cuts[k + 1]) std::this_thread::yield();
+    if (in_err.load()) { clean = false; break; }
+    off[k + 1] = off[k];
+    const uint64_t n = cuts[k + 1] - cuts[k];
+    if (!n && k) continue;
+    const int f = k == 0 ? format : TBZ_FORMAT_DEFLATE;
+    uint64_t io = cuts[k], il = n, oo = off[k], oc = out_cap - off[k];
+    if ((rc = inflate_core(ctx, f, 1, ctx->d_in_stage.p, &io, &il, ctx->d_out_stage.p, &oo, &oc, &recs[k], false))) { clean = false; break; }
+    const tbz_timings& t = ctx->tim;
+    acc.scan_ms += t.scan_ms; acc.huff_ms += t.huff_ms; acc.lz_ms += t.lz_ms; acc.cksum_ms += t.cksum_ms; acc.total_ms += t.total_ms;
+    acc.find_ms += t.find_ms; acc.resolve_ms += t.resolve_ms; acc.huff_launches += t.huff_launches; acc.token_words += t.token_words;
+    acc.n_segments += t.n_segments; acc.n_groups += t.n_groups; acc.n_candidates += t.n_candidates; acc.n_hgroups += t.n_hgroups;
+    acc.k1_gang = t.k1_gang; acc.k2_kinds |= t.k2_kinds; acc.scratch_bytes = std::max(acc.scratch_bytes, t.scratch_bytes);
+    const bool ok = k == last ? recs[k].status == TBZ_FINISHED : (recs[k].status == TBZ_INPUT_UNDERRUN && recs[k].in_consumed == n);
+    if (!ok) { clean = false; break; }
+    if (format != TBZ_FORMAT_DEFLATE) {
+      std::vector<uint64_t> o{off[k]}, l{recs[k].out_len};
+      std::vector<uint32_t> init{format == TBZ_FORMAT_ZLIB ? 1u : 0u}, sums;
+      if ((rc = run_checksums(ctx, format == TBZ_FORMAT_ZLIB ? 1 : 2, ctx->d_out_stage.p, o, l, init, sums))) { clean = false; break; }
+      cks[k] = sums[0];
+    }
+    off[k + 1] = off[k] + recs[k].out_len;
+    for (size_t j = k + 2; j <= S; j++) off[j] = off[k + 1];
+    avail.store(off[k + 1], std::memory_order_release);  // (octets that leave before a verdict that turns out not clean are the
+                                                         // ones the ordinary path then delivers again, or a prefix of them)
+  }
+  uint64_t total = 0, consumed = 0;
+  uint32_t check = 0;
+  if (clean) {
+    int why = 0;
+    const int v = tbz_inflate_sharded_verdict(format, in, in_len, S, cuts.data(), recs.data(), cks.data(), nullptr, &total, &check,
+                                              &consumed, &why);
+    if (v != 0) clean = false;
+    if (ctx->tun.debug) fprintf(stderr, "tbz: pipelined host decode: %zu parts, verdict %d (why %d)\n", last + 1, v, why);
+  } else if (ctx->tun.debug) {
+    for (size_t k = 0; k <= last; k++)
+      fprintf(stderr, "tbz: pipelined host decode: part %zu status %d consumed %llu of %llu out %llu\n", k, recs[k].status,
+              (unsigned long long)recs[k].in_consumed, (unsigned long long)(cuts[k + 1] - cuts[k]), (unsigned long long)recs[k].out_len);
+  }
+  if (clean) {
+    avail.store(off[last + 1], std::memory_order_release);
+    all_decoded.store(true, std::memory_order_release);
+  } else {
+    abort_out.store(true);
+  }
+  t_in.join();   // (the fallback decodes from the device: the whole input has to be there)
+  t_out.join();
+  *uploaded = in_err.load() == 0;
+  if (rc) return rc;
+  if (in_err.load()) return in_err.load();
+  if (!clean) return 0;
+  if (out_err.load()) return out_err.load();
+  memset(res, 0, sizeof *res);
+  res->status = TBZ_FINISHED;
+  res->out_len = res->out_total = res->boundary_out = total;
+  res->in_consumed = consumed;
+  res->flags = 2u | (format != TBZ_FORMAT_DEFLATE ? 1u : 0u);
+  for (size_t k = 0; k <= last; k++) res->segments += recs[k].segments;
+  if (format == TBZ_FORMAT_ZLIB) {
+    res->adler32 = res->trailer_check = check;
+  } else if (format == TBZ_FORMAT_GZIP) {
+    res->crc32 = res->trailer_check = check;
+    const uint8_t* t = in + (consumed - 4);
+    res->trailer_isize = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+  }
+  acc.passes = (uint32_t)(last + 1);
+  ctx->tim = acc;
+  *handled = true;
+  return 0;
+}
+
 static int stage_batch(tbz_ctx* ctx, int format, size_t n, const uint8_t* const* ins, const size_t* in_lens,
                        uint8_t* const* outs, const size_t* out_caps, tbz_result* results, bool size_only) {
   using namespace tbz;
@@ -2916,7 +3115,18 @@ static int stage_batch(tbz_ctx* ctx, int format, size_t n, const uint8_t* const*
   if ((r = ensure(ctx, ctx->d_in_stage, it + 64))) return r;
   if (!size_only && (r = ensure(ctx, ctx->d_out_stage, ot + 64))) return r;
   const double t_in = now_ms();
-  {
+  bool uploaded = false;
+  if (n == 1 && !size_only && ctx->pipe_min && in_lens[0] >= ctx->pipe_min && ins[0] && (outs[0] || !out_caps[0])) {
+    bool handled = false;
+    if ((r = inflate_host_pipelined(ctx, format, ins[0], in_lens[0], outs[0], out_caps[0], &results[0], &handled, &uploaded))) return r;
+    if (handled) {
+      ctx->tim.h2d_copies = 1;
+      ctx->tim.h2d_ms = ctx->tim.d2h_ms = 0.f;  // (the legs overlap: only their sum means anything)
+      ctx->tim.host_decode_ms = (float)(now_ms() - t_in);
+      return 0;
+    }
+  }
+  if (!uploaded) {
     std::vector<StagePiece> ps;
     for (size_t i = 0; i < n; i++)
       if (in_lens[i]) {
@@ -3106,8 +3316,11 @@ int tbz_assign_streams(const size_t* in_lens, size_t n, size_t n_parts, uint32_t
 int tbz_inflate_batch_multi(tbz_ctx* const* ctxs, size_t n_ctx, int format, size_t n, const uint8_t* const* ins,
                             const size_t* in_lens, uint8_t* const* outs, const size_t* out_caps, tbz_result* results) {
   if (!ctxs || !n_ctx || !results || (n && (!ins || !in_lens || !outs || !out_caps))) return TBZ_E_ARG;
-  for (size_t k = 0; k < n_ctx; k++)
+  for (size_t k = 0; k < n_ctx; k++) {
     if (!ctxs[k]) return TBZ_E_ARG;
+    for (size_t j = 0; j < k; j++)
+      if (ctxs[j] == ctxs[k]) return TBZ_E_ARG;  // (two host threads on one context's pools and streams)
+  }
   std::vector<uint32_t> owner(n);
   int r = tbz_assign_streams(in_lens, n, n_ctx, owner.data());
   if (r) return r;
@@ -3136,6 +3349,152 @@ int tbz_inflate_batch_multi(tbz_ctx* const* ctxs, size_t n_ctx, int format, size
   for (auto& t : th) t.join();
   for (size_t k = 0; k < n_ctx; k++)
     if (rc[k]) return rc[k];
+  return 0;
+}
+
+// the same with the streams ALREADY RESIDENT on the devices (io-mmap.lisp:26-54: foreign / device pointers): context k
+// decodes the n_streams[k] streams that live at d_ins[k] + in_offs[k][i] into d_outs[k] + out_offs[k][i] — per context
+// the arguments of tbz_inflate_batch_device, all contexts at once, a host thread each.  Nothing crosses PCIe but the
+// result records.
+int tbz_inflate_batch_multi_device(tbz_ctx* const* ctxs, size_t n_ctx, int format, const size_t* n_streams,
+                                   const void* const* d_ins, const uint64_t* const* in_offs, const uint64_t* const* in_lens,
+                                   void* const* d_outs, const uint64_t* const* out_offs, const uint64_t* const* out_caps,
+                                   tbz_result* const* results) {
+  if (!ctxs || !n_ctx || !n_streams || !d_ins || !in_offs || !in_lens || !d_outs || !out_offs || !out_caps || !results)
+    return TBZ_E_ARG;
+  for (size_t k = 0; k < n_ctx; k++) {
+    if (!ctxs[k]) return TBZ_E_ARG;
+    for (size_t j = 0; j < k; j++)
+      if (ctxs[j] == ctxs[k]) return TBZ_E_ARG;
+  }
+  std::vector<int> rc(n_ctx, 0);
+  std::vector<std::thread> th;
+  for (size_t k = 0; k < n_ctx; k++)
+    th.emplace_back([&, k]() {
+      if (!n_streams[k]) return;
+      rc[k] = tbz_inflate_batch_device(ctxs[k], format, n_streams[k], d_ins[k], in_offs[k], in_lens[k], d_outs[k], out_offs[k],
+                                       out_caps[k], results[k]);
+    });
+  for (auto& t : th) t.join();
+  for (size_t k = 0; k < n_ctx; k++)
+    if (rc[k]) return rc[k];
+  return 0;
+}
+
+// ---- ONE flush-delimited stream over several decoders (the argument is in 3bz_amd/multi.py's header:
+// a deflate stream may be entered at any block boundary, deflate.lisp:518-528, and the octet after 00 00 FF FF is one
+// if the marker is real).  The plan and the verdict are host arithmetic over octets the host already holds and over the
+// parts' result records, so that any host language can drive the parts — ranks of a torch.distributed job, the contexts
+// of one process, or one context after another (tbz_inflate's pipelined path).
+//
+// plan: cuts[0] = 0 (start), cuts[r] = end of the first flush marker at or after the r-th equal share of the octets
+// (in_len when there is none), cuts[n_parts] = in_len.  Part r is in[cuts[r], cuts[r+1]): part 0 in the stream's own
+// format, the others as raw deflate.
+int tbz_inflate_sharded_plan(const uint8_t* in, size_t in_len, size_t n_parts, uint64_t* cuts) {
+  if (!cuts || !n_parts || (in_len && !in)) return TBZ_E_ARG;
+  cuts[0] = 0;
+  for (size_t r = 1; r < n_parts; r++) {
+    const uint64_t share = (uint64_t)((unsigned __int128)in_len * r / n_parts);
+    uint64_t p = std::max<uint64_t>(cuts[r - 1], share);
+    uint64_t cut = in_len;
+    while (p + 4 <= in_len) {
+      const uint8_t* q = (const uint8_t*)memchr(in + p, 0, in_len - p - 3);
+      if (!q) break;
+      p = (uint64_t)(q - in);
+      if (in[p + 1] == 0 && in[p + 2] == 0xff && in[p + 3] == 0xff) {
+        cut = p + 4;
+        break;
+      }
+      p++;
+    }
+    cuts[r] = cut;
+  }
+  cuts[n_parts] = in_len;
+  return 0;
+}
+}  // extern "C"
+
+namespace tbz {
+static uint32_t adler32_combine(uint32_t a1, uint32_t a2, uint64_t len2) {
+  const uint32_t B = 65521;
+  const uint32_t s1a = a1 & 0xffff, s2a = a1 >> 16, s1b = a2 & 0xffff, s2b = a2 >> 16;
+  const uint32_t s1 = (s1a + s1b + B - 1) % B;
+  const uint64_t rem = len2 % B;
+  const uint32_t s2 = (uint32_t)((s2a + s2b + rem * ((s1a + B - 1) % B)) % B);
+  return s1 | (s2 << 16);
+}
+static uint32_t crc32_combine(uint32_t c1, uint32_t c2, uint64_t len2) {
+  // c1 * x^(8 len2) mod P (reflected, #xedb88320: checksums.lisp:177-193), by squaring
+  auto mul = [](uint32_t a, uint32_t b) { return h_mulmod(a, b); };
+  uint32_t pw = 0x80000000u, sq = 0x00800000u;  // x^0, x^8
+  for (uint64_t n = len2; n; n >>= 1) {
+    if (n & 1) pw = mul(sq, pw);
+    sq = mul(sq, sq);
+  }
+  return mul(pw, c1) ^ c2;
+}
+}  // namespace tbz
+
+extern "C" {
+// verdict: recs[r] = what part r's decoder reported — its tbz_result and the checksum of its output continued from the
+// format's initial value (adler32 from 1 / crc32 from 0; part 0's own checksum field serves).  All seams clean (every part
+// but the last live one ran out of input exactly at its range's end, at a block boundary; the last one finished) =>
+// returns 0 with *total, *check, *in_consumed filled and out_offs[r] = where part r's octets start in the whole; for a
+// container format the trailer that follows the last part is read from `in` and compared.  Anything else => returns 1
+// (decode the stream by the ordinary path: ITS statuses are the answer) and *why says which rule failed.
+int tbz_inflate_sharded_verdict(int format, const uint8_t* in, size_t in_len, size_t n_parts, const uint64_t* cuts,
+                                const tbz_result* recs, const uint32_t* part_check, uint64_t* out_offs, uint64_t* total,
+                                uint32_t* check, uint64_t* in_consumed, int* why) {
+  using namespace tbz;
+  if (!cuts || !recs || !n_parts || format < 0 || format > 2 || (in_len && !in)) return TBZ_E_ARG;
+  auto fail = [&](int w) {
+    if (why) *why = w;
+    return 1;
+  };
+  size_t last = 0;
+  for (size_t r = 0; r < n_parts; r++)
+    if (cuts[r + 1] > cuts[r] || r == 0) last = r;
+  for (size_t r = 0; r <= last; r++) {
+    const bool live = cuts[r + 1] > cuts[r] || r == 0;
+    if (!live) continue;
+    if (r != last && !(recs[r].status == TBZ_INPUT_UNDERRUN && recs[r].in_consumed == cuts[r + 1] - cuts[r])) return fail(1 + (int)r);
+    if (r == last && recs[r].status != TBZ_FINISHED) return fail(-1);
+  }
+  uint64_t tot = 0;
+  for (size_t r = 0; r < n_parts; r++) {
+    if (out_offs) out_offs[r] = tot;
+    const bool live = r <= last && (cuts[r + 1] > cuts[r] || r == 0);
+    tot += live ? recs[r].out_len : 0;
+  }
+  uint64_t consumed = cuts[last] - cuts[0] + recs[last].in_consumed;
+  uint32_t ck = 0;
+  if (format != TBZ_FORMAT_DEFLATE && last != 0) {
+    if (!part_check) return TBZ_E_ARG;
+    bool first = true;
+    for (size_t r = 0; r <= last; r++) {
+      if (!(cuts[r + 1] > cuts[r] || r == 0)) continue;
+      if (first) {
+        ck = part_check[r];
+        first = false;
+      } else {
+        ck = format == TBZ_FORMAT_ZLIB ? adler32_combine(ck, part_check[r], recs[r].out_len) : crc32_combine(ck, part_check[r], recs[r].out_len);
+      }
+    }
+    const uint64_t at = cuts[last] + recs[last].in_consumed;  // the raw-deflate part ends at its final block: the trailer follows
+    const uint64_t need = format == TBZ_FORMAT_ZLIB ? 4 : 8;
+    if (at + need > cuts[n_parts]) return fail(-2);
+    const uint8_t* t = in + at;
+    const uint32_t stored = format == TBZ_FORMAT_ZLIB ? ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3]
+                                                      : (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+    if (stored != ck) return fail(-3);
+    consumed += need;
+  } else if (format != TBZ_FORMAT_DEFLATE) {
+    ck = part_check ? part_check[0] : (format == TBZ_FORMAT_ZLIB ? recs[0].adler32 : recs[0].crc32);
+  }
+  if (total) *total = tot;
+  if (check) *check = ck;
+  if (in_consumed) *in_consumed = consumed;
+  if (why) *why = 0;
   return 0;
 }
 

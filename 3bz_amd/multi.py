@@ -126,17 +126,18 @@ def crc32_combine(c1, c2, len2):
     return c1 ^ c2
 
 
-def shard_plan(data, world, start=0, end=None):
+def shard_plan(data, world, start=0, end=None, lib=None):
     """world+1 cut points in `data[start:end]`: cut_r = end of the first flush marker at or after the r-th
-    equal share of the compressed octets (a range may be empty when markers are scarce)"""
+    equal share of the compressed octets (a range may be empty when markers are scarce).  tbz_inflate_sharded_plan
+    (include/tbz_amd.h): the same arithmetic a Lisp host calls through the shim."""
     end = len(data) if end is None else end
-    cuts = [start]
-    for r in range(1, world):
-        target = max(cuts[-1], start + (end - start) * r // world)
-        p = data.find(MARK, target, end)
-        cuts.append(end if p < 0 else p + 4)
-    cuts.append(end)
-    return cuts
+    L = lib or _lib.load()
+    view = bytes(memoryview(data)[start:end])
+    cuts = (C.c_uint64 * (world + 1))()
+    rc = L.tbz_inflate_sharded_plan(C.cast(C.c_char_p(view), C.c_void_p), len(view), world, cuts)
+    if rc:
+        raise ValueError("tbz_inflate_sharded_plan: %d" % rc)
+    return [start + int(c) for c in cuts]
 
 
 def shard_decode(eng, data, fmt, cuts, r):
@@ -160,53 +161,51 @@ def shard_decode(eng, data, fmt, cuts, r):
     return rec, d_out, got
 
 
-def shard_verdict(recs, data, fmt, cuts):
+_WHY = {-1: "last part did not finish", -2: "trailer incomplete", -3: "checksum mismatch"}
+
+
+def shard_verdict(recs, data, fmt, cuts, lib=None):
     """the same decision on every rank from the gathered records: {"ok": bool, ...}.  ok => "offsets"
-    (where each rank's part starts in the output), "total", "check", "in_consumed"."""
+    (where each rank's part starts in the output), "total", "check", "in_consumed".  The rules live in C
+    (tbz_inflate_sharded_verdict, include/tbz_amd.h) so that every host language applies the same ones."""
     world = len(recs)
-    live = [r for r in range(world) if cuts[r + 1] > cuts[r] or r == 0]
-    last = live[-1]
-    for r in live:
-        status, got, consumed, rlen = recs[r][0], recs[r][1], recs[r][2], recs[r][3]
-        if r != last and not (status == 1 and consumed == rlen):
-            return {"ok": False, "why": "seam after rank %d not clean (status %d)" % (r, status)}
-        if r == last and status != 0:
-            return {"ok": False, "why": "last part: status %d" % status}
-    offsets, total = [], 0
+    L = lib or _lib.load()
+    base = cuts[0]
+    view = bytes(memoryview(data)[base:cuts[-1]])
+    rs = (_lib.Result * world)()
+    cks = (C.c_uint32 * world)()
     for r in range(world):
-        offsets.append(total)
-        total += recs[r][1]
-    check = None
-    consumed = cuts[last] - cuts[0] + recs[last][2]
-    if fmt != FMT_DEFLATE and last != 0:   # (last == 0: the engine itself checked the trailer)
-        comb = adler32_combine if fmt == FMT_ZLIB else crc32_combine
-        check = recs[live[0]][4]
-        for r in live[1:]:
-            check = comb(check, recs[r][4], recs[r][1])
-        at = cuts[last] + recs[last][2]    # the raw-deflate part ends at its final block: the trailer follows
-        need = 4 if fmt == FMT_ZLIB else 8
-        if at + need > cuts[-1]:
-            return {"ok": False, "why": "trailer incomplete"}
-        stored = int.from_bytes(data[at:at + 4], "big" if fmt == FMT_ZLIB else "little")
-        if stored != check:
-            return {"ok": False, "why": "checksum mismatch"}
-        consumed += need
-    elif fmt != FMT_DEFLATE:
-        check = recs[0][4]
-    return {"ok": True, "offsets": offsets, "total": total, "check": check, "in_consumed": consumed}
+        rs[r].status, rs[r].out_len, rs[r].in_consumed = recs[r][0], recs[r][1], recs[r][2]
+        if fmt == FMT_ZLIB:
+            rs[r].adler32 = recs[r][4]
+        elif fmt == FMT_GZIP:
+            rs[r].crc32 = recs[r][4]
+        cks[r] = recs[r][4] & 0xFFFFFFFF
+    cc = (C.c_uint64 * (world + 1))(*[c - base for c in cuts])
+    offs = (C.c_uint64 * world)()
+    total, consumed, check, why = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_int()
+    rc = L.tbz_inflate_sharded_verdict(fmt, C.cast(C.c_char_p(view), C.c_void_p), len(view), world, cc, rs, cks, offs,
+                                       C.byref(total), C.byref(check), C.byref(consumed), C.byref(why))
+    if rc < 0:
+        raise ValueError("tbz_inflate_sharded_verdict: %d" % rc)
+    if rc:
+        w = why.value
+        return {"ok": False, "why": _WHY.get(w, "seam after rank %d not clean (status %d)" % (w - 1, recs[w - 1][0] if w > 0 else 0))}
+    return {"ok": True, "offsets": [int(o) for o in offs], "total": int(total.value),
+            "check": None if fmt == FMT_DEFLATE else int(check.value), "in_consumed": int(consumed.value)}
 
 
 def inflate_sharded(eng, data, fmt, rank, world, dist, torch, device="cpu"):
     """decode ONE stream with all ranks.  Returns a dict: "sharded" (bool), "status", "total", "check",
     and this rank's part: "d_out" (device pointer or None), "offset", "len".  When the stream does not
     shard (see above) rank 0 holds everything and "status" is the ordinary single-GPU status."""
-    cuts = shard_plan(data, world)
+    cuts = shard_plan(data, world, lib=eng.lib)
     rec, d_out, n = shard_decode(eng, data, fmt, cuts, rank)
     mine = torch.tensor(rec, dtype=torch.int64, device=device)
     gathered = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine)
     recs = [[int(x) for x in g.cpu().tolist()] for g in gathered]
-    v = shard_verdict(recs, data, fmt, cuts)
+    v = shard_verdict(recs, data, fmt, cuts, lib=eng.lib)
     if v["ok"]:
         return {"sharded": True, "status": 0, "total": v["total"], "check": v["check"],
                 "in_consumed": v["in_consumed"], "d_out": d_out, "offset": v["offsets"][rank], "len": n}

@@ -8,6 +8,9 @@ input and output resident in HBM when the timed region starts.
     python bench.py [--config 2] [--gpus N] [--steps K] [--warmup W]
 
   --config 2   (default) :zlib, 1 GiB of enwik-style text, Z_FULL_FLUSH every 16 KiB — the config the metric is quoted on
+  --config 2s  config 2's ONE stream (seed 0x3B2 on every rank) decoded by ALL ranks together: rank r takes the octets between
+               cut r and cut r+1 (tbz_inflate_sharded_plan), one all_gather of 8 x int64 per rank, the seam proof and the
+               combined checksum (tbz_inflate_sharded_verdict) inside the timed region  ("scaling": "strong")
   --config 2b  the same text with Z_SYNC_FLUSH (history crosses every flush point)
   --config nf  the same text, no flush at all (an ordinary zlib stream: ONE segment for a marker scanner)
   --config 1   :deflate, one stored block of 65 535 octets (plumbing / call floor)
@@ -41,8 +44,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-CONFIGS = ("1", "2", "2b", "nf", "3", "3u", "4", "5", "5f")
-DEFAULT_MIB = {"1": 0, "2": 1024, "2b": 256, "nf": 64, "3": 1024, "3u": 1024, "4": 1024, "5": 256, "5f": 256}
+CONFIGS = ("1", "2", "2s", "2b", "nf", "3", "3u", "4", "5", "5f")
+DEFAULT_MIB = {"1": 0, "2": 1024, "2s": 1024, "2b": 256, "nf": 64, "3": 1024, "3u": 1024, "4": 1024, "5": 256, "5f": 256}
 
 
 def parse_args(argv=None):
@@ -116,6 +119,13 @@ def build_workload(cfg, mib, rank, world, workers):
     from tools import corpus as K
     U = int(mib * (1 << 20))
     seed = 0x3B2 + rank
+    if cfg == "2s":
+        s, p, a = K.zlib_flush_stream(U, seed=0x3B2, workers=workers)   # the SAME stream on every rank
+        w = Workload("config 2s: :zlib, ONE stream of %g MiB enwik-style text, Z_FULL_FLUSH every 16 KiB (%d segments), decoded by "
+                     "all ranks together: contiguous parts cut at flush markers, seams proven from the parts' own results, one "
+                     "all_gather of 8 x int64 per rank" % (mib, U // 16384), "zlib", [(s, p, a)], scaling="strong")
+        w.total_U = U
+        return w
     if cfg in ("2", "2b", "nf"):
         if cfg == "2":
             s, p, a = K.zlib_flush_stream(U, seed=seed, workers=workers)
@@ -271,7 +281,13 @@ def main(argv=None):
         ipos, opos = len(blob), opos + (4 << 20)
     d_in = eng.malloc(ipos + 64)
     d_out = eng.malloc(opos + 64)
-    if blob is not None:
+    shard = None
+    if cfg == "2s":   # this rank's part of the one stream, resident on its device; any part's output fits U
+        s0 = wl.streams[0][0]
+        cuts = M.shard_plan(s0, world, lib=eng.lib)
+        shard = {"cuts": cuts, "lo": cuts[rank], "hi": cuts[rank + 1], "fmt": fmt if rank == 0 else T.FORMATS["deflate"]}
+        eng.h2d(d_in, s0[shard["lo"]:shard["hi"]])
+    elif blob is not None:
         eng.h2d(d_in, blob)
     else:
         for (s, _, _), o in zip(wl.streams, in_offs):
@@ -283,7 +299,33 @@ def main(argv=None):
 
     member_offs = [None]
 
+    verdicts = [None]
+
+    def step_sharded():
+        n_in = shard["hi"] - shard["lo"]
+        if n_in == 0 and rank > 0:
+            rec, res = [1, 0, 0, 0, 0, 0, 0, 0], None
+        else:
+            res = eng.inflate_device(d_in, n_in, d_out, out_caps[0], shard["fmt"])
+            got = int(res.out_len) if res.status >= 0 else 0
+            ck = 0
+            if res.status in (0, 1):
+                s1, s2 = eng.adler32_device(d_out, got, 1, 0)
+                ck = s1 | (s2 << 16)
+            rec = [int(res.status), got, int(res.in_consumed), n_in, ck, int(res.flags), 0, 0]
+        recs = [rec]
+        if world > 1:
+            mine = torch.tensor(rec, dtype=torch.int64, device=dev)
+            out = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(out, mine)
+            recs = [[int(x) for x in g.cpu().tolist()] for g in out]
+        verdicts[0] = M.shard_verdict(recs, wl.streams[0][0], fmt, shard["cuts"], lib=eng.lib)
+        assert verdicts[0]["ok"], verdicts[0]
+        return [res] if res is not None else []
+
     def step():
+        if shard is not None:
+            return step_sharded()
         if blob is not None:
             res, _io, member_offs[0] = eng.inflate_gzip_members_device(d_in, len(blob), d_out, opos, n + 8)
             assert len(res) == n, (len(res), n)
@@ -323,7 +365,7 @@ def main(argv=None):
             t = eng.timings()
             for k in keys:
                 tim[k] += getattr(t, k + "_ms")
-    if world > 1:  # inside the timed region: the last exchange has to have arrived and to be clean
+    if world > 1 and shard is None:  # inside the timed region: the last exchange has to have arrived and to be clean
         for r_, t_ in enumerate(gathered[0]):
             for rec in M.tensor_to_results(t_):
                 assert rec.status == 0, (r_, rec.status)
@@ -337,15 +379,27 @@ def main(argv=None):
 
     # ---- correctness of what was timed: status, length, checksum against what the generator computed from the
     # plaintext (and the engine's own trailer verdict), and a byte compare of the output
+    if shard is not None and not args.no_check:
+        # one stream across the ranks: the verdict of the last step (seams, total, combined checksum against the stream's own
+        # trailer) and this rank's octets against its part of the plaintext
+        v, (s0, p0, a0) = verdicts[0], wl.streams[0]
+        assert v["ok"] and v["total"] == len(p0) and v["check"] == a0 and v["in_consumed"] == len(s0), v
+        if not args.no_verify:
+            lo = v["offsets"][rank]
+            hi = v["offsets"][rank + 1] if rank + 1 < world else v["total"]
+            got = bytearray(hi - lo)
+            if hi > lo:
+                eng.d2h(got, d_out, hi - lo)
+            assert np.array_equal(np.frombuffer(got, dtype=np.uint8), np.frombuffer(p0, dtype=np.uint8)[lo:hi]), "part differs"
     for i, ((s, p, ck), r) in enumerate(zip(wl.streams, res)):
-        if args.no_check:
+        if args.no_check or shard is not None:
             break
         assert r.status == 0 and r.out_len == len(p), (i, r.status, r.out_len, len(p))
         if wl.fmt == "zlib":
             assert r.adler32 == ck and (r.flags & 1), (i, hex(r.adler32), hex(ck))
         elif wl.fmt == "gzip":
             assert r.crc32 == ck and (r.flags & 1), (i, hex(r.crc32), hex(ck))
-    if not args.no_verify and not args.no_check and n:
+    if not args.no_verify and not args.no_check and n and shard is None:
         got = bytearray(opos)
         eng.d2h(got, d_out, opos)
         g = np.frombuffer(got, dtype=np.uint8)
@@ -422,7 +476,7 @@ def main(argv=None):
     # tbz_inflate_batch.  Never `value`.  The ceiling beside it: what hipMemcpy moves on this box between PINNED host
     # memory and the device (torch's pinned tensors), each direction alone.
     h2h = None
-    if rank == 0 and world == 1 and n and blob is None and not emu and not args.no_h2h:
+    if rank == 0 and world == 1 and n and blob is None and shard is None and not emu and not args.no_h2h:
         h_ins = [s for s, _, _ in wl.streams]
         h_outs = [bytearray(len(p)) for _, p, _ in wl.streams]
         def h2h_step():

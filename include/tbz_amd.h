@@ -194,6 +194,34 @@ int tbz_inflate_to_device(tbz_ctx* ctx, int format, const uint8_t* in, size_t in
 int tbz_assign_streams(const size_t* in_lens, size_t n, size_t n_parts, uint32_t* owner);
 int tbz_inflate_batch_multi(tbz_ctx* const* ctxs, size_t n_ctx, int format, size_t n, const uint8_t* const* ins,
                             const size_t* in_lens, uint8_t* const* outs, const size_t* out_caps, tbz_result* results);
+/* The same with the streams ALREADY RESIDENT on the devices (foreign / device pointers: io-mmap.lisp:26-54): context k
+ * decodes the n_streams[k] streams at d_ins[k] + in_offs[k][i] into d_outs[k] + out_offs[k][i] — per context the
+ * arguments of tbz_inflate_batch_device — all contexts at once, a host thread each; results[k][i] is context k's stream
+ * i.  Nothing but the result records crosses PCIe.  The contexts must be distinct (TBZ_E_ARG; also in the host variant:
+ * one context is one in-flight call). */
+int tbz_inflate_batch_multi_device(tbz_ctx* const* ctxs, size_t n_ctx, int format, const size_t* n_streams,
+                                   const void* const* d_ins, const uint64_t* const* in_offs, const uint64_t* const* in_lens,
+                                   void* const* d_outs, const uint64_t* const* out_offs, const uint64_t* const* out_caps,
+                                   tbz_result* const* results);
+
+/* ---- ONE flush-delimited stream over several decoders ---------------------------
+ * 3bz finds a block only by finishing the one before it (deflate.lisp:719-722), but a deflate stream may be ENTERED at
+ * any block boundary (deflate.lisp:518-528 reads BFINAL / BTYPE with no other state), and the octet after a flush marker
+ * 00 00 FF FF is one — if the marker is real.  tbz_inflate_sharded_plan cuts the stream at such markers near equal shares
+ * of its octets: part r = in[cuts[r], cuts[r+1]), part 0 in the stream's own format, the others as raw deflate
+ * (TBZ_FORMAT_DEFLATE).  Whoever decodes the parts — the ranks of a distributed job, the contexts of one process, one
+ * context after another — hands their result records to tbz_inflate_sharded_verdict: every part but the last must have
+ * run out of input (TBZ_INPUT_UNDERRUN) having consumed EXACTLY its range, the last must have finished; by induction
+ * from part 0's true start every cut is then a true block boundary and the parts concatenate to what a front-to-back
+ * decoder produces.  part_check[r] = checksum of part r's output continued from the format's initial value (adler32 from
+ * 1, crc32 from 0; tbz_adler32_device / tbz_crc32_device); the whole's checksum is their ordered combine and is compared
+ * with the trailer behind the last part.  Returns 0 (clean: *total, *check, *in_consumed, out_offs[r] filled), 1 (not
+ * clean: decode the stream by the ordinary path — its statuses are the answer; *why: r+1 = the seam after part r, -1 the
+ * last part did not finish, -2 trailer incomplete, -3 checksum mismatch), or a TBZ_E_* argument error. */
+int tbz_inflate_sharded_plan(const uint8_t* in, size_t in_len, size_t n_parts, uint64_t* cuts /* [n_parts + 1] */);
+int tbz_inflate_sharded_verdict(int format, const uint8_t* in, size_t in_len, size_t n_parts, const uint64_t* cuts,
+                                const tbz_result* recs, const uint32_t* part_check, uint64_t* out_offs, uint64_t* total,
+                                uint32_t* check, uint64_t* in_consumed, int* why);
 
 /* ---- every member of a concatenated gzip file ------------------------------------------------------
  * 3bz decodes ONE member per call and stops after its trailer (gzip.lisp:277-286: "todo: support multiple

@@ -80,6 +80,7 @@
   (session :pointer) (out :pointer) (out-cap :size) (res :pointer))
 (cffi:defcfun ("tbz_gzip_header_parse" %gzip-header-parse) :int (in :pointer) (in-len :size) (out :pointer))
 (cffi:defcfun ("tbz_device_count" %device-count) :int)
+(cffi:defcfun ("tbz_memcpy_d2h" %memcpy-d2h) :int (ctx :pointer) (h-dst :pointer) (d-src :pointer) (bytes :size))
 (cffi:defcfun ("tbz_inflate_size" %inflate-size) :int
   (ctx :pointer) (format :int) (in :pointer) (in-len :size) (res :pointer))
 (cffi:defcfun ("tbz_inflate_batch_multi" %inflate-batch-multi) :int
@@ -257,6 +258,18 @@
              (check-call (%session-feed session (cffi:inc-pointer p (cb-offset b)) n 0) "tbz_session_feed"))))
         (octet-pointer-context
          (assert (valid-octet-pointer (op context)))                  ; io-mmap.lisp:66
+         ;; the gzip-state's metadata slots are filled from the octets the state is GIVEN, whatever memory holds them:
+         ;; the head of the range (a header is at most ~70 KB) is copied into a Lisp vector — read in place from host
+         ;; memory, fetched from the device for a device pointer
+         (when (and (typep state 'gzip-state) (not (gs-header-parsed state)))
+           (let* ((m (min n 70000))
+                  (v (make-array m :element-type 'octet))
+                  (src (cffi:inc-pointer (%pointer context) (cb-offset b))))
+             (if (device-p (op context))
+                 (cffi:with-pointer-to-vector-data (pv v)
+                   (check-call (%memcpy-d2h (engine) pv src m) "tbz_memcpy_d2h"))
+                 (dotimes (i m) (setf (aref v i) (cffi:mem-aref src :uint8 i))))
+             (note-gzip-header state v 0 m)))
          (check-call (%session-feed session (cffi:inc-pointer (%pointer context) (cb-offset b)) n
                                     (if (device-p (op context)) 1 0))
                      "tbz_session_feed"))
@@ -356,8 +369,13 @@
 returns.  ONE call of tbz_inflate_gzip_members: the member starts are found on the device, all members are decoded as
 one batch, and the walk that proves them runs inside the library.  A damaged or incomplete member signals what the
 one-member call at its offset signals."
-  (let ((*alloc-results* nil) (members nil))
-    (cffi:with-foreign-objects ((res '(:struct tbz-result) max-members) (offs :uint64 max-members) (n :size))
+  ;; (the result / offset arrays live on the HEAP: a million result records are 64 MiB, and WITH-FOREIGN-OBJECTS puts
+  ;; them on the control stack — 2 MiB on SBCL.  A member takes at least 20 octets, which bounds how many there can be.)
+  (let* ((*alloc-results* nil) (members nil)
+         (max-members (max 1 (min max-members (1+ (floor (- end start) 20)))))
+         (res (cffi:foreign-alloc '(:struct tbz-result) :count max-members))
+         (offs (cffi:foreign-alloc :uint64 :count max-members)))
+    (cffi:with-foreign-objects ((n :size))
       (unwind-protect
            (progn
              (cffi:with-pointer-to-vector-data (pin compressed)
@@ -372,7 +390,9 @@ one-member call at its offset signals."
                    (unless (zerop status) (error "incomplete gzip stream"))
                    (push (take-alloc-result (pop cells)) members)))))
         (dolist (cell *alloc-results*)   ; (what was handed out and not taken — an error above — is given back)
-          (unless (cffi:null-pointer-p (car cell)) (cffi:foreign-free (car cell))))))
+          (unless (cffi:null-pointer-p (car cell)) (cffi:foreign-free (car cell))))
+        (cffi:foreign-free res)
+        (cffi:foreign-free offs)))
     (nreverse members)))
 
 ;;; ---- many independent streams over several devices (SURVEY §8e; north_star: "host code stays Common Lisp") ----

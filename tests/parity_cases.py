@@ -1066,7 +1066,7 @@ def case_gzip_members(eng, n_members=8, max_len=12_000, n_false=300):
     # a damaged / truncated member raises what the one-member call at its offset raises
     for bad, start in ((blob[:-3], len(blob) - len(parts[-1])), (blob[:len(parts[0]) - 8] + b"\x00" + blob[len(parts[0]) - 7:], 0),
                        (b"\x1f\x8c" + blob[2:], 0)):
-        w = oracle_oneshot(bad, "gzip", max_len + 8, start=start)
+        w = oracle_oneshot(bad, "gzip", max(len(q) for q in plains) + 8, start=start)
         try:
             A.decompress_gzip_members(bad, engine=eng)
             raise AssertionError("damaged member accepted")
@@ -1075,6 +1075,64 @@ def case_gzip_members(eng, n_members=8, max_len=12_000, n_false=300):
                 assert e.code == w["code"], (e.code, w["code"])
             else:
                 assert w["flag"] == "underrun" and e.code == -20
+
+
+def case_stream_contexts(eng, n=50_000):
+    """make-octet-stream-context / %resync-file-stream (io-common.lisp:47-63): a stream that sits in the middle of a file —
+    octets before it, another stream behind it — decoded through a file stream; results as with the vector context over
+    the same octets (i.e. the oracle's), the context's offset and the FILE POSITION left just behind the stream's trailer
+    so that the caller reads on from there (what the resync is for), chunked reading through :end, and the asserts."""
+    import io
+    import tempfile
+    p1, p2 = _mixed_plain(n, 21), K.enwik_like(n // 3, seed=22)
+    s1, s2 = zlib.compress(p1, 6), pygzip.compress(p2, 6, mtime=0)
+    blob = b"HEAD" + s1 + s2 + b"TAIL"
+    with tempfile.TemporaryFile() as f:
+        f.write(blob)
+        f.flush()
+        f.seek(0)
+        want = oracle_oneshot(blob, "zlib", n + 10, start=4)
+        st = A.make_zlib_state(bytearray(n + 10))
+        ctx = A.make_octet_stream_context(f, offset=4)
+        assert A.valid_octet_stream(f) and ctx.end == len(blob)
+        ret = A.decompress(ctx, st, engine=eng)
+        assert A.finished(st) and ret == want["ret"] == len(p1) and bytes(st.output_buffer[:ret]) == p1
+        assert ctx.offset == 4 + len(s1) and f.tell() == ctx.offset       # just behind the adler32
+        # the caller goes on with the next stream from where the file stands
+        st2 = A.make_gzip_state(bytearray(len(p2)))
+        ctx2 = A.make_octet_stream_context(f, offset=f.tell())
+        ret = A.decompress(ctx2, st2, engine=eng)
+        assert A.finished(st2) and bytes(st2.output_buffer[:ret]) == p2 and f.read() == b"TAIL"
+        # a context stored for later: the stream has moved on meanwhile, the resync puts it back
+        ctx3 = A.make_octet_stream_context(f, offset=4, end=4 + 1000)
+        f.seek(0, 2)
+        A.resync_file_stream(ctx3)
+        assert f.tell() == 4
+        A.resync_file_stream(A.make_octet_vector_context(blob))           # (the default method: nothing)
+        # chunked: :end moved forward call by call, compared with the oracle fed the same chunks
+        so, se = O.State(FMT["zlib"], bytearray(n + 10)), A.make_zlib_state(bytearray(n + 10))
+        pos = 4
+        while not O.finished(so):
+            end = min(len(blob), pos + 7001)
+            ro = O.decompress(O.make_octet_vector_context(blob, start=pos, end=end), so)
+            re_ = A.decompress(A.make_octet_stream_context(f, offset=pos, end=end), se, engine=eng)
+            assert re_ == ro and (A.finished(se), A.input_underrun(se)) == (O.finished(so), O.input_underrun(so))
+            pos = end
+        assert bytes(se.output_buffer[:se.output_offset]) == p1
+    for bad in (io.StringIO("text"), None):
+        try:
+            A.make_octet_stream_context(bad)
+            raise AssertionError("accepted something that is no binary input stream")
+        except A.ThreeBzError:
+            pass
+    closed = io.BytesIO(s1)
+    c4 = A.make_octet_stream_context(closed)
+    closed.close()
+    try:
+        A.decompress(c4, A.make_zlib_state(bytearray(10)), engine=eng)
+        raise AssertionError("closed stream accepted")
+    except A.ThreeBzError:
+        pass
 
 
 def case_pointer_contexts(eng, n=60_000):
@@ -1126,6 +1184,44 @@ def case_pointer_contexts(eng, n=60_000):
             eng.free(d_in)
 
 
+def host_pipeline(eng_factory, n=800 << 10):
+    """tbz_inflate on a LARGE host stream decodes it part by part — input of part k+1, decode of part k, output of part
+    k-1 at the same time — where it is a clean chain of flush-delimited parts (tbz_inflate_sharded_plan / _verdict), and
+    by the ordinary path everywhere else: results are the ordinary path's, to the octet and the flag.  `eng_factory(env)`
+    makes an engine with the thresholds in `env` (the CPU suite forces the path at 1 MiB)."""
+    env = {"TBZ_PIPE_MIN_KIB": 256, "TBZ_PIPE_PART_KIB": 96, "TBZ_STAGE_CHUNK_KIB": 128, "TBZ_COPY_THREADS": 3} if n < (32 << 20) else {}
+    e, plain_eng = eng_factory(env), eng_factory({"TBZ_PIPE_MIN_KIB": 0})
+    try:
+        s, p, ad = K.zlib_flush_stream(n)
+        c = zlib.compressobj(6, zlib.DEFLATED, 31)
+        g = b"".join(c.compress(p[i:i + 16384]) + c.flush(zlib.Z_FULL_FLUSH) for i in range(0, len(p), 16384)) + c.flush()
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        d = b"".join(c.compress(p[i:i + 16384]) + c.flush(zlib.Z_FULL_FLUSH) for i in range(0, len(p), 16384)) + c.flush()
+        for fmt, blob in (("zlib", s), ("gzip", g), ("deflate", d)):
+            out, out0 = bytearray(len(p)), bytearray(len(p))
+            r, r0 = e.inflate(blob, FMT[fmt], out), plain_eng.inflate(blob, FMT[fmt], out0)
+            assert e.timings().passes >= 2, "the pipelined path did not take this stream"
+            assert bytes(out) == p == bytes(out0)
+            for f in ("status", "out_len", "out_total", "in_consumed", "adler32", "crc32", "trailer_check", "trailer_isize",
+                      "segments", "boundary_out"):
+                assert getattr(r, f) == getattr(r0, f), (fmt, f, getattr(r, f), getattr(r0, f))
+            assert (r.flags & 3) == (r0.flags & 3), (r.flags, r0.flags)
+        # everything that is not a clean chain of parts: the ordinary path's answer
+        s2, p2, _ = K.zlib_flush_stream(n // 2, flush=zlib.Z_SYNC_FLUSH)          # history across the cuts
+        pz = K.enwik_like(n // 2, 3)
+        bad = bytearray(s)
+        bad[len(bad) * 2 // 3] ^= 4                                               # damage in a late part
+        for what, blob, cap in (("sync flush", s2, len(p2)), ("no flush", zlib.compress(pz, 6), len(pz)), ("damaged", bytes(bad), len(p)),
+                                ("short buffer", s, len(p) // 2), ("truncated", s[:len(s) * 3 // 4], len(p)), ("bad adler", s[:-1] + bytes([s[-1] ^ 1]), len(p))):
+            out, out0 = bytearray(cap), bytearray(cap)
+            r, r0 = e.inflate(blob, FMT["zlib"], out), plain_eng.inflate(blob, FMT["zlib"], out0)
+            assert (r.status, r.out_len, r.in_consumed, r.adler32) == (r0.status, r0.out_len, r0.in_consumed, r0.adler32), (what, r.status, r0.status)
+            assert bytes(out[:r.out_len]) == bytes(out0[:r0.out_len]), what
+    finally:
+        e.close()
+        plain_eng.close()
+
+
 def multi_context_batch(engines):
     """tbz_inflate_batch_multi: n streams over several contexts, one host thread each, results in stream order; the
     assignment is multi.assign_streams's (longest compressed first to the least loaded).  Statuses, counts, checksums
@@ -1152,6 +1248,46 @@ def multi_context_batch(engines):
         o = oracle_oneshot(streams[i], "zlib", caps[i])
         if o["flag"] != "error":
             assert bytes(outs2[i][:g.out_len]) == o["bytes"], i
+    # the same streams ALREADY RESIDENT on their contexts' devices (tbz_inflate_batch_multi_device): nothing is staged
+    owner = eng.assign_streams(sizes, len(engines))
+    parts, bufs = [], []
+    for k, e in enumerate(engines):
+        mine = [i for i in range(len(streams)) if owner[i] == k]
+        io_, oo_, ip, op = [], [], 0, 0
+        for i in mine:
+            io_.append(ip)
+            ip += (len(streams[i]) + 15) & ~15
+            oo_.append(op)
+            op += (caps[i] + 15) & ~15
+        d_in, d_out = e.malloc(ip + 64), e.malloc(op + 64)
+        for i, o in zip(mine, io_):
+            if streams[i]:
+                e.h2d(d_in + o, streams[i])
+        parts.append((d_in, io_, [len(streams[i]) for i in mine], d_out, oo_, [caps[i] for i in mine]))
+        bufs.append((mine, d_in, d_out, oo_))
+    try:
+        got_d = T.Engine.inflate_batch_multi_device(engines, parts, FMT["zlib"])
+        for (mine, d_in, d_out, oo_), rs, e in zip(bufs, got_d, engines):
+            for i, o, g in zip(mine, oo_, rs):
+                w = want[i]
+                assert (w.status, w.out_len, w.out_total, w.adler32, w.in_consumed) == (g.status, g.out_len, g.out_total, g.adler32, g.in_consumed), i
+                back = bytearray(int(g.out_len))
+                if g.out_len:
+                    e.d2h(back, d_out + o)
+                assert bytes(back) == bytes(outs1[i][:w.out_len]), i
+    finally:
+        for (mine, d_in, d_out, oo_), e in zip(bufs, engines):
+            e.free(d_in)
+            e.free(d_out)
+    # one context is one in-flight call: the same context twice is refused, by both entries
+    if len(engines) >= 2:
+        for call in (lambda: T.Engine.inflate_batch_multi([eng, eng], streams[:2], FMT["zlib"], [bytearray(caps[0]), bytearray(caps[1])]),
+                     lambda: T.Engine.inflate_batch_multi_device([eng, eng], [parts[0], parts[0]], FMT["zlib"])):
+            try:
+                call()
+                raise AssertionError("duplicate contexts accepted")
+            except T.EngineError:
+                pass
     # ... and a single decode straight into device memory (tbz_inflate_to_device)
     res, d = eng.inflate_to_device(streams[0], FMT["zlib"])
     try:
@@ -1166,7 +1302,7 @@ ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_reference_chunk
              case_noflush_streams, case_block_starts_found, case_close_block_starts, case_fixed_block_chains, case_history_across_groups,
              case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_device_buffers,
              case_checksum_kernels, case_deep_codes, case_chunked_resume, case_gzip_members,
-             case_pointer_contexts, case_container_headers, case_gzip_metadata, case_scratch_bounds, case_token_density, case_fuzz]
+             case_pointer_contexts, case_stream_contexts, case_container_headers, case_gzip_metadata, case_scratch_bounds, case_token_density, case_fuzz]
 # what each engine flavour of the test modules runs.  "auto" runs everything; the others run the cases that can
 # tell them apart (the CPU suite has to stay within minutes: a case costs seconds on the lane emulator)
 FLAVOUR_CASES = {

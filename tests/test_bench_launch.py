@@ -46,3 +46,13 @@ def test_bench_single_process_configs():
         j = _run("--config", cfg, "--size-mib", "0.5")
         assert j["n_gpus"] == 1 and j["value"] > 0, cfg
         assert j["config"]["workload"].startswith("config %s:" % cfg)
+
+
+def test_bench_one_stream_across_two_ranks():
+    """--config 2s: ONE flush-delimited stream decoded by both ranks together (tbz_inflate_sharded_plan / _verdict, one
+    all_gather of 8 x int64 per rank): strong scaling, the whole stream's octets counted once"""
+    j = _run("--gpus", "2", "--config", "2s", "--size-mib", "0.5")
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["workload"].startswith("config 2s:")
+    assert j["config"]["decompressed_bytes"] == 512 << 10 and j["value"] > 0
+    j = _run("--config", "2s", "--size-mib", "0.25")     # one rank: the plan is one part, the verdict the engine's own
+    assert j["n_gpus"] == 1 and j["scaling"] == "strong"

@@ -85,6 +85,20 @@ def test_emu_batch_over_two_contexts():
             e.close()
 
 
+def test_emu_host_pipeline():
+    """the part-by-part host-to-host path of tbz_inflate, forced at 1 MiB"""
+    T = importlib.import_module("3bz_amd")
+
+    def factory(env):
+        os.environ.update({k: str(v) for k, v in env.items()})
+        try:
+            return T.Engine(0, lib_path=os.path.join(EMU_DIR, "libtbz_emu.so"))
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    P.host_pipeline(factory)
+
+
 def test_emu_k0b_two_tiles_per_wave():
     """large launches of the K0b validation put two tiles on a wave (32 lanes each): forced here at a small size"""
     T = importlib.import_module("3bz_amd")
@@ -124,25 +138,19 @@ def test_emu_k6_resolve_with_the_window_in_lds():
 
 
 def test_emu_sanitized():
-    """ASan/UBSan are CPU-only on this pool: the kernel + engine sources, compiled with both, run the cases
-    that stress addressing (known-answer vectors; false markers incl. crowded tiles and fix-up rounds).  The
-    whole case list was run this way once per K1 flavour when the kernels last changed."""
-    import sys
-
-    r = subprocess.run(["make", "-C", EMU_DIR, "libtbz_emu_asan.so"], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
-    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
-    code = (
-        "import importlib, sys\n"
-        "sys.path.insert(0, %r)\n"
-        "from tests import parity_cases as P\n"
-        "T = importlib.import_module('3bz_amd')\n"
-        "eng = T.Engine(0, lib_path=%r)\n"
-        "for c in (P.case_known_answer_vectors, P.case_false_markers):\n"
-        "    c(eng)\n"
-        "eng.close()\n"
-        "print('sanitized ok')\n" % (ROOT, os.path.join(EMU_DIR, "libtbz_emu_asan.so")))
-    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0")
-    env.pop("TBZ_K1_MODE", None)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
-    assert r.returncode == 0 and "sanitized ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+    """ASan/UBSan are CPU-only on this pool: the kernel + engine sources, compiled with both, run
+    tests/sanitizer_scenarios.py — scenarios sized for the sanitizer that reach every kernel family, the ones rounds 3
+    and 4 added included (K0g and the member walk, K6's LDS resolve, the ring kernel's far read-back, tbz_k3_slice, K0c
+    inside items, ITEM_RESUME, the second stream, gangs of 32 with parked lists, staged host copies).  The run is
+    started in the background when the CPU session starts (tests/conftest.py) and joined here."""
+    from tests import san_runner
+    procs = san_runner.start()
+    for names, p in procs:
+        try:
+            out, err = p.communicate(timeout=1500)
+        except Exception:
+            p.kill()
+            raise
+        assert p.returncode == 0 and "sanitized ok" in out, (names, out[-800:], err[-3000:])
+        for n in names:
+            assert (n + " ok") in out, (n, out[-800:])

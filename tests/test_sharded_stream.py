@@ -26,7 +26,7 @@ def eng():
 
 
 def run_all_ranks(eng, data, fmt, world):
-    cuts = M.shard_plan(data, world)
+    cuts = M.shard_plan(data, world, lib=eng.lib)
     recs, parts = [], []
     for r in range(world):
         rec, d, n = M.shard_decode(eng, data, fmt, cuts, r)
@@ -37,7 +37,7 @@ def run_all_ranks(eng, data, fmt, world):
             eng.free(d)
         recs.append(rec)
         parts.append(bytes(b))
-    return cuts, recs, M.shard_verdict(recs, data, fmt, cuts), b"".join(parts)
+    return cuts, recs, M.shard_verdict(recs, data, fmt, cuts, lib=eng.lib), b"".join(parts)
 
 
 def flushed(plain, wbits, every, mode=zlib.Z_FULL_FLUSH, level=6):

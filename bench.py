@@ -51,8 +51,8 @@ DEFAULT_MIB = {"1": 0, "2": 1024, "2s": 1024, "2b": 256, "nf": 64, "3": 1024, "3
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="2", choices=CONFIGS)
     ap.add_argument("--size-mib", type=float, default=0, help="decompressed MiB of the workload (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -181,6 +181,37 @@ def build_workload(cfg, mib, rank, world, workers):
     raise SystemExit("unknown config")
 
 
+def save_workload(wl, d):
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    idx = {"name": wl.name, "fmt": wl.fmt, "scaling": wl.scaling, "note": wl.note, "total_U": getattr(wl, "total_U", None),
+           "blob": getattr(wl, "blob", None) is not None, "streams": []}
+    with open(os.path.join(d, "octets.bin"), "wb") as f:
+        for s, p, ck in wl.streams:
+            idx["streams"].append([len(s), len(p), ck])
+            f.write(s)
+            f.write(p)
+        if idx["blob"]:
+            idx["blob_len"] = len(wl.blob)
+            f.write(wl.blob)
+    with open(os.path.join(d, "index.json"), "w") as f:
+        json.dump(idx, f)
+
+
+def load_workload(d):
+    idx = json.load(open(os.path.join(d, "index.json")))
+    streams = []
+    with open(os.path.join(d, "octets.bin"), "rb") as f:
+        for ls, lp, ck in idx["streams"]:
+            streams.append((f.read(ls), f.read(lp), ck))
+        blob = f.read(idx["blob_len"]) if idx["blob"] else None
+    wl = Workload(idx["name"], idx["fmt"], streams, scaling=idx["scaling"], note=idx["note"])
+    if idx["total_U"]:
+        wl.total_U = idx["total_U"]
+    if blob is not None:
+        wl.blob = blob
+    return wl
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -232,17 +263,23 @@ def main(argv=None):
     wl = None
     cache = None
     if args.corpus_cache:
-        import pickle
-        os.makedirs(args.corpus_cache, exist_ok=True)
-        cache = os.path.join(args.corpus_cache, "wl_%s_%g_r%dof%d.pkl" % (cfg, mib, rank, world))
-        if os.path.exists(cache):
-            with open(cache, "rb") as f:
-                wl = pickle.load(f)
+        # The cache holds raw octets and a JSON index — nothing that executes when it is read — in a directory only this
+        # user can enter, and its name carries a hash of the generators (tools/corpus.py) and of this file's workload
+        # table: a change to either makes a new entry instead of silently reusing a corpus the source no longer describes.
+        import hashlib
+        h = hashlib.sha256(open(os.path.join(ROOT, "tools", "corpus.py"), "rb").read())
+        h.update(open(os.path.abspath(__file__), "rb").read())
+        os.makedirs(args.corpus_cache, mode=0o700, exist_ok=True)
+        st = os.stat(args.corpus_cache)
+        if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+            raise SystemExit("--corpus-cache %s: not a private directory of this user" % args.corpus_cache)
+        cache = os.path.join(args.corpus_cache, "wl_%s_%g_r%dof%d_%s" % (cfg, mib, rank, world, h.hexdigest()[:16]))
+        if os.path.exists(os.path.join(cache, "index.json")):
+            wl = load_workload(cache)
     if wl is None:
         wl = build_workload(cfg, mib, rank, world, workers)  # forks its worker pool here, before any GPU / RCCL state
         if cache:
-            with open(cache, "wb") as f:
-                pickle.dump(wl, f, protocol=4)
+            save_workload(wl, cache)
     gen_s = time.time() - t0
     if args.gen_only:
         return 0

@@ -12,6 +12,6 @@ for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
          "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_FLAT SQ_INSTS_BRANCH" \
          "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C -d $R/gpurun_out/pmc_${TAG}_$i -o p -- python3 $R/bench.py --corpus-cache /tmp/tbz_corpus_$(id -u) --steps 1 --warmup 1 --size-mib $SZ --no-cpu-baseline > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1 || { echo "pass $i failed"; tail -3 $R/gpurun_out/pmc_${TAG}_$i.log; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C -d $R/gpurun_out/pmc_${TAG}_$i -o p -- python3 $R/bench.py --corpus-cache /tmp/tbz_corpus_$(id -u) --steps 1 --warmup 1 --size-mib $SZ --no-cpu-baseline --no-h2h > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1 || { echo "pass $i failed"; tail -3 $R/gpurun_out/pmc_${TAG}_$i.log; }
 done
 ls $R/gpurun_out/ | head -30

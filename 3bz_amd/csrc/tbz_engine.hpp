@@ -56,7 +56,7 @@ struct DevBuf {
   X(d_out_stage) X(d_kb_tf) X(d_kb_slots) X(d_kb_counts) X(d_kb_offsets) X(d_kb_cands) X(d_kb_fc) X(d_kb_head) \
   X(d_markers2) X(d_kb_fm2) X(d_mark) X(d_hg) X(d_k6s) X(d_bigs) X(d_recs) X(d_kc_tf) \
   X(d_kc_slots) X(d_kc_ends) X(d_kc_link) X(d_kc_fm2) X(d_markers3) X(d_kb_keep) X(d_kb_kcounts) X(d_gz_cands) \
-  X(d_gz_count) X(d_gz_tmp) X(d_wide_res) X(d_cold) X(d_cold2)
+  X(d_gz_count) X(d_gz_tmp) X(d_wide_res) X(d_cold) X(d_cold2) X(d_small_rec)
 
 namespace tbz {
 // A few host threads that copy between a caller's (pageable) buffer and the pinned staging buffers: one thread moves
@@ -173,6 +173,8 @@ struct tbz_ctx {
   tbz::CopyPool* copy_pool = nullptr;
   tbz::CopyPool* copy_pool2 = nullptr;  // the pipelined path drains the output while the input is still arriving
   hipStream_t stream_in = nullptr, stream_out = nullptr;  // ... on streams of their own
+  bool small_fused = true;   // env TBZ_SMALL_FUSED=0: no one-launch path for small streams (tbz_small_fused)
+  size_t small_max_in = 80u << 10;  // ... which takes single streams up to this many octets (env TBZ_SMALL_MAX_KIB)
   size_t pipe_min = 64u << 20;  // host inputs from this size on are decoded part by part (env TBZ_PIPE_MIN_KIB; 0: never)
   size_t pipe_part = 32u << 20; // ... of about this many input octets (env TBZ_PIPE_PART_KIB)
   int copy_threads = 8;      // env TBZ_COPY_THREADS (1: the calling thread alone)
@@ -611,6 +613,51 @@ struct CoreOpts {
   int32_t first_error = 0;     // prefix_on_error: the status a plain call would have reported (0 if none)
 };
 
+// ---- one small stream in ONE launch (tbz_small_fused, tbz_kernels.hpp): the kernel decides the clean case only —
+// finished, trailer present and matching, everything fits — and says "fall back" for anything else, so every other
+// outcome is produced by the general path below.  One launch, one 128-octet read-back: the call floor falls from ~200 us
+// (a dozen launches, three read-backs) to ~35.
+static int small_fused_try(tbz_ctx* ctx, int format, const void* d_in, uint64_t in_len, void* d_out, uint64_t out_cap,
+                           tbz_result* R, bool* handled) {
+  *handled = false;
+  int r;
+  const uint64_t tok_words = (in_len * 8 >> 1) + 256, run_slots = (in_len * 8 >> RUN_SHIFT) + 4;
+  if ((r = ensure(ctx, ctx->d_tok, tok_words * 2))) return r;
+  if ((r = ensure(ctx, ctx->d_runs, run_slots * sizeof(RunRec)))) return r;
+  if ((r = ensure(ctx, ctx->d_small_rec, sizeof(SmallRec)))) return r;
+  if ((r = pinned(ctx, sizeof(SmallRec)))) return r;
+  SmallParams sp{(const u8*)d_in, in_len, (u8*)d_out, out_cap, (u32)format, (u32)std::max<long>(0, ctx->tun.find_min_len),
+                 (u16*)ctx->d_tok.p, (RunRec*)ctx->d_runs.p, (const u32*)ctx->d_crc_tab.p, (SmallRec*)ctx->d_small_rec.p};
+  TBZ_LAUNCH(tbz_small_fused, 1, ctx->stream, sp);
+  SmallRec* h = (SmallRec*)ctx->h_pin;
+  TBZ_HIP(hipMemcpyAsync(h, ctx->d_small_rec.p, sizeof(SmallRec), hipMemcpyDeviceToHost, ctx->stream));
+  TBZ_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->tun.debug) fprintf(stderr, "tbz: small fused: state %u why %u\n", h->state, h->why);
+  if (h->state != SMALL_DONE) return 0;
+  const SegResult& q = h->seg;
+  memset(R, 0, sizeof *R);
+  R->status = TBZ_FINISHED;
+  R->segments = (q.tok_words || q.out_bytes) ? 1u : 0u;
+  R->out_len = R->out_total = R->boundary_out = q.out_bytes;
+  R->in_consumed = q.end_bit / 8;
+  R->flags = 2u | (format != TBZ_FORMAT_DEFLATE ? 1u : 0u);
+  if (format != TBZ_FORMAT_DEFLATE) {
+    R->trailer_check = q.trailer0;
+    R->trailer_isize = format == TBZ_FORMAT_GZIP ? q.trailer1 : 0u;
+    (format == TBZ_FORMAT_ZLIB ? R->adler32 : R->crc32) = h->check;
+  }
+  ctx->tim.huff_launches = 1;
+  ctx->tim.k1_gang = 64;
+  ctx->tim.k2_kinds = q.tok_words ? 4u : 0u;
+  ctx->tim.token_words = q.tok_words;
+  ctx->tim.n_segments = ctx->tim.n_groups = R->segments;
+  ctx->tim.scratch_bytes = scratch_total(ctx);
+  ctx->gang_rounds = q.reserved >> 32;
+  ctx->gang_valid = q.reserved & 0xffffffffu;
+  *handled = true;
+  return 0;
+}
+
 // the whole pipeline on device-resident buffers
 static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, const uint64_t* in_offs,
                         const uint64_t* in_lens, void* d_out, const uint64_t* out_offs, const uint64_t* out_caps,
@@ -630,6 +677,16 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
   if (n == 0) return 0;
   if (n > 0x7fffffffu) return TBZ_E_ARG;
   int r;
+  // one small stream, an ordinary one-shot call, the engine's own flavours: the one-launch path first
+  if (n == 1 && !opt && !size_only && ctx->small_fused && in_lens[0] && in_lens[0] <= ctx->small_max_in && d_in && (d_out || !out_caps[0]) &&
+      !ctx->k1_mode && ctx->find_mode == 1 && !ctx->host_layout && !ctx->k2_single && ctx->sym_hist && !ctx->tun.tok_full) {
+    bool handled = false;
+    if ((r = small_fused_try(ctx, format, (const uint8_t*)d_in + in_offs[0], in_lens[0], d_out ? (uint8_t*)d_out + out_offs[0] : nullptr,
+                             out_caps[0], &results[0], &handled)))
+      return r;
+    if (handled) return 0;
+    ctx->tim = tbz_timings{};
+  }
 
   // ---------------------------------------------------------------- stream table + tiles
   std::vector<StreamPlan> sp(n);
@@ -2164,6 +2221,8 @@ int tbz_ctx_create(int device_id, tbz_ctx** out_ctx) {
   }
   if (const char* m = getenv("TBZ_COPY_THREADS")) ctx->copy_threads = std::max(1, std::min(64, atoi(m)));
   if (const char* m = getenv("TBZ_STAGE_CHUNK_KIB")) ctx->stage_chunk = (size_t)std::max(64, atoi(m)) << 10;
+  if (const char* m = getenv("TBZ_SMALL_FUSED")) ctx->small_fused = m[0] != '0';
+  if (const char* m = getenv("TBZ_SMALL_MAX_KIB")) ctx->small_max_in = (size_t)std::max(0, atoi(m)) << 10;
   if (const char* m = getenv("TBZ_PIPE_MIN_KIB")) ctx->pipe_min = (size_t)std::max(0, atoi(m)) << 10;
   if (const char* m = getenv("TBZ_PIPE_PART_KIB")) ctx->pipe_part = (size_t)std::max(16, atoi(m)) << 10;
   ctx->copy_threads = std::min<int>(ctx->copy_threads, std::max(1u, std::thread::hardware_concurrency()));

@@ -1184,6 +1184,70 @@ def case_pointer_contexts(eng, n=60_000):
             eng.free(d_in)
 
 
+def small_fused(eng_factory):
+    """tbz_small_fused: one launch for one small stream without flush points (the call floor).  The kernel only decides
+    the clean case; everything else falls back to the general path.  Here: the one-shot entry (tbz_inflate) with the
+    fused path on against the same engine with it off (TBZ_SMALL_FUSED=0) — every field of the result and the octets —
+    and against the oracle, over the reference's vectors, the three containers, stored / fixed / dynamic blocks, empty
+    output, truncations, damage, buffers that are too small, flush points (not its case), and config 1."""
+    e, e0 = eng_factory({}), eng_factory({"TBZ_SMALL_FUSED": 0})
+    fields = ("status", "out_len", "out_total", "in_consumed", "adler32", "crc32", "trailer_check", "trailer_isize", "boundary_out")
+    took = 0
+    try:
+        def check(blob, fmt, cap, what):
+            nonlocal took
+            out, out0 = bytearray(cap), bytearray(cap)
+            r, r0 = e.inflate(blob, FMT[fmt], out), e0.inflate(blob, FMT[fmt], out0)
+            t = e.timings()
+            took += t.k1_gang == 64 and t.huff_launches == 1 and t.scan_ms == 0.0
+            for f in fields:
+                assert getattr(r, f) == getattr(r0, f), (what, f, getattr(r, f), getattr(r0, f))
+            assert (r.flags & 7) == (r0.flags & 7), (what, r.flags, r0.flags)
+            assert bytes(out[:r.out_len]) == bytes(out0[:r0.out_len]), what
+            w = oracle_oneshot(blob, fmt, cap)
+            if w["flag"] == "finished":
+                assert r.status == 0 and bytes(out[:r.out_len]) == w["bytes"], what
+        vs = json.load(open(os.path.join(GOLDEN, "deflate_vectors.json")))["vectors"]
+        for v in vs:
+            check(bytes.fromhex(v["input_hex"]), "deflate", 1024, "vector@%d" % v["line"])
+        s1, p1 = K.config1_stream()
+        check(s1, "deflate", len(p1), "config 1")
+        check(s1, "deflate", len(p1) - 1, "config 1, short buffer")
+        s2, p2 = K.config1_stream(True)
+        check(s2, "deflate", len(p2), "config 1, two stored blocks")
+        for n in (1, 700, 9000, 40_000):
+            plain = _mixed_plain(n, n)
+            for level in (0, 1, 6, 9):
+                z = zlib.compress(plain, level)
+                g = pygzip.compress(plain, level, mtime=0)
+                for fmt, blob in (("zlib", z), ("gzip", g), ("deflate", z[2:-4])):
+                    check(blob, fmt, len(plain), "%s L%d n%d" % (fmt, level, n))
+                    check(blob, fmt, len(plain) + 77, "%s L%d n%d roomy" % (fmt, level, n))
+                    check(blob, fmt, len(plain) // 2, "%s L%d n%d short buffer" % (fmt, level, n))
+                    check(blob[:-1], fmt, len(plain), "%s L%d n%d cut by one" % (fmt, level, n))
+                    check(blob[:len(blob) // 2], fmt, len(plain), "%s L%d n%d cut in half" % (fmt, level, n))
+                    bad = bytearray(blob)
+                    bad[len(bad) // 2] ^= 0x20
+                    check(bytes(bad), fmt, len(plain), "%s L%d n%d damaged" % (fmt, level, n))
+                    check(blob[:-1] + bytes([blob[-1] ^ 1]), fmt, len(plain), "%s L%d n%d bad trailer" % (fmt, level, n))
+        for fmt in ("zlib", "gzip", "deflate"):
+            empty = {"zlib": zlib.compress(b"", 6), "gzip": pygzip.compress(b"", 6, mtime=0), "deflate": zlib.compress(b"", 6)[2:-4]}[fmt]
+            check(empty, fmt, 0, "empty " + fmt)
+            check(empty, fmt, 10, "empty, roomy " + fmt)
+        c = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+        check(c.compress(p1[:3000]) + c.flush(), "zlib", 3000, "fixed-Huffman block")
+        check(zlib.compress(bytes(200_000), 6), "zlib", 200_000, "zeros (dense tokens)")
+        check(zlib.compress(bytes(600_000), 9), "zlib", 600_000, "output beyond the fused path's bound")
+        fs, fp, _ = K.zlib_flush_stream(48 << 10)
+        check(fs, "zlib", len(fp), "flush points: the general path's stream")
+        s3, p3 = _fixed_chain(3, 60, 20)
+        check(s3, "deflate", len(p3) + 10, "chain of fixed blocks")
+        assert took > 100, took   # (the clean cases did go through the one launch)
+    finally:
+        e.close()
+        e0.close()
+
+
 def host_pipeline(eng_factory, n=800 << 10):
     """tbz_inflate on a LARGE host stream decodes it part by part — input of part k+1, decode of part k, output of part
     k-1 at the same time — where it is a clean chain of flush-delimited parts (tbz_inflate_sharded_plan / _verdict), and

@@ -85,6 +85,21 @@ def test_emu_batch_over_two_contexts():
             e.close()
 
 
+def _factory(env):
+    T = importlib.import_module("3bz_amd")
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return T.Engine(0, lib_path=os.path.join(EMU_DIR, "libtbz_emu.so"))
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+
+
+def test_emu_small_fused():
+    """the one-launch path for small streams against the general path and the oracle"""
+    P.small_fused(_factory)
+
+
 def test_emu_host_pipeline():
     """the part-by-part host-to-host path of tbz_inflate, forced at 1 MiB"""
     T = importlib.import_module("3bz_amd")

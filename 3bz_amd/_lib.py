@@ -53,7 +53,7 @@ SYMBOLS = [
     "tbz_session_create", "tbz_session_destroy", "tbz_session_feed", "tbz_session_decompress", "tbz_session_stats",
     "tbz_gzip_header_parse", "tbz_inflate_gzip_members", "tbz_inflate_gzip_members_device",
     "tbz_inflate_to_device", "tbz_assign_streams", "tbz_inflate_batch_multi", "tbz_inflate_batch_multi_device",
-    "tbz_inflate_sharded_plan", "tbz_inflate_sharded_verdict",
+    "tbz_inflate_sharded_plan", "tbz_inflate_sharded_verdict", "tbz_inflate_sharded_multi",
 ]
 
 
@@ -117,6 +117,7 @@ def load(path=None):
     L.tbz_inflate_sharded_plan.argtypes = [vp, sz, sz, u64p]
     L.tbz_inflate_sharded_verdict.argtypes = [C.c_int, vp, sz, sz, u64p, C.POINTER(Result), C.POINTER(C.c_uint32), u64p, u64p,
                                               C.POINTER(C.c_uint32), u64p, C.POINTER(C.c_int)]
+    L.tbz_inflate_sharded_multi.argtypes = [C.POINTER(vp), sz, C.c_int, vp, sz, vp, sz, C.POINTER(Result), C.POINTER(C.c_int)]
     for s in SYMBOLS:
         getattr(L, s)  # AttributeError if the ABI is incomplete
     return L

@@ -160,6 +160,16 @@ class Engine:
                                                              (vp * k)(*[q[3] for q in parts]), col(2), col(3), rp))
         return [list(r)[:len(q[1])] for r, q in zip(res, parts)]
 
+    @staticmethod
+    def inflate_sharded_multi(engines, data, fmt, out):
+        """ONE flush-delimited stream over several contexts in one call (tbz_inflate_sharded_multi): (result, sharded?)"""
+        k = len(engines)
+        ctxs = (C.c_void_p * k)(*[e._ctx for e in engines])
+        res, sh = _lib.Result(), C.c_int(0)
+        engines[0]._check(engines[0].lib.tbz_inflate_sharded_multi(ctxs, k, fmt, _addr(data), len(data), _addr(out),
+                                                                   len(out) if out is not None else 0, C.byref(res), C.byref(sh)))
+        return res, bool(sh.value)
+
     def assign_streams(self, sizes, parts):
         """tbz_assign_streams: owner[i] of stream i among `parts` contexts / ranks"""
         n = len(sizes)

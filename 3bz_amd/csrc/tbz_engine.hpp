@@ -3557,6 +3557,90 @@ int tbz_inflate_sharded_verdict(int format, const uint8_t* in, size_t in_len, si
   return 0;
 }
 
+// ONE flush-delimited stream over the contexts of several devices, from one host process (the counterpart of
+// 3bz_amd/multi.py:inflate_sharded for a host that is not a torch.distributed rank): plan, one host thread per context
+// (its part staged to its device, decoded into device memory sized by K1, checksummed there), verdict, and — all seams
+// clean — the parts copied into `out` at their offsets.  Anything not clean: context 0 decodes the whole stream by the
+// ordinary path (tbz_inflate), so statuses and errors are the single-device ones.  *sharded says which it was.
+int tbz_inflate_sharded_multi(tbz_ctx* const* ctxs, size_t n_ctx, int format, const uint8_t* in, size_t in_len, uint8_t* out,
+                              size_t out_cap, tbz_result* res, int* sharded) {
+  if (!ctxs || !n_ctx || !res || (in_len && !in) || (out_cap && !out) || format < 0 || format > 2) return TBZ_E_ARG;
+  for (size_t k = 0; k < n_ctx; k++) {
+    if (!ctxs[k]) return TBZ_E_ARG;
+    for (size_t j = 0; j < k; j++)
+      if (ctxs[j] == ctxs[k]) return TBZ_E_ARG;
+  }
+  if (sharded) *sharded = 0;
+  std::vector<uint64_t> cuts(n_ctx + 1);
+  int r = tbz_inflate_sharded_plan(in, in_len, n_ctx, cuts.data());
+  if (r) return r;
+  std::vector<tbz_result> recs(n_ctx);
+  std::vector<uint32_t> cks(n_ctx, 0);
+  std::vector<void*> bufs(n_ctx, nullptr);
+  std::vector<int> rc(n_ctx, 0);
+  for (auto& q : recs) memset(&q, 0, sizeof q);
+  size_t live = 0;
+  for (size_t k = 0; k < n_ctx; k++) live += cuts[k + 1] > cuts[k];
+  if (n_ctx > 1 && live > 1) {
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < n_ctx; k++)
+      th.emplace_back([&, k]() {
+        const uint64_t n = cuts[k + 1] - cuts[k];
+        if (!n && k) { recs[k].status = TBZ_INPUT_UNDERRUN; return; }
+        rc[k] = tbz_inflate_to_device(ctxs[k], k == 0 ? format : TBZ_FORMAT_DEFLATE, in + cuts[k], n, &bufs[k], &recs[k]);
+        if (rc[k] || recs[k].status < 0 || format == TBZ_FORMAT_DEFLATE || !recs[k].out_len) return;
+        if (format == TBZ_FORMAT_ZLIB) {
+          uint32_t s1 = 0, s2 = 0;
+          rc[k] = tbz_adler32_device(ctxs[k], bufs[k], recs[k].out_len, 1, 0, &s1, &s2);
+          cks[k] = s1 | (s2 << 16);
+        } else {
+          rc[k] = tbz_crc32_device(ctxs[k], bufs[k], recs[k].out_len, 0, &cks[k]);
+        }
+      });
+    for (auto& t : th) t.join();
+    bool ok = true;
+    for (size_t k = 0; k < n_ctx; k++) {
+      ok = ok && rc[k] == 0;
+      if (format == TBZ_FORMAT_ZLIB && recs[k].status >= 0 && !recs[k].out_len) cks[k] = 1;  // (adler32 of nothing)
+    }
+    std::vector<uint64_t> offs(n_ctx);
+    uint64_t total = 0, consumed = 0;
+    uint32_t check = 0;
+    int why = 0;
+    if (ok) ok = tbz_inflate_sharded_verdict(format, in, in_len, n_ctx, cuts.data(), recs.data(), cks.data(), offs.data(), &total,
+                                             &check, &consumed, &why) == 0;
+    if (ok && total <= out_cap) {
+      std::vector<std::thread> cp;
+      for (size_t k = 0; k < n_ctx; k++)
+        if (bufs[k] && recs[k].out_len)
+          cp.emplace_back([&, k]() { rc[k] = tbz_memcpy_d2h(ctxs[k], out + offs[k], bufs[k], recs[k].out_len); });
+      for (auto& t : cp) t.join();
+      for (size_t k = 0; k < n_ctx; k++) ok = ok && rc[k] == 0;
+    } else {
+      ok = false;
+    }
+    for (size_t k = 0; k < n_ctx; k++)
+      if (bufs[k]) tbz_device_free(ctxs[k], bufs[k]);
+    if (ok) {
+      memset(res, 0, sizeof *res);
+      res->status = TBZ_FINISHED;
+      res->out_len = res->out_total = res->boundary_out = total;
+      res->in_consumed = consumed;
+      res->flags = 2u | (format != TBZ_FORMAT_DEFLATE ? 1u : 0u);
+      for (size_t k = 0; k < n_ctx; k++) res->segments += recs[k].segments;
+      if (format == TBZ_FORMAT_ZLIB) res->adler32 = res->trailer_check = check;
+      if (format == TBZ_FORMAT_GZIP) {
+        res->crc32 = res->trailer_check = check;
+        const uint8_t* t = in + (consumed - 4);
+        res->trailer_isize = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+      }
+      if (sharded) *sharded = 1;
+      return 0;
+    }
+  }
+  return tbz_inflate(ctxs[0], format, in, in_len, out, out_cap, res);
+}
+
 int tbz_inflate_size(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len, tbz_result* res) {
   return stage_batch(ctx, format, 1, &in, &in_len, nullptr, nullptr, res, true);
 }

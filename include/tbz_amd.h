@@ -219,6 +219,12 @@ int tbz_inflate_batch_multi_device(tbz_ctx* const* ctxs, size_t n_ctx, int forma
  * clean: decode the stream by the ordinary path — its statuses are the answer; *why: r+1 = the seam after part r, -1 the
  * last part did not finish, -2 trailer incomplete, -3 checksum mismatch), or a TBZ_E_* argument error. */
 int tbz_inflate_sharded_plan(const uint8_t* in, size_t in_len, size_t n_parts, uint64_t* cuts /* [n_parts + 1] */);
+/* The three steps in one call for a host process that holds one context per device (the Lisp shim): plan over n_ctx parts,
+ * one host thread per context (stage its part, decode it into device memory, checksum it there), verdict, and — all seams
+ * clean — the parts copied into `out` at their offsets (*sharded = 1).  Anything else: ctxs[0] decodes the whole stream by
+ * tbz_inflate (*sharded = 0), so that statuses and errors are the single-device ones. */
+int tbz_inflate_sharded_multi(tbz_ctx* const* ctxs, size_t n_ctx, int format, const uint8_t* in, size_t in_len, uint8_t* out,
+                              size_t out_cap, tbz_result* res, int* sharded);
 int tbz_inflate_sharded_verdict(int format, const uint8_t* in, size_t in_len, size_t n_parts, const uint64_t* cuts,
                                 const tbz_result* recs, const uint32_t* part_check, uint64_t* out_offs, uint64_t* total,
                                 uint32_t* check, uint64_t* in_consumed, int* why);

@@ -89,6 +89,16 @@
 (cffi:defcfun ("tbz_inflate_gzip_members" %inflate-gzip-members) :int
   (ctx :pointer) (in :pointer) (in-len :size) (alloc :pointer) (user :pointer) (max-members :size) (results :pointer)
   (member-in-off :pointer) (n-members :pointer))
+;;; one flush-delimited stream over several decoders (SURVEY §8e row 2): the cut points, the seam proof, and the three
+;;; steps in one call for the contexts of OPEN-ENGINES
+(cffi:defcfun ("tbz_inflate_sharded_plan" %sharded-plan) :int
+  (in :pointer) (in-len :size) (n-parts :size) (cuts :pointer))
+(cffi:defcfun ("tbz_inflate_sharded_verdict" %sharded-verdict) :int
+  (format :int) (in :pointer) (in-len :size) (n-parts :size) (cuts :pointer) (recs :pointer) (part-check :pointer)
+  (out-offs :pointer) (total :pointer) (check :pointer) (in-consumed :pointer) (why :pointer))
+(cffi:defcfun ("tbz_inflate_sharded_multi" %inflate-sharded-multi) :int
+  (ctxs :pointer) (n-ctx :size) (format :int) (in :pointer) (in-len :size) (out :pointer) (out-cap :size) (res :pointer)
+  (sharded :pointer))
 
 (deftype octet () '(unsigned-byte 8))
 (deftype octet-vector () '(simple-array octet (*)))
@@ -410,6 +420,26 @@ one-member call at its offset signals."
 (defun close-engines ()
   (mapc #'%ctx-destroy *engines*)
   (setf *engines* nil))
+
+(defun decompress-vector-over-engines (compressed output &key (format :zlib) (start 0) (end (length compressed)))
+  "ONE stream decoded by all the engines of OPEN-ENGINES together where it is a clean chain of flush-delimited parts
+(tbz_inflate_sharded_multi: plan, a host thread per device, the seam proof), by the first engine alone otherwise.
+Returns (values OUTPUT COUNT SHARDED-P).  Signals what DECOMPRESS-VECTOR signals."
+  (let* ((engines (or *engines* (open-engines))) (k (length engines)))
+    (cffi:with-foreign-objects ((ctxs :pointer k) (res '(:struct tbz-result)) (sh :int))
+      (loop for e in engines for i from 0 do (setf (cffi:mem-aref ctxs :pointer i) e))
+      (cffi:with-pointer-to-vector-data (pin compressed)
+        (cffi:with-pointer-to-vector-data (pout output)
+          (check-call (%inflate-sharded-multi ctxs k (format-code format) (cffi:inc-pointer pin start) (- end start)
+                                              pout (length output) res sh)
+                      "tbz_inflate_sharded_multi")))
+      (cffi:with-foreign-slots ((status out-len) res (:struct tbz-result))
+        (when (minusp status) (error "~a" (%strerror status)))
+        (unless (zerop status)
+          (if (= status 1)
+              (error "incomplete ~a stream" format)
+              (error "not enough space to decompress ~a stream" format)))
+        (values output out-len (= 1 (cffi:mem-ref sh :int)))))))
 
 (defun decompress-vectors (vectors outputs &key (format :zlib))
   "VECTORS: a list of octet vectors, each one stream.  OUTPUTS: a list of octet vectors to decode them into (as

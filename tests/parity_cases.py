@@ -1352,6 +1352,19 @@ def multi_context_batch(engines):
                 raise AssertionError("duplicate contexts accepted")
             except T.EngineError:
                 pass
+    # ONE flush-delimited stream over the contexts in one call (tbz_inflate_sharded_multi): sharded where the seams are
+    # clean, the first context alone where they are not — results as one context's either way
+    if len(engines) >= 2:
+        fs, fp, fa = K.zlib_flush_stream(400 << 10)
+        ss, sp_, _ = K.zlib_flush_stream(200 << 10, flush=zlib.Z_SYNC_FLUSH)
+        for blob, plain, cap, want_sharded in ((fs, fp, len(fp), True), (ss, sp_, len(sp_), False), (fs, fp, len(fp) // 2, False),
+                                               (fs[:-1] + bytes([fs[-1] ^ 1]), fp, len(fp), False)):
+            o1, o2 = bytearray(cap), bytearray(cap)
+            w = eng.inflate(blob, FMT["zlib"], o1)
+            g, sh = T.Engine.inflate_sharded_multi(engines, blob, FMT["zlib"], o2)
+            assert sh == want_sharded, (sh, want_sharded)
+            assert (w.status, w.out_len, w.out_total, w.adler32, w.in_consumed, w.segments) == (g.status, g.out_len, g.out_total, g.adler32, g.in_consumed, g.segments)
+            assert bytes(o1[:w.out_len]) == bytes(o2[:g.out_len])
     # ... and a single decode straight into device memory (tbz_inflate_to_device)
     res, d = eng.inflate_to_device(streams[0], FMT["zlib"])
     try:

@@ -3154,6 +3154,129 @@ static int inflate_host_pipelined(tbz_ctx* ctx, int format, const uint8_t* in, s
   return 0;
 }
 
+// ---- a large BATCH, host to host, sub-batch by sub-batch: the same three movers as above — one thread gathers the
+// callers' input buffers into pinned chunks and streams them up, the calling thread decodes a sub-batch of consecutive
+// streams (about pipe_part octets of input) as soon as its last stream has arrived, a third thread streams the output
+// range down as far as it has been decoded and scatters it into the callers' buffers.  Streams are independent: there is
+// no verdict and no fallback, every stream's result is what the one-batch call gives it.
+static int batch_host_pipelined(tbz_ctx* ctx, int format, size_t n, const uint8_t* const* ins, uint8_t* const* outs,
+                                const std::vector<uint64_t>& io, const std::vector<uint64_t>& il, const std::vector<uint64_t>& oo,
+                                const std::vector<uint64_t>& oc, uint64_t in_total, uint64_t out_total, tbz_result* results) {
+  using namespace tbz;
+  int r;
+  if ((r = stage_setup(ctx))) return r;
+  std::vector<StagePiece> ps_in, ps_out(n);
+  for (size_t i = 0; i < n; i++) {
+    if (il[i]) ps_in.push_back(StagePiece{(uint8_t*)ins[i], io[i], il[i]});
+    ps_out[i] = StagePiece{outs[i], oo[i], 0};
+  }
+  std::atomic<uint64_t> arrived{0}, avail{0};
+  std::atomic<bool> all_decoded{false}, abort_out{false};
+  std::atomic<int> in_err{0}, out_err{0};
+  const uint64_t ch = ctx->stage_chunk;
+  auto hip_ok = [](hipError_t e) { return e == hipSuccess ? 0 : (int)TBZ_E_HIP; };
+  std::thread t_in([&]() {
+    hipSetDevice(ctx->device);
+    const size_t nch = (size_t)((in_total + ch - 1) / ch);
+    std::vector<CopySeg> sg;
+    size_t cursor = 0;
+    int e = 0;
+    for (size_t j = 0; j < nch && !e; j++) {
+      const int b = (int)(j & 1);
+      const uint64_t o = j * ch, len = std::min<uint64_t>(ch, in_total - o);
+      if (j >= 2) e = hip_ok(hipEventSynchronize(ctx->ev_stage[b]));
+      if (!e) {
+        stage_segments(ps_in, cursor, o, o + len, (uint8_t*)ctx->h_stage[b], true, sg);
+        stage_run(ctx->copy_pool, sg);
+        e = hip_ok(hipMemcpyAsync((uint8_t*)ctx->d_in_stage.p + o, ctx->h_stage[b], len, hipMemcpyHostToDevice, ctx->stream_in));
+      }
+      if (!e) e = hip_ok(hipEventRecord(ctx->ev_stage[b], ctx->stream_in));
+      if (!e && j >= 1) {
+        e = hip_ok(hipEventSynchronize(ctx->ev_stage[b ^ 1]));
+        if (!e) arrived.store(j * ch, std::memory_order_release);
+      }
+    }
+    if (!e && nch) e = hip_ok(hipEventSynchronize(ctx->ev_stage[(nch - 1) & 1]));
+    if (e) in_err.store(e);
+    arrived.store(in_total, std::memory_order_release);
+  });
+  std::thread t_out([&]() {
+    hipSetDevice(ctx->device);
+    int e = 0;
+    uint64_t issued = 0, pend_o[2] = {0, 0}, pend_n[2] = {0, 0};
+    size_t j = 0, cursor = 0;
+    std::vector<CopySeg> sg;
+    auto drain = [&](int b) {   // the chunk in pinned buffer b: scattered into the callers' buffers
+      if (!pend_n[b] || e) return;
+      e = hip_ok(hipEventSynchronize(ctx->ev_stage[2 + b]));
+      if (!e) {
+        stage_segments(ps_out, cursor, pend_o[b], pend_o[b] + pend_n[b], (uint8_t*)ctx->h_stage[2 + b], false, sg);
+        stage_run(ctx->copy_pool2, sg);
+      }
+      pend_n[b] = 0;
+    };
+    for (;;) {
+      uint64_t len = 0;
+      for (;;) {
+        if (abort_out.load()) return;
+        const uint64_t av = avail.load(std::memory_order_acquire);
+        const bool fin = all_decoded.load(std::memory_order_acquire);
+        if (av - issued >= ch) { len = ch; break; }
+        if (fin) { len = avail.load(std::memory_order_acquire) - issued; break; }
+        std::this_thread::yield();
+      }
+      const int b = (int)(j & 1);
+      drain(b);
+      if (len && !e) {
+        e = hip_ok(hipMemcpyAsync(ctx->h_stage[2 + b], (const uint8_t*)ctx->d_out_stage.p + issued, len, hipMemcpyDeviceToHost, ctx->stream_out));
+        if (!e) e = hip_ok(hipEventRecord(ctx->ev_stage[2 + b], ctx->stream_out));
+        pend_o[b] = issued;
+        pend_n[b] = len;
+        issued += len;
+        j++;
+      }
+      drain((int)(j & 1));
+      if (e || (all_decoded.load(std::memory_order_acquire) && issued == avail.load(std::memory_order_acquire))) break;
+    }
+    drain(0);
+    drain(1);
+    if (e) out_err.store(e);
+  });
+  int rc = 0;
+  tbz_timings acc{};
+  size_t units = 0;
+  for (size_t a = 0; a < n && !rc;) {
+    size_t b = a;
+    uint64_t got = 0;
+    while (b < n && (b == a || got < ctx->pipe_part)) got += il[b++];
+    const uint64_t need = io[b - 1] + il[b - 1];
+    while (arrived.load(std::memory_order_acquire) < need) std::this_thread::yield();
+    if (in_err.load()) break;
+    rc = inflate_passes(ctx, format, b - a, ctx->d_in_stage.p, io.data() + a, il.data() + a, ctx->d_out_stage.p, oo.data() + a,
+                        oc.data() + a, results + a, false);
+    if (rc) break;
+    const tbz_timings& t = ctx->tim;
+    acc.scan_ms += t.scan_ms; acc.huff_ms += t.huff_ms; acc.lz_ms += t.lz_ms; acc.cksum_ms += t.cksum_ms; acc.total_ms += t.total_ms;
+    acc.find_ms += t.find_ms; acc.resolve_ms += t.resolve_ms; acc.huff_launches += t.huff_launches; acc.token_words += t.token_words;
+    acc.n_segments += t.n_segments; acc.n_groups += t.n_groups; acc.n_candidates += t.n_candidates; acc.n_hgroups += t.n_hgroups;
+    acc.k1_gang = t.k1_gang; acc.k2_kinds |= t.k2_kinds; acc.scratch_bytes = std::max(acc.scratch_bytes, t.scratch_bytes);
+    for (size_t i = a; i < b; i++) ps_out[i].len = (results[i].status >= 0 && outs[i]) ? results[i].out_len : 0;
+    avail.store(b < n ? oo[b] : out_total, std::memory_order_release);
+    units++;
+    a = b;
+  }
+  if (rc || in_err.load()) abort_out.store(true); else all_decoded.store(true, std::memory_order_release);
+  t_in.join();
+  t_out.join();
+  if (rc) return rc;
+  if (in_err.load()) return in_err.load();
+  if (out_err.load()) return out_err.load();
+  acc.passes = (uint32_t)units;
+  acc.h2d_copies = (uint32_t)ps_in.size();
+  ctx->tim = acc;
+  return 0;
+}
+
 static int stage_batch(tbz_ctx* ctx, int format, size_t n, const uint8_t* const* ins, const size_t* in_lens,
                        uint8_t* const* outs, const size_t* out_caps, tbz_result* results, bool size_only) {
   using namespace tbz;
@@ -3184,6 +3307,14 @@ static int stage_batch(tbz_ctx* ctx, int format, size_t n, const uint8_t* const*
       ctx->tim.host_decode_ms = (float)(now_ms() - t_in);
       return 0;
     }
+  }
+  if (n > 1 && !size_only && ctx->pipe_min && it >= ctx->pipe_min) {
+    for (size_t i = 0; i < n; i++)
+      if ((in_lens[i] && !ins[i]) || (out_caps[i] && !outs[i])) return TBZ_E_ARG;
+    if ((r = batch_host_pipelined(ctx, format, n, ins, outs, io, il, oo, oc, it, ot, results))) return r;
+    ctx->tim.h2d_ms = ctx->tim.d2h_ms = 0.f;
+    ctx->tim.host_decode_ms = (float)(now_ms() - t_in);
+    return 0;
   }
   if (!uploaded) {
     std::vector<StagePiece> ps;

@@ -1281,6 +1281,24 @@ def host_pipeline(eng_factory, n=800 << 10):
             r, r0 = e.inflate(blob, FMT["zlib"], out), plain_eng.inflate(blob, FMT["zlib"], out0)
             assert (r.status, r.out_len, r.in_consumed, r.adler32) == (r0.status, r0.out_len, r0.in_consumed, r0.adler32), (what, r.status, r0.status)
             assert bytes(out[:r.out_len]) == bytes(out0[:r0.out_len]), what
+        # a large BATCH goes sub-batch by sub-batch through the same three movers (no seams to prove: streams are
+        # independent): results and octets as the one-batch call's, failures and short buffers among them
+        rng = random.Random(0x3B8)
+        m = 48 if n < (32 << 20) else 600
+        plains = [K.enwik_like(rng.randrange(1, n // 12), seed=500 + i) for i in range(m)] + [b""]
+        streams = [zlib.compress(q, rng.choice([1, 6])) for q in plains]
+        streams[5] = streams[5][:len(streams[5]) // 2]
+        streams[9] = streams[9][:30] + b"\xff" + streams[9][31:]
+        caps = [len(q) for q in plains]
+        caps[3] //= 2
+        o1, o0 = [bytearray(c) for c in caps], [bytearray(c) for c in caps]
+        r1, r0s = e.inflate_batch(streams, FMT["zlib"], o1), plain_eng.inflate_batch(streams, FMT["zlib"], o0)
+        assert e.timings().passes >= 2, "the batch was not pipelined"
+        for i, (a, b) in enumerate(zip(r1, r0s)):
+            assert (a.status, a.out_len, a.out_total, a.adler32, a.in_consumed, a.flags & 7) == (b.status, b.out_len, b.out_total, b.adler32, b.in_consumed, b.flags & 7), i
+            assert bytes(o1[i][:a.out_len]) == bytes(o0[i][:b.out_len]), i
+            if a.status == 0:
+                assert bytes(o1[i]) == plains[i], i
     finally:
         e.close()
         plain_eng.close()

@@ -14,7 +14,7 @@ quad-cycle whatever its type" and came out at 1.03 - 1.15 of it: a ceiling the m
 one gfx950 SIMD retires per NANOSECOND — the shader clock gives way under load, so cycles are the wrong unit — was taken for
 streams of the decoders' own instructions (v_alignbit / v_bfe / v_cndmask; s_and_b64 / s_cselect_b64; ds_read_u16) at
 VALU : SALU = 1 : 0, 2 : 1 and 1 : 1, with 1 .. 8 waves per SIMD on all 1 024 SIMDs.  A kernel's roof is that table read at
-the kernel's own SALU : VALU ratio and waves per SIMD (bilinear); issue_frac = (VALU + SALU + LDS per launch) / (1024 SIMDs x
+the kernel's own (SALU + LDS) : VALU ratio and waves per SIMD (bilinear); issue_frac = (VALU + SALU + LDS per launch) / (1024 SIMDs x
 duration x roof), which cannot exceed 1 by construction of the roof.  valu_frac is the vector pipe alone against the
 1 : 0 stream at the same occupancy."""
 import glob
@@ -99,7 +99,10 @@ def main(pattern, out, config, commit=None, date=None, roof_path=None):
         dur = c["_dur_ns"]
         valu, salu, lds = g("SQ_INSTS_VALU"), g("SQ_INSTS_SALU"), g("SQ_INSTS_LDS")
         w = wc / (busy / 4.0) / N_SIMD if busy else 0.0
-        spv = salu / valu if valu else 0.0
+        # scalar AND LDS instructions ride along with the vector ones (issue_roof: VS, VS11, VSL rows): the table is read at
+        # (SALU + LDS) per VALU (reading it at SALU per VALU alone put tbz_k0b_scan, a kernel AT the vector roof with an LDS
+        # lookup per four code lengths, at 1.11)
+        spv = (salu + lds) / valu if valu else 0.0
         peak = roof.rate(spv, w) if w else None          # wave-instructions per SIMD per ns, this mix, this occupancy
         vpeak = roof.rate(0.0, w, 2) if w else None      # the vector pipe alone
         ach = (valu + salu + lds) / (N_SIMD * dur) if dur else None

@@ -181,7 +181,10 @@ int tbz_inflate_batch_device(tbz_ctx* ctx, int format, size_t n, const void* d_i
                              const uint64_t* out_caps, tbz_result* results);
 
 /* One decode of host input into DEVICE memory that the caller then owns (release it with tbz_device_free): *d_out is
- * allocated once K1 has sized the output — no sizing pass, no second decode.  res->out_len octets at *d_out. */
+ * allocated once K1 has sized the output — no sizing pass, no second decode.  res->out_len octets at *d_out.  *d_out
+ * is NULL whenever the call returns non-zero (TBZ_E_NOMEM: the device refused the output allocation) and also for an
+ * output of zero octets; a stream-level error (res->status != TBZ_OK) still returns 0 with the octets decoded before
+ * it at *d_out. */
 int tbz_inflate_to_device(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len, void** d_out, tbz_result* res);
 
 /* ---- several devices from ONE host process --------------------------------------------------------

@@ -162,6 +162,7 @@ struct tbz_ctx {
   tbz_timings tim{};
   uint64_t gang_rounds = 0, gang_valid = 0;  // diagnostics of the last call (K1g)
   bool k1h = true;           // env TBZ_K1H=0: no header pre-pass (the gang leaders parse every header)
+  bool k2_ring2 = false;     // env TBZ_K2_RING=2: the ring kernel on two waves (round 3) instead of three
   bool k2_single = false;    // env TBZ_K2_MODE=single: one wave per group for the linear-window groups too (default: two)
   bool host_layout = false;  // env TBZ_HOST_LAYOUT=1: always chain / lay out on the host (tests force both paths)
   void* h_pin = nullptr;     // pinned host scratch for small read-backs
@@ -1404,7 +1405,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         k2.cls = h_glob->n_big < n_it ? 2 : 0;
         ctx->tim.k2_kinds |= 4u;
         if (ctx->k2_single) TBZ_LAUNCH(tbz_k2_lz77, n_it, ctx->stream, k2);
-        else TBZ_LAUNCH_WG(tbz_k2_lz77_ring2, n_it, 128, ctx->stream, k2);
+        else if (ctx->k2_ring2) TBZ_LAUNCH_WG(tbz_k2_lz77_ring2, n_it, 128, ctx->stream, k2);
+        else TBZ_LAUNCH_WG(tbz_k2_lz77_ring3, n_it, 192, ctx->stream, k2);
       }
       TBZ_HIP(hipGetLastError());
     }
@@ -1896,7 +1898,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       k2.win_bytes = 0;
       ctx->tim.k2_kinds |= 4u;
       if (ctx->k2_single) TBZ_LAUNCH(tbz_k2_lz77, order_big.size(), ctx->stream, k2);
-      else TBZ_LAUNCH_WG(tbz_k2_lz77_ring2, order_big.size(), 128, ctx->stream, k2);
+      else if (ctx->k2_ring2) TBZ_LAUNCH_WG(tbz_k2_lz77_ring2, order_big.size(), 128, ctx->stream, k2);
+        else TBZ_LAUNCH_WG(tbz_k2_lz77_ring3, order_big.size(), 192, ctx->stream, k2);
     }
     if (!order_h.empty()) {
       // ---- K6 work lists (see tbz_kernels.hpp): blocks = runs of consecutive H-groups of one stream, at most `bmax` long
@@ -2008,7 +2011,8 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       {
         const size_t nwg = order_big.size() + 2 * order_h.size();
         if (ctx->k2_single) TBZ_LAUNCH(tbz_k2_lz77, nwg, ctx->stream, k2);
-        else TBZ_LAUNCH_WG(tbz_k2_lz77_ring2, nwg, 128, ctx->stream, k2);
+        else if (ctx->k2_ring2) TBZ_LAUNCH_WG(tbz_k2_lz77_ring2, nwg, 128, ctx->stream, k2);
+        else TBZ_LAUNCH_WG(tbz_k2_lz77_ring3, nwg, 192, ctx->stream, k2);
       }
       TBZ_HIP(hipEventRecord(ctx->ev[10], ctx->stream));
       const K6Range* dr = (const K6Range*)ctx->d_hg.p;
@@ -2228,6 +2232,7 @@ int tbz_ctx_create(int device_id, tbz_ctx** out_ctx) {
   ctx->copy_threads = std::min<int>(ctx->copy_threads, std::max(1u, std::thread::hardware_concurrency()));
   if (const char* m = getenv("TBZ_HOST_LAYOUT")) ctx->host_layout = m[0] == '1';
   if (const char* m = getenv("TBZ_K2_MODE")) ctx->k2_single = !strcmp(m, "single");
+  if (const char* m = getenv("TBZ_K2_RING")) ctx->k2_ring2 = !strcmp(m, "2");
   if (const char* m = getenv("TBZ_K1H")) ctx->k1h = m[0] != '0';
   if (const char* m = getenv("TBZ_HIST")) ctx->sym_hist = strcmp(m, "off") != 0;
   if (const char* m = getenv("TBZ_POOL_CAP_MIB")) ctx->pool_cap = (uint64_t)std::max(1, atoi(m)) << 20;

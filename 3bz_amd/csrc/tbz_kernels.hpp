@@ -3532,6 +3532,7 @@ constexpr u32 K2_SLACK = 64;     // window octets past a group's output: alignme
 constexpr u32 K2_SMALL_MAX = 32768;  // groups producing at most this much (incl. K2_SLACK) take the linear path
 constexpr u32 K2_IDT = 256 + 40; // identity octets (k & 255): the low plane of a run of computed pointers, read like any source
 static_assert(K2R_HIST >= K2R_FLUSH + K2_SPAN + 258 + 16 + K2R_SPAN, "far sources must have been flushed");
+static_assert(K2R_FLUSH > K2R_SPAN, "a flush interval above the batch span: the first batch alone never triggers a flush");
 
 // window flavours: RW = 0 is the linear window; otherwise a ring of RW octets (a multiple of 16) of which HIST are
 // history
@@ -3585,16 +3586,18 @@ TBZ_DEV void k2_flush(const u8* win, u8* outp, u64 from, u64 to, u64 clip, u32 a
   u64 head_end = ((from + a0 + 15) & ~15ull) - a0;  // first 16-aligned offset >= from
   if (head_end > to) head_end = to;
   u64 body_end = head_end + ((to - head_end) & ~15ull);
-  if (from + lane < head_end) outp[from + lane] = win[LINEAR ? (u32)(from + lane + a0) : (u32)((from + lane + a0) % RW)];
+  // window index of offset x >= from: one 64-bit remainder per call, the rest in 32 bits (to - from < 2^32 always)
+  const u32 rf = LINEAR ? (u32)(from + a0) : (u32)((from + a0) % RW);
+  auto idx = [&](u64 x) -> u32 { return LINEAR ? rf + (u32)(x - from) : (rf + (u32)(x - from)) % RW; };
+  if (from + lane < head_end) outp[from + lane] = win[idx(from + lane)];
   u64 nchunk = (body_end - head_end) >> 4;
-  u32 r0 = LINEAR ? (u32)(head_end + a0) : (u32)((head_end + a0) % RW);
+  const u32 r0 = idx(head_end);
   for (u32 c = lane; c < (u32)nchunk; c += 64) {
     u32 ri = LINEAR ? r0 + c * 16 : (r0 + c * 16) % RW;
     uint4 v = *(const uint4*)(win + ri);
     *(uint4*)(outp + head_end + (u64)c * 16) = v;
   }
-  if (body_end + lane < to)
-    outp[body_end + lane] = win[LINEAR ? (u32)(body_end + lane + a0) : (u32)((body_end + lane + a0) % RW)];
+  if (body_end + lane < to) outp[body_end + lane] = win[idx(body_end + lane)];
   tbz_sync();
 }
 
@@ -3702,9 +3705,13 @@ TBZ_DEV void k2_copy_coop(const K2Src& S, u32 rpos, u64 gpos, i64 d, u32 rd, u32
 // final).  The first unresolved match is always ready, so every round makes progress.
 // RING: matches that copy from the flushed output or from computed pointers depend on nothing in flight: they go
 // first, all at once (one memory round trip per batch that has any).
-template <class W>
+// STAGE (ring kernels on three waves, tbz_k2_lz77_ring3): K2_FAR = that first round only, K2_NEAR = everything after it
+// (the far round was another wave's, one batch earlier: its memory round trip is off the resolving wave's path).
+constexpr u32 K2_ALL = 0, K2_FAR = 1, K2_NEAR = 2;
+template <class W, u32 STAGE = K2_ALL>
 TBZ_DEV void k2_resolve(const K2Src& S, u64 pend, u32 rpos, u64 gpos, u32 dofs, u32 len, u32 dist) {
   constexpr bool LINEAR = W::LINEAR;
+  static_assert(STAGE == K2_ALL || !LINEAR, "stages are the ring kernels'");
   constexpr u32 RW = LINEAR ? 1u : W::RW;
   u8* win = S.win;
   const bool SYM = !LINEAR && S.hist != 0;  // (wave-uniform)
@@ -3726,7 +3733,9 @@ TBZ_DEV void k2_resolve(const K2Src& S, u64 pend, u32 rpos, u64 gpos, u32 dofs, 
     const bool odd = mine && !symall && !far && (dist > W::HIST || (SYM && s < 0));
     const bool wide = len <= K2_SHORT && rd + 32 <= RW;
     const u64 farm = tbz_ballot(mine && far), symm = tbz_ballot(mine && symall), oddm = tbz_ballot(odd);
-    if (farm | symm) {
+    if (STAGE == K2_NEAR) {
+      pend &= ~(farm | symm);
+    } else if (farm | symm) {
       const bool fw = mine && wide && (far || symall);
       u64 A0 = 0, A1 = 0, B0 = 0, B1 = 0;
       const u64 m17 = tbz_ballot(fw && far && len >= 17);
@@ -3793,6 +3802,7 @@ TBZ_DEV void k2_resolve(const K2Src& S, u64 pend, u32 rpos, u64 gpos, u32 dofs, 
       pend &= ~(farm | symm);
       tbz_sync();
     }
+    if (STAGE == K2_FAR) return;
     // ---- sources that straddle the group's first octet wait their turn like any other (their part inside the group
     // must be final), then take the octet-by-octet path
     const u64 oddq = oddm & pend;
@@ -3935,18 +3945,24 @@ TBZ_DEV bool k2_pick_group(const K2Params& P, u32& gi, Group& g, Seg& sg_guess, 
 // resolving wave and returns while it is IN FLIGHT — so the ring is flushed only up to that batch's first octet, a
 // stored run (which this wave copies into the ring itself) waits for the resolving wave to drain, and the ring must
 // hold its history plus TWO spans.
-template <class W, u32 SPAN, bool DUAL, class Emit, class Finish>
+// DUAL = 2 (ring, three waves: front end -> far sources -> resolve): TWO batches are in flight behind the front end.
+template <class W, u32 SPAN, u32 DUAL, class Emit, class Finish>
 TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_guess, u8* win, u16* tks,
                      u32* rcache, Emit&& emit, Finish&& finish) {
   constexpr bool LINEAR = W::LINEAR;
-  static_assert(LINEAR || W::RW >= W::HIST + (DUAL ? 2 : 1) * SPAN + 64, "ring: history + the spans in flight");
+  static_assert(LINEAR || W::RW >= W::HIST + (DUAL + 1) * SPAN + 64, "ring: history + the spans in flight");
+  // what a far match reads has been flushed, and the flush waited for, when its batch is handed over: the flush stops at
+  // the oldest batch in flight and happens every K2R_FLUSH octets at the latest
+  static_assert(LINEAR || W::HIST >= SPAN + 258 + 16 + (K2R_FLUSH > DUAL * SPAN + 16 ? K2R_FLUSH : DUAL * SPAN + 16),
+                "far sources must have been flushed");
   const u32 lane = tbz_lane();
   const u64 lane_bit = 1ull << lane;
   u8* outp = P.out_base + (g.out_abs - P.out_bias);
   const u32 a0 = (u32)((uintptr_t)outp & 15);
   const u64 clip = g.out_end > g.out_abs ? g.out_end - g.out_abs : 0;
   u64 pos = 0, flushed = 0;
-  u64 bstart = 0;  // DUAL: first octet of the batch in flight (everything before it is resolved)
+  u64 bstart = 0;  // DUAL: first octet of the batch handed over last
+  u64 bprev = 0;   // DUAL = 2: ... and of the one before it (everything before the OLDEST batch in flight is resolved)
   u32 rpos = a0;   // window index of `pos`
   const u32 litmask = (!LINEAR && P.plane) ? 0u : 0xffu;  // mark plane: every octet this group produces itself is "known" = 0
   bool stores_in_flight = false;  // RING: a flush has been issued since the last wait (a far match reads what it stored)
@@ -3957,6 +3973,8 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
     stores_in_flight = true;
   };
   auto emit_batch = [&](u64 pend, u32 dofs, u32 len, u32 dist) {
+    bprev = bstart;
+    bstart = pos;
     if (!LINEAR && stores_in_flight) {  // (wave-uniform) what was flushed must have arrived before a resolve step reads it back
       tbz_vm_drain();
       stores_in_flight = false;
@@ -4088,7 +4106,6 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
         const bool hasm = (hav || hbv) && act;
         const u32 len = hav ? len_a : len_b;
         const u32 dist = ((hav ? b : na) & 0x7fffu) + 1;
-        bstart = pos;
         emit_batch(tbz_ballot(hasm), hav ? oa : ob, hasm ? len : 0u, dist);
         pos += total;
         rpos = ring<W>(rpos + total);
@@ -4107,10 +4124,8 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
           u32 w1 = tbz_readlane(w, 1), w2 = tbz_readlane(w, 2), w3 = tbz_readlane(w, 3), w0 = tbz_readlane(w, 0);
           u64 cnt = (w0 & 0x3fff) | ((u64)(w1 & 3) << 14);
           u64 src = ((u64)(w1 >> 2) & 0x1fff) | ((u64)w2 << 13) | ((u64)w3 << 28);
-          if (DUAL) {  // an empty batch: when its hand-over returns, the batch before it is resolved
-            emit_batch(0ull, 0u, 0u, 1u);
-            bstart = pos;
-          }
+          // an empty batch per batch in flight: when their hand-overs have returned, everything before is resolved
+          for (u32 e = 0; e < DUAL; e++) emit_batch(0ull, 0u, 0u, 1u);
           while (cnt) {
             u32 c = cnt < SPAN ? (u32)cnt : SPAN;  // (the ring holds its history + one span)
             tbz_sync();
@@ -4129,7 +4144,7 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
             rpos = ring<W>(rpos + c);
             src += c;
             cnt -= c;
-            bstart = pos;
+            bstart = bprev = pos;
             if (!LINEAR && (pos - flushed >= K2R_FLUSH || pos >= clip))
               flush_upto(pos >= clip ? pos : ((pos + a0) & ~15ull) - a0);
             if (pos >= clip) break;
@@ -4156,15 +4171,17 @@ TBZ_DEV void k2_body(const K2Params& P, u32 gi, const Group& g, const Seg& sg_gu
         u32 dofs = incl - len;  // octet offset of this token inside the batch
         u32 dist = (tbz_wave_shl1(w) & 0x7fffu) + 1;
         if (islit && (act & lane_bit)) win[ring<W>(rpos + dofs)] = (u8)(w & litmask);
-        bstart = pos;
         emit_batch(mb & act, dofs, len, dist);
         pos += total;
         rpos = ring<W>(rpos + total);
         p += m;
       }
       if (!LINEAR && pos - flushed >= K2R_FLUSH) {
-        const u64 lim = DUAL ? bstart : pos;
-        flush_upto(((lim + a0) & ~15ull) - a0);  // keep the unaligned tail in the ring
+        const u64 lim = DUAL == 2 ? bprev : DUAL ? bstart : pos;
+        const u64 al = (lim + a0) & ~15ull;  // keep the unaligned tail in the ring
+        // (al <= a0: nothing is final yet — a FIRST batch of K2R_FLUSH octets or more, which only a flush interval at or
+        // below the batch span allows; such a build flushed the whole group from an empty ring: found on config 5)
+        if (al > a0) flush_upto(al - a0);
       }
     }
   }
@@ -4409,6 +4426,72 @@ TBZ_KERNEL_WG(128, 5) void tbz_k2_lz77_ring2(K2Params P) {
       }
       tbz_wg_barrier();
       if (H[k & 1].end) break;
+    }
+  }
+}
+
+// The ring kernel on THREE wavefronts: front end -> far sources -> resolve, a batch moving one stage per workgroup
+// barrier.  What a batch copies from the flushed output (distances beyond the ring's history) or out of computed
+// pointers depends on nothing in flight, so the middle wave lands it in the ring while the batch before is still being
+// resolved: the memory round trip of the far round — a third of a batch's resolve time — leaves the critical path.  The
+// ring holds its history and THREE spans; the front end flushes up to the oldest batch in flight.  H[j % 3] = batch j.
+constexpr u32 K2R3_RW = K2R_HIST + 3 * K2R_SPAN + 64;
+static_assert(K2R3_RW % 16 == 0, "16-octet chunks must not straddle the ring's seam");
+using K2Ring3 = K2W<K2R3_RW, K2R_HIST>;
+TBZ_KERNEL_WG(192, 6) void tbz_k2_lz77_ring3(K2Params P) {
+  TBZ_SHARED __attribute__((aligned(16))) u8 win[K2R3_RW];
+  TBZ_SHARED __attribute__((aligned(16))) u8 idt[K2_IDT];
+  TBZ_SHARED __attribute__((aligned(16))) u16 tks[K2_TOKBUF];
+  TBZ_SHARED u32 rcache[128];
+  TBZ_SHARED K2Hand H[3];
+  u32 gi;
+  Group g;
+  Seg sg;
+  K2Params Q;
+  if (!k2_ring_select(P, Q, gi, g, sg)) return;  // all three waves take the same decision
+  const u32 lane = tbz_lane();
+  const u32 wv = tbz_wave();
+  k2_idt_init(idt, 192);
+  tbz_wg_barrier();
+  if (wv == 0) {
+    u32 k = 0;
+    k2_body<K2Ring3, K2R_SPAN, 2>(
+        Q, gi, g, sg, win, tks, rcache,
+        [&](u64 pend, u32 rpos, u64 gpos, u32 dofs, u32 len, u32 dist) {
+          K2Hand& h = H[k % 3];
+          h.desc[lane] = (u64)dofs | ((u64)len << 16) | ((u64)dist << 32);
+          if (lane == 0) {
+            h.pend = pend;
+            h.rpos = rpos;
+            h.gpos = gpos;
+            h.end = 0;
+          }
+          tbz_wg_barrier();
+          k += 1;
+        },
+        [&](u64, u32) {
+          if (lane == 0) H[k % 3].end = 1;
+          tbz_wg_barrier();  // the last batch has its far sources ...
+          tbz_wg_barrier();  // ... and is resolved: the final flush may read the window
+        });
+  } else {
+    K2Src S{win, idt, Q.out_base + (g.out_abs - Q.out_bias), Q.hist, Q.plane};
+    for (u32 k = 0;; k++) {
+      tbz_wg_barrier();  // batch k has been handed over
+      const bool end = H[k % 3].end != 0;
+      // wave 1: the far round of batch k; wave 2: the rest of batch k - 1
+      const u32 j = wv == 1 ? k : k - 1;
+      if ((wv == 1 && !end) || (wv == 2 && k > 0)) {
+        const K2Hand& h = H[j % 3];
+        const u64 d = h.desc[lane];
+        const u32 dofs = (u32)(d & 0xffffu), len = (u32)((d >> 16) & 0xffffu), dist = (u32)(d >> 32);
+        if (wv == 1) k2_resolve<K2Ring3, K2_FAR>(S, h.pend, h.rpos, h.gpos, dofs, len, dist);
+        else k2_resolve<K2Ring3, K2_NEAR>(S, h.pend, h.rpos, h.gpos, dofs, len, dist);
+      }
+      if (end) {
+        tbz_wg_barrier();
+        break;
+      }
     }
   }
 }

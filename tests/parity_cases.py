@@ -1410,6 +1410,9 @@ FLAVOUR_CASES = {
     # one wave per group in K2
     "k2single": ["case_flush_streams", "case_history_across_groups", "case_configs_1_3_5", "case_deep_codes",
                  "case_overflow_and_underrun"],
+    # the ring kernel on two waves instead of three (large groups, H-groups)
+    "k2ring2": ["case_noflush_streams", "case_history_across_groups", "case_configs_1_3_5", "case_containers_and_levels",
+                "case_overflow_and_underrun"],
 }
 # the cases whose behaviour depends on the K1 flavour (forced-flavour runs skip the rest: checksums, device
 # buffers and the replay protocol go through the same engine calls whatever decodes the Huffman codes)

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 
 
-@pytest.fixture(scope="module", params=["auto", "findalways", "hostlayout", "k2single", "gang8", "lane"])
+@pytest.fixture(scope="module", params=["auto", "findalways", "hostlayout", "k2single", "k2ring2", "gang8", "lane"])
 def eng(request):
     """the three K1 flavours (TBZ_K1_MODE is read when a context is created)"""
     subprocess.check_call(["make", "-C", EMU_DIR, "libtbz_emu.so"], stdout=subprocess.DEVNULL)
@@ -26,12 +26,15 @@ def eng(request):
         os.environ["TBZ_FIND"] = "always"
     elif request.param == "k2single":  # one wave per group in K2 (default: front end and resolve on two waves)
         os.environ["TBZ_K2_MODE"] = "single"
+    elif request.param == "k2ring2":  # the ring kernel on two waves (default: three — front end, far sources, resolve)
+        os.environ["TBZ_K2_RING"] = "2"
     elif request.param != "auto":
         os.environ["TBZ_K1_MODE"] = request.param
     e = T.Engine(0, lib_path=os.path.join(EMU_DIR, "libtbz_emu.so"))
     os.environ.pop("TBZ_K1_MODE", None)
     os.environ.pop("TBZ_HOST_LAYOUT", None)
     os.environ.pop("TBZ_K2_MODE", None)
+    os.environ.pop("TBZ_K2_RING", None)
     os.environ.pop("TBZ_FIND", None)
     yield e
     e.close()

@@ -5512,11 +5512,72 @@ TBZ_KERNEL_OCC(2) void tbz_small_fused(SmallParams P) {
     s_item = it;
   }
   tbz_sync();
-  // ---- not this kernel's streams: flush points (the general path decodes their segments side by side and counts them),
+  // ---- a stream that is nothing but stored blocks (deflate.lisp:532-573; incompressible data: config 1) needs neither
+  // tokens nor a window: this wave walks the headers and copies input to output as it goes.  Anything that is not a
+  // plain chain to a final block inside the buffers leaves the decision to the code below (which decodes from the
+  // start again: whatever this copied is overwritten).
+  bool chain = false;
+  if (P.format != 2) {
+    u64 at = 0;
+    bool ok = true;
+    if (P.format == 1) {  // the zlib header exactly as K1 accepts it (zlib.lisp:20-35), or not this path's stream
+      ok = P.in_len >= 2 && (P.in[0] & 15) == 8 && (P.in[0] >> 4) <= 7 && (P.in[1] & 0x20) == 0 &&
+           (((u32)P.in[0] << 8) | P.in[1]) % 31 == 0;
+      at = 2;
+    }
+    u64 o = 0;
+    bool fin = false;
+    while (ok && !fin) {
+      if (at + 5 > P.in_len) { ok = false; break; }
+      const u32 h = P.in[at];
+      const u32 len = P.in[at + 1] | ((u32)P.in[at + 2] << 8), nlen = P.in[at + 3] | ((u32)P.in[at + 4] << 8);
+      if (((h >> 1) & 3) != 0 || (len ^ nlen) != 0xffffu) { ok = false; break; }
+      if (len == 0 && !(h & 1)) { ok = false; break; }  // an empty stored block is a flush point: the general path counts it
+      if (at + 5 + len > P.in_len || o + len > P.out_cap || o + len > SMALL_MAX_OUT) { ok = false; break; }
+      fin = (h & 1) != 0;
+      const u8* in = P.in + at + 5;
+      u8* out = P.out + o;
+      u32 c = lane * 16;
+      for (; c + 3 * 1024 + 16 <= len; c += 4096) {  // sixteen octets per lane, four loads in flight (eight: no faster)
+        const K2U128 v0 = *(const K2U128*)(in + c), v1 = *(const K2U128*)(in + c + 1024);
+        const K2U128 v2 = *(const K2U128*)(in + c + 2048), v3 = *(const K2U128*)(in + c + 3072);
+        *(K2U128*)(out + c) = v0;
+        *(K2U128*)(out + c + 1024) = v1;
+        *(K2U128*)(out + c + 2048) = v2;
+        *(K2U128*)(out + c + 3072) = v3;
+      }
+      for (; c < len; c += 1024) {
+        if (c + 16 <= len) {
+          *(K2U128*)(out + c) = *(const K2U128*)(in + c);
+        } else {
+          for (u32 k = c; k < len; k++) out[k] = in[k];
+        }
+      }
+      at += 5 + len;
+      o += len;
+    }
+    if (ok && P.format == 1 && at + 4 > P.in_len) ok = false;  // (a cut trailer: the general path says how much is missing)
+    if (ok) {
+      chain = true;
+      if (lane == 0) {
+        SegResult r{};
+        r.status = SEG_FINAL;
+        r.out_bytes = o;
+        r.trailer_have = 2;
+        if (P.format == 1) {
+          r.trailer0 = ((u32)P.in[at] << 24) | ((u32)P.in[at + 1] << 16) | ((u32)P.in[at + 2] << 8) | P.in[at + 3];
+          at += 4;
+        }
+        r.end_bit = at * 8;
+        s_res = r;
+      }
+    }
+  }
+  // ---- (anything but a stored chain, whose octets cannot hold a flush point that counts) not this kernel's streams: flush points (the general path decodes their segments side by side and counts them),
   // and streams long enough for the block-start finder unless they begin with a stored block (raw deflate and zlib: the
   // first block header sits at a known place; a gzip header is parsed by K1, so a long gzip stream goes the general way)
-  if (small_has_marker(P.in, P.in_len)) return leave(SMALL_FALLBACK, 0, 1);
-  if (P.in_len >= P.find_min) {
+  if (!chain && small_has_marker(P.in, P.in_len)) return leave(SMALL_FALLBACK, 0, 1);
+  if (!chain && P.in_len >= P.find_min) {
     bool stored = false;
     if (P.format != 2) {
       const u64 hb = P.format == 1 ? 2 : 0;
@@ -5525,7 +5586,7 @@ TBZ_KERNEL_OCC(2) void tbz_small_fused(SmallParams P) {
     if (!stored) return leave(SMALL_FALLBACK, 0, 2);
   }
   // ---- K1: the whole stream is one item for a gang of 64
-  {
+  if (!chain) {
     K1gParams kp{};
     kp.in_base = P.in;
     kp.tok = P.tok;

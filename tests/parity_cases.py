@@ -1135,6 +1135,38 @@ def case_stream_contexts(eng, n=50_000):
         pass
 
 
+def case_long_stored_runs(eng, sizes=(14_337, 65_535, 100_001)):
+    """Stored blocks long enough to leave the ring kernels' window behind (their head goes straight from the input to
+    the output: k2_body), FOLLOWED by compressed data that copies out of them — near the run's end, far back in it, and
+    across its seams — in the three containers, with buffers that end inside the run, right behind it and inside the
+    data after it.  deflate.lisp:532-573 (:uncompressed-block / copy-block), :343-352 (copy-history)."""
+    rng = random.Random(0x570)
+    for n in sizes:
+        raw = bytes(rng.getrandbits(8) for _ in range(n))
+        tail = raw[-3000:] * 3 + b"abcabcabc" * 300 + raw[-30_000:-100] + raw[:2000]
+        plain = raw + tail
+        for fmt, wbits in (("deflate", -15), ("zlib", 15), ("gzip", 31)):
+            c = zlib.compressobj(0, zlib.DEFLATED, wbits)
+            head = c.compress(raw) + c.flush(zlib.Z_SYNC_FLUSH if n & 1 else zlib.Z_FULL_FLUSH)
+            body = zlib.compressobj(6, zlib.DEFLATED, -15, zdict=raw[-32768:])
+            s = head + body.compress(tail) + body.flush()
+            if fmt == "zlib":
+                s += struct.pack(">I", zlib.adler32(plain))
+            elif fmt == "gzip":
+                s += struct.pack("<II", zlib.crc32(plain), len(plain) & 0xffffffff)
+            for cap in (len(plain) + 8, len(plain), len(plain) - 1, n + 5, n, n - 7, 1000):
+                r = assert_same(eng, s, fmt, cap, what="stored run of %d, %s, cap %d" % (n, fmt, cap))
+                if cap >= len(plain):
+                    assert r["flag"] == "finished" and r["bytes"] == plain, (n, fmt, cap, r["flag"])
+        # a stored run that ENDS its stream (nothing is kept in the ring), and one cut short by the input's end
+        for fmt, wbits in (("deflate", -15), ("zlib", 15)):
+            c = zlib.compressobj(0, zlib.DEFLATED, wbits)
+            s = c.compress(raw) + c.flush()
+            assert assert_same(eng, s, fmt, n, what="stored only %d %s" % (n, fmt))["bytes"] == raw
+            assert_same(eng, s, fmt, n, end=len(s) - 2000, what="stored only, cut %d %s" % (n, fmt))
+            assert_same(eng, s, fmt, n - 4000, what="stored only, short buffer %d %s" % (n, fmt))
+
+
 def case_pointer_contexts(eng, n=60_000):
     """with-octet-pointer / make-octet-pointer-context (io-mmap.lisp:26-54): the same calls over foreign memory —
     a host pointer (tbz_inflate reads it in place) and a device pointer (tbz_inflate_device, no staging) — must give
@@ -1242,6 +1274,12 @@ def small_fused(eng_factory):
         check(fs, "zlib", len(fp), "flush points: the general path's stream")
         s3, p3 = _fixed_chain(3, 60, 20)
         check(s3, "deflate", len(p3) + 10, "chain of fixed blocks")
+        pm = b"ab" * 100 + b"\x00\x00\xff\xff" + b"cd" * 100   # (a stored chain is copied before anything looks for markers)
+        for fmt, blob in (("zlib", zlib.compress(pm, 0)), ("deflate", zlib.compress(pm, 0)[2:-4])):
+            check(blob, fmt, len(pm), "stored data that holds a marker's octets, " + fmt)
+        c = zlib.compressobj(0)
+        sf = c.compress(pm) + c.flush(zlib.Z_SYNC_FLUSH) + c.compress(pm) + c.flush()
+        check(sf, "zlib", 2 * len(pm), "stored blocks around a flush point")
         assert took > 100, took   # (the clean cases did go through the one launch)
     finally:
         e.close()
@@ -1397,7 +1435,7 @@ ALL_CASES = [case_known_answer_vectors, case_test_deflated, case_reference_chunk
              case_noflush_streams, case_block_starts_found, case_close_block_starts, case_fixed_block_chains, case_history_across_groups,
              case_configs_1_3_5, case_overflow_and_underrun, case_errors, case_false_markers, case_device_buffers,
              case_checksum_kernels, case_deep_codes, case_chunked_resume, case_gzip_members,
-             case_pointer_contexts, case_stream_contexts, case_container_headers, case_gzip_metadata, case_scratch_bounds, case_token_density, case_fuzz]
+             case_long_stored_runs, case_pointer_contexts, case_stream_contexts, case_container_headers, case_gzip_metadata, case_scratch_bounds, case_token_density, case_fuzz]
 # what each engine flavour of the test modules runs.  "auto" runs everything; the others run the cases that can
 # tell them apart (the CPU suite has to stay within minutes: a case costs seconds on the lane emulator)
 FLAVOUR_CASES = {
@@ -1409,10 +1447,10 @@ FLAVOUR_CASES = {
                    "case_false_markers", "case_device_buffers", "case_errors", "case_fuzz"],
     # one wave per group in K2
     "k2single": ["case_flush_streams", "case_history_across_groups", "case_configs_1_3_5", "case_deep_codes",
-                 "case_overflow_and_underrun"],
+                 "case_overflow_and_underrun", "case_long_stored_runs"],
     # the ring kernel on two waves instead of three (large groups, H-groups)
     "k2ring2": ["case_noflush_streams", "case_history_across_groups", "case_configs_1_3_5", "case_containers_and_levels",
-                "case_overflow_and_underrun"],
+                "case_overflow_and_underrun", "case_long_stored_runs"],
 }
 # the cases whose behaviour depends on the K1 flavour (forced-flavour runs skip the rest: checksums, device
 # buffers and the replay protocol go through the same engine calls whatever decodes the Huffman codes)

@@ -3520,10 +3520,20 @@ TBZ_K1G_KERNEL(64, 4)
 // 6.4 ms for two passes at ten per CU: profiles/README.md.)
 // ================================================================================================
 constexpr u32 ADLER_P = 65521;
-constexpr u32 K2_SPAN = 3072;    // (one-wave ring kernel) most octets one batch may produce
-constexpr u32 K2R_SPAN = 1536;   // ring kernels on two waves: most octets one batch may produce (two batches are in flight)
-constexpr u32 K2R_HIST = 8192;   // ring kernels: a match up to this distance copies inside the ring, a longer one from the output
-constexpr u32 K2R_FLUSH = 2048;  // ring kernels: flush every this many octets (what a far match reads must have left the ring:
+#ifndef TBZ_EXP_K2R_SPAN  // (experiments: hipcc -DTBZ_EXP_K2R_SPAN=768 -DTBZ_EXP_K2R_HIST=4096 -DTBZ_EXP_K2R_FLUSH=1024 ...)
+#define TBZ_EXP_K2R_SPAN 1536
+#endif
+#ifndef TBZ_EXP_K2R_HIST
+#define TBZ_EXP_K2R_HIST 8192
+#endif
+#ifndef TBZ_EXP_K2R_FLUSH
+#define TBZ_EXP_K2R_FLUSH 2048
+#endif
+constexpr u32 K2L_SPAN = 3072;   // linear windows: most octets of a stored run copied between two flush checks
+constexpr u32 K2R_SPAN = TBZ_EXP_K2R_SPAN;   // ring kernels on two / three waves: most octets one batch may produce (batches are in flight)
+constexpr u32 K2_SPAN = 2 * K2R_SPAN;        // (one-wave ring kernel) most octets one batch may produce
+constexpr u32 K2R_HIST = TBZ_EXP_K2R_HIST;   // ring kernels: a match up to this distance copies inside the ring, a longer one from the output
+constexpr u32 K2R_FLUSH = TBZ_EXP_K2R_FLUSH; // ring kernels: flush every this many octets (what a far match reads must have left the ring:
                                  // K2R_HIST >= K2R_FLUSH + K2_SPAN + 258 + 16)
 constexpr u32 K2_SHORT = 32;     // matches up to this length are copied by their own lane
 constexpr u32 K2_TCH = 512;      // token words per staged chunk: one 16-octet load per lane
@@ -4242,7 +4252,7 @@ TBZ_KERNEL void tbz_k2_lz77_small(K2Params P) {
   if (!k2_pick_group(P, gi, g, sg)) return;
   u8* win = dyn;
   K2Src S{win, nullptr, nullptr, 0, 0};
-  k2_body<K2Linear, K2_SPAN, false>(
+  k2_body<K2Linear, K2L_SPAN, false>(
       P, gi, g, sg, win, (u16*)(dyn + P.win_bytes), (u32*)(dyn + P.win_bytes + 2 * K2_TOKBUF),
       [&](u64 pend, u32 rpos, u64 gpos, u32 dofs, u32 len, u32 dist) { k2_resolve<K2Linear>(S, pend, rpos, gpos, dofs, len, dist); },
       [](u64, u32) {});
@@ -4274,7 +4284,7 @@ TBZ_KERNEL_WG(128, 2) void tbz_k2_lz77_dual(K2Params P) {
   [[maybe_unused]] u64 tr_wait = 0, tr_x = 0;
   if (tbz_wave() == 0) {
     u32 k = 0;
-    k2_body<K2Linear, K2_SPAN, false>(
+    k2_body<K2Linear, K2L_SPAN, false>(
         P, gi, g, sg, win, (u16*)(dyn + P.win_bytes), (u32*)(dyn + P.win_bytes + 2 * K2_TOKBUF),
         [&](u64 pend, u32 rpos, u64 gpos, u32 dofs, u32 len, u32 dist) {
           K2Hand& h = H[k & 1];

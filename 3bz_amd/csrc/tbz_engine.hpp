@@ -659,6 +659,167 @@ static int small_fused_try(tbz_ctx* ctx, int format, const void* d_in, uint64_t 
   return 0;
 }
 
+// An H-group is a group decoded in parallel with the groups before it: its matches may reach into output
+// that does not exist yet.  hgs = the H-groups of the call in output order; the launch list holds n_small groups for the
+// linear kernels (launched by the caller), then n_big plain large groups, then the n_h H-groups.
+struct HGroupSpan { uint64_t start, end, floor; uint32_t stream; };
+// The ring launch for the plain large groups and BOTH planes of the H-groups (octets -> the output, pointer high octets ->
+// the mark plane over [mark_lo, mark_hi) of it), then K6: the work lists (blocks and superblocks of consecutive H-groups),
+// the chains over the groups' tails, and the parallel resolve of everything else.  Events 10 / 11 bracket K6.
+static int hgroups_launch(tbz_ctx* ctx, const std::vector<HGroupSpan>& hgs, K2Params k2, size_t n_small, size_t n_big,
+                          size_t n_h, void* d_out, uint64_t mark_lo, uint64_t mark_hi) {
+  int r;
+  // ---- K6 work lists (see tbz_kernels.hpp): blocks = runs of consecutive H-groups of one stream, at most `bmax` long
+  size_t max_per_stream = 0;
+  for (size_t i = 0, j; i < hgs.size(); i = j) {
+    for (j = i; j < hgs.size() && hgs[j].stream == hgs[i].stream; j++) {}
+    max_per_stream = std::max(max_per_stream, j - i);
+  }
+  // three levels: groups -> blocks of at most bmax groups -> superblocks of at most bmax blocks, bmax = N^(1/3): the
+  // dependent chain is 3 * bmax steps (two levels: 2 * sqrt(N))
+  size_t bmax = 1;
+  while (bmax * bmax * bmax < max_per_stream) bmax++;
+  if (ctx->tun.k6_block) bmax = std::max(1, ctx->tun.k6_block);
+  const bool three = !ctx->tun.k6_two_levels;
+  if (!three) {
+    bmax = 1;
+    while (bmax * bmax < max_per_stream) bmax++;
+    if (ctx->tun.k6_block) bmax = std::max(1, ctx->tun.k6_block);
+  }
+  std::vector<K6Range> ranges;
+  std::vector<K6List> lists;
+  // section 1: tails of the groups of multi-group blocks (tbz_k6_chain_sym, relative to the block afterwards);
+  // section 1b: the last 32 KiB of the blocks of multi-block superblocks (tbz_k6_chain_sym again, relative to the
+  // superblock afterwards); section 2: one range per superblock, one list per stream (tbz_k6_chain: final);
+  // sections 3s / 3a / 3b: tbz_k6_resolve, in this order (what each refers to is final by then)
+  std::vector<K6Range> r1, r1b, r2, r3s, r3a, r3b;
+  std::vector<K6List> l1, l1b, l2;
+  struct Blk { size_t j, e; uint64_t B0, E, last_lo, fl; };
+  for (size_t i = 0, jj; i < hgs.size(); i = jj) {
+    // ---- this stream's blocks
+    std::vector<Blk> blks;
+    for (jj = i; jj < hgs.size() && hgs[jj].stream == hgs[i].stream;) {
+      size_t e = jj + 1;  // block [jj, e)
+      while (e < hgs.size() && e - jj < bmax && hgs[e].stream == hgs[jj].stream && hgs[e].start == hgs[e - 1].end) e++;
+      const uint64_t B0 = hgs[jj].start, E = hgs[e - 1].end, fl = hgs[jj].floor;
+      const uint64_t last_lo = E - B0 > K6_W ? E - K6_W : B0;
+      blks.push_back(Blk{jj, e, B0, E, last_lo, fl});
+      if (e - jj > 1) {
+        l1.push_back(K6List{(u32)r1.size(), (u32)(e - jj)});
+        for (size_t k = jj; k < e; k++) {
+          const uint64_t t_lo = hgs[k].end - hgs[k].start > K6_W ? hgs[k].end - K6_W : hgs[k].start;
+          r1.push_back(K6Range{hgs[k].start, t_lo, hgs[k].end, fl});
+          if (t_lo < std::min(hgs[k].end, last_lo)) r3a.push_back(K6Range{B0, t_lo, std::min(hgs[k].end, last_lo), fl});
+        }
+      }
+      for (size_t k = jj; k < e; k++)  // a group's octets before its tail, in sub-ranges of at most 64 KiB
+        if (hgs[k].end - hgs[k].start > K6_W)
+          for (uint64_t x = hgs[k].start; x < hgs[k].end - K6_W; x += 65536)
+            r3b.push_back(K6Range{hgs[k].start, x, std::min(x + 65536, hgs[k].end - K6_W), fl});
+      jj = e;
+    }
+    // ---- its superblocks: runs of adjacent blocks
+    // (a superblock that begins 32 KiB or more after the one before it ended sees nothing of it: everything in
+    // between came out of groups that needed no history and is final in memory — such superblocks open a list of
+    // their own, i.e. a workgroup of their own: config 5f alternates H-groups and plain ones, and ONE workgroup
+    // walked its thousand superblocks for 2.4 ms)
+    K6List ls{(u32)r2.size(), 0};
+    uint64_t prev_SE = 0;
+    for (size_t q = 0, qe; q < blks.size(); q = qe) {
+      qe = q + 1;
+      while (three && qe < blks.size() && qe - q < bmax && blks[qe].B0 == blks[qe - 1].E) qe++;
+      const uint64_t S0 = blks[q].B0, SE = blks[qe - 1].E, fl = blks[q].fl;
+      if (ls.count && S0 - prev_SE >= K6_W) {
+        l2.push_back(ls);
+        ls = K6List{(u32)r2.size(), 0};
+      }
+      prev_SE = SE;
+      const uint64_t s_last_lo = SE - S0 > K6_W ? SE - K6_W : S0;
+      if (qe - q > 1) {
+        l1b.push_back(K6List{(u32)r1b.size(), (u32)(qe - q)});
+        for (size_t k = q; k < qe; k++) {
+          r1b.push_back(K6Range{blks[k].B0, blks[k].last_lo, blks[k].E, fl});
+          if (blks[k].last_lo < std::min(blks[k].E, s_last_lo)) r3s.push_back(K6Range{S0, blks[k].last_lo, std::min(blks[k].E, s_last_lo), fl});
+        }
+      }
+      r2.push_back(K6Range{S0, s_last_lo, SE, fl});
+      ls.count++;
+    }
+    l2.push_back(ls);
+  }
+  const size_t o1b = r1.size(), o2 = o1b + r1b.size(), o3s = o2 + r2.size(), o3a = o3s + r3s.size(), o3b = o3a + r3a.size();
+  for (auto& l : l1b) l.first += (u32)o1b;
+  for (auto& l : l2) l.first += (u32)o2;
+  ranges = r1;
+  ranges.insert(ranges.end(), r1b.begin(), r1b.end());
+  ranges.insert(ranges.end(), r2.begin(), r2.end());
+  ranges.insert(ranges.end(), r3s.begin(), r3s.end());
+  ranges.insert(ranges.end(), r3a.begin(), r3a.end());
+  ranges.insert(ranges.end(), r3b.begin(), r3b.end());
+  lists = l1;
+  lists.insert(lists.end(), l1b.begin(), l1b.end());
+  lists.insert(lists.end(), l2.begin(), l2.end());
+  // the mark plane covers [mark_lo, mark_hi) of the output, at the same alignment (mod 16) as the output itself
+  const uint32_t m0 = (uint32_t)(((uintptr_t)d_out + mark_lo) & 15);
+  if ((r = ensure(ctx, ctx->d_mark, (mark_hi - mark_lo) + 64))) return r;
+  if ((r = upload(ctx, ctx->d_hg, ranges))) return r;
+  if ((r = upload(ctx, ctx->d_k6s, lists))) return r;
+  // ONE launch of the ring kernel: the plain large groups, and both planes of every H-group (octets -> out, pointer
+  // high octets -> the mark plane) as neighbouring workgroups, which read the same tokens
+  k2.order = (const u32*)ctx->d_order.p + n_small;
+  k2.n_groups = (u32)(n_big + n_h);
+  k2.win_bytes = 0;
+  k2.mixed = 1;
+  k2.n_plain = (u32)n_big;
+  k2.mark_base = (u8*)ctx->d_mark.p + m0;
+  k2.mark_bias = mark_lo;
+  ctx->tim.k2_kinds |= 4u | 8u;
+  ctx->tim.n_hgroups = n_h;
+  {
+    const size_t nwg = n_big + 2 * n_h;
+    if (ctx->k2_single) TBZ_LAUNCH(tbz_k2_lz77, nwg, ctx->stream, k2);
+    else if (ctx->k2_ring2) TBZ_LAUNCH_WG(tbz_k2_lz77_ring2, nwg, 128, ctx->stream, k2);
+    else TBZ_LAUNCH_WG(tbz_k2_lz77_ring3, nwg, 192, ctx->stream, k2);
+  }
+  TBZ_HIP(hipEventRecord(ctx->ev[10], ctx->stream));
+  const K6Range* dr = (const K6Range*)ctx->d_hg.p;
+  const K6List* dl = (const K6List*)ctx->d_k6s.p;
+  K6Params k6{(u8*)d_out, (u8*)ctx->d_mark.p + m0, mark_lo, dr, dl, (u32)ranges.size(), 0, 0};
+  if (!l1.empty()) {
+    k6.n_lists = (u32)l1.size();
+    TBZ_LAUNCH_WG(tbz_k6_chain_sym, l1.size(), K6_THREADS, ctx->stream, k6);
+  }
+  if (!l1b.empty()) {
+    k6.lists = dl + l1.size();
+    k6.n_lists = (u32)l1b.size();
+    TBZ_LAUNCH_WG(tbz_k6_chain_sym, l1b.size(), K6_THREADS, ctx->stream, k6);
+  }
+  k6.lists = dl + l1.size() + l1b.size();
+  k6.n_lists = (u32)l2.size();
+  TBZ_LAUNCH_WG(tbz_k6_chain, l2.size(), K6_THREADS, ctx->stream, k6);
+  auto resolve = [&](size_t first, const std::vector<K6Range>& rs, uint64_t maxlen) {
+    const size_t count = rs.size();
+    if (!count) return;
+    K6Params q = k6;
+    q.ranges = dr + first;
+    q.n_ranges = (u32)count;
+    uint64_t total = 0;
+    for (const K6Range& g : rs) total += g.hi > g.lo ? g.hi - g.lo : 0;
+    if (total / count >= (uint64_t)ctx->tun.k6_lds_min) {  // long ranges: the pointers' 32 KiB staged in LDS (1 GiB no-flush stream: K6 1.89 -> 1.44 ms)
+      q.pieces = (u32)((maxlen + 15 + K6R_PIECE - 1) / K6R_PIECE);
+      TBZ_LAUNCH_WG(tbz_k6_resolve_lds, count * (size_t)q.pieces, K6R_THREADS, ctx->stream, q);
+    } else {
+      q.pieces = (u32)((maxlen + 15 + K6_PIECE - 1) / K6_PIECE);
+      TBZ_LAUNCH(tbz_k6_resolve, count * (size_t)q.pieces, ctx->stream, q);
+    }
+  };
+  resolve(o3s, r3s, K6_W);
+  resolve(o3a, r3a, K6_W);
+  resolve(o3b, r3b, 65536);
+  TBZ_HIP(hipEventRecord(ctx->ev[11], ctx->stream));
+  return 0;
+}
+
 // the whole pipeline on device-resident buffers
 static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, const uint64_t* in_offs,
                         const uint64_t* in_lens, void* d_out, const uint64_t* out_offs, const uint64_t* out_caps,
@@ -1838,8 +1999,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
     // run with dynamic LDS sized to the largest of them; the rest take the 32 KiB-history ring kernel;
     // H-groups take the ring kernel twice (octet plane, pointer plane) and K6 afterwards
     std::vector<uint32_t> order_small, order_big, order_h;
-    struct HG { uint64_t start, end, floor; uint32_t stream; };
-    std::vector<HG> hgs;
+    std::vector<HGroupSpan> hgs;
     uint64_t max_small = 0, mark_lo = ~0ull, mark_hi = 0;
     for (size_t gi = 0; gi < h_groups.size(); gi++) {
       uint64_t tot = 0;
@@ -1852,7 +2012,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
       if (h_hist[gi]) {
         const StreamPlan& S = sp[h_gstream[gi]];
         order_h.push_back((uint32_t)gi);
-        hgs.push_back(HG{h_groups[gi].out_abs, std::max(h_groups[gi].out_abs, std::min(h_groups[gi].out_abs + tot, h_groups[gi].out_end)),
+        hgs.push_back(HGroupSpan{h_groups[gi].out_abs, std::max(h_groups[gi].out_abs, std::min(h_groups[gi].out_abs + tot, h_groups[gi].out_end)),
                          S.out_off - (h_gstream[gi] == 0 ? hist_len : 0), h_gstream[gi]});
         mark_lo = std::min(mark_lo, S.out_off);
         mark_hi = std::max(mark_hi, h_groups[gi].out_end);
@@ -1902,154 +2062,7 @@ static int inflate_core(tbz_ctx* ctx, int format, size_t n, const void* d_in, co
         else TBZ_LAUNCH_WG(tbz_k2_lz77_ring3, order_big.size(), 192, ctx->stream, k2);
     }
     if (!order_h.empty()) {
-      // ---- K6 work lists (see tbz_kernels.hpp): blocks = runs of consecutive H-groups of one stream, at most `bmax` long
-      size_t max_per_stream = 0;
-      for (size_t i = 0, j; i < hgs.size(); i = j) {
-        for (j = i; j < hgs.size() && hgs[j].stream == hgs[i].stream; j++) {}
-        max_per_stream = std::max(max_per_stream, j - i);
-      }
-      // three levels: groups -> blocks of at most bmax groups -> superblocks of at most bmax blocks, bmax = N^(1/3): the
-      // dependent chain is 3 * bmax steps (two levels: 2 * sqrt(N))
-      size_t bmax = 1;
-      while (bmax * bmax * bmax < max_per_stream) bmax++;
-      if (ctx->tun.k6_block) bmax = std::max(1, ctx->tun.k6_block);
-      const bool three = !ctx->tun.k6_two_levels;
-      if (!three) {
-        bmax = 1;
-        while (bmax * bmax < max_per_stream) bmax++;
-        if (ctx->tun.k6_block) bmax = std::max(1, ctx->tun.k6_block);
-      }
-      std::vector<K6Range> ranges;
-      std::vector<K6List> lists;
-      // section 1: tails of the groups of multi-group blocks (tbz_k6_chain_sym, relative to the block afterwards);
-      // section 1b: the last 32 KiB of the blocks of multi-block superblocks (tbz_k6_chain_sym again, relative to the
-      // superblock afterwards); section 2: one range per superblock, one list per stream (tbz_k6_chain: final);
-      // sections 3s / 3a / 3b: tbz_k6_resolve, in this order (what each refers to is final by then)
-      std::vector<K6Range> r1, r1b, r2, r3s, r3a, r3b;
-      std::vector<K6List> l1, l1b, l2;
-      struct Blk { size_t j, e; uint64_t B0, E, last_lo, fl; };
-      for (size_t i = 0, jj; i < hgs.size(); i = jj) {
-        // ---- this stream's blocks
-        std::vector<Blk> blks;
-        for (jj = i; jj < hgs.size() && hgs[jj].stream == hgs[i].stream;) {
-          size_t e = jj + 1;  // block [jj, e)
-          while (e < hgs.size() && e - jj < bmax && hgs[e].stream == hgs[jj].stream && hgs[e].start == hgs[e - 1].end) e++;
-          const uint64_t B0 = hgs[jj].start, E = hgs[e - 1].end, fl = hgs[jj].floor;
-          const uint64_t last_lo = E - B0 > K6_W ? E - K6_W : B0;
-          blks.push_back(Blk{jj, e, B0, E, last_lo, fl});
-          if (e - jj > 1) {
-            l1.push_back(K6List{(u32)r1.size(), (u32)(e - jj)});
-            for (size_t k = jj; k < e; k++) {
-              const uint64_t t_lo = hgs[k].end - hgs[k].start > K6_W ? hgs[k].end - K6_W : hgs[k].start;
-              r1.push_back(K6Range{hgs[k].start, t_lo, hgs[k].end, fl});
-              if (t_lo < std::min(hgs[k].end, last_lo)) r3a.push_back(K6Range{B0, t_lo, std::min(hgs[k].end, last_lo), fl});
-            }
-          }
-          for (size_t k = jj; k < e; k++)  // a group's octets before its tail, in sub-ranges of at most 64 KiB
-            if (hgs[k].end - hgs[k].start > K6_W)
-              for (uint64_t x = hgs[k].start; x < hgs[k].end - K6_W; x += 65536)
-                r3b.push_back(K6Range{hgs[k].start, x, std::min(x + 65536, hgs[k].end - K6_W), fl});
-          jj = e;
-        }
-        // ---- its superblocks: runs of adjacent blocks
-        // (a superblock that begins 32 KiB or more after the one before it ended sees nothing of it: everything in
-        // between came out of groups that needed no history and is final in memory — such superblocks open a list of
-        // their own, i.e. a workgroup of their own: config 5f alternates H-groups and plain ones, and ONE workgroup
-        // walked its thousand superblocks for 2.4 ms)
-        K6List ls{(u32)r2.size(), 0};
-        uint64_t prev_SE = 0;
-        for (size_t q = 0, qe; q < blks.size(); q = qe) {
-          qe = q + 1;
-          while (three && qe < blks.size() && qe - q < bmax && blks[qe].B0 == blks[qe - 1].E) qe++;
-          const uint64_t S0 = blks[q].B0, SE = blks[qe - 1].E, fl = blks[q].fl;
-          if (ls.count && S0 - prev_SE >= K6_W) {
-            l2.push_back(ls);
-            ls = K6List{(u32)r2.size(), 0};
-          }
-          prev_SE = SE;
-          const uint64_t s_last_lo = SE - S0 > K6_W ? SE - K6_W : S0;
-          if (qe - q > 1) {
-            l1b.push_back(K6List{(u32)r1b.size(), (u32)(qe - q)});
-            for (size_t k = q; k < qe; k++) {
-              r1b.push_back(K6Range{blks[k].B0, blks[k].last_lo, blks[k].E, fl});
-              if (blks[k].last_lo < std::min(blks[k].E, s_last_lo)) r3s.push_back(K6Range{S0, blks[k].last_lo, std::min(blks[k].E, s_last_lo), fl});
-            }
-          }
-          r2.push_back(K6Range{S0, s_last_lo, SE, fl});
-          ls.count++;
-        }
-        l2.push_back(ls);
-      }
-      const size_t o1b = r1.size(), o2 = o1b + r1b.size(), o3s = o2 + r2.size(), o3a = o3s + r3s.size(), o3b = o3a + r3a.size();
-      for (auto& l : l1b) l.first += (u32)o1b;
-      for (auto& l : l2) l.first += (u32)o2;
-      ranges = r1;
-      ranges.insert(ranges.end(), r1b.begin(), r1b.end());
-      ranges.insert(ranges.end(), r2.begin(), r2.end());
-      ranges.insert(ranges.end(), r3s.begin(), r3s.end());
-      ranges.insert(ranges.end(), r3a.begin(), r3a.end());
-      ranges.insert(ranges.end(), r3b.begin(), r3b.end());
-      lists = l1;
-      lists.insert(lists.end(), l1b.begin(), l1b.end());
-      lists.insert(lists.end(), l2.begin(), l2.end());
-      // the mark plane covers [mark_lo, mark_hi) of the output, at the same alignment (mod 16) as the output itself
-      const uint32_t m0 = (uint32_t)(((uintptr_t)d_out + mark_lo) & 15);
-      if ((r = ensure(ctx, ctx->d_mark, (mark_hi - mark_lo) + 64))) return r;
-      if ((r = upload(ctx, ctx->d_hg, ranges))) return r;
-      if ((r = upload(ctx, ctx->d_k6s, lists))) return r;
-      // ONE launch of the ring kernel: the plain large groups, and both planes of every H-group (octets -> out, pointer
-      // high octets -> the mark plane) as neighbouring workgroups, which read the same tokens
-      k2.order = (const u32*)ctx->d_order.p + order_small.size();
-      k2.n_groups = (u32)(order_big.size() + order_h.size());
-      k2.win_bytes = 0;
-      k2.mixed = 1;
-      k2.n_plain = (u32)order_big.size();
-      k2.mark_base = (u8*)ctx->d_mark.p + m0;
-      k2.mark_bias = mark_lo;
-      ctx->tim.k2_kinds |= 4u | 8u;
-      ctx->tim.n_hgroups = order_h.size();
-      {
-        const size_t nwg = order_big.size() + 2 * order_h.size();
-        if (ctx->k2_single) TBZ_LAUNCH(tbz_k2_lz77, nwg, ctx->stream, k2);
-        else if (ctx->k2_ring2) TBZ_LAUNCH_WG(tbz_k2_lz77_ring2, nwg, 128, ctx->stream, k2);
-        else TBZ_LAUNCH_WG(tbz_k2_lz77_ring3, nwg, 192, ctx->stream, k2);
-      }
-      TBZ_HIP(hipEventRecord(ctx->ev[10], ctx->stream));
-      const K6Range* dr = (const K6Range*)ctx->d_hg.p;
-      const K6List* dl = (const K6List*)ctx->d_k6s.p;
-      K6Params k6{(u8*)d_out, (u8*)ctx->d_mark.p + m0, mark_lo, dr, dl, (u32)ranges.size(), 0, 0};
-      if (!l1.empty()) {
-        k6.n_lists = (u32)l1.size();
-        TBZ_LAUNCH_WG(tbz_k6_chain_sym, l1.size(), K6_THREADS, ctx->stream, k6);
-      }
-      if (!l1b.empty()) {
-        k6.lists = dl + l1.size();
-        k6.n_lists = (u32)l1b.size();
-        TBZ_LAUNCH_WG(tbz_k6_chain_sym, l1b.size(), K6_THREADS, ctx->stream, k6);
-      }
-      k6.lists = dl + l1.size() + l1b.size();
-      k6.n_lists = (u32)l2.size();
-      TBZ_LAUNCH_WG(tbz_k6_chain, l2.size(), K6_THREADS, ctx->stream, k6);
-      auto resolve = [&](size_t first, const std::vector<K6Range>& rs, uint64_t maxlen) {
-        const size_t count = rs.size();
-        if (!count) return;
-        K6Params q = k6;
-        q.ranges = dr + first;
-        q.n_ranges = (u32)count;
-        uint64_t total = 0;
-        for (const K6Range& g : rs) total += g.hi > g.lo ? g.hi - g.lo : 0;
-        if (total / count >= (uint64_t)ctx->tun.k6_lds_min) {  // long ranges: the pointers' 32 KiB staged in LDS (1 GiB no-flush stream: K6 1.89 -> 1.44 ms)
-          q.pieces = (u32)((maxlen + 15 + K6R_PIECE - 1) / K6R_PIECE);
-          TBZ_LAUNCH_WG(tbz_k6_resolve_lds, count * (size_t)q.pieces, K6R_THREADS, ctx->stream, q);
-        } else {
-          q.pieces = (u32)((maxlen + 15 + K6_PIECE - 1) / K6_PIECE);
-          TBZ_LAUNCH(tbz_k6_resolve, count * (size_t)q.pieces, ctx->stream, q);
-        }
-      };
-      resolve(o3s, r3s, K6_W);
-      resolve(o3a, r3a, K6_W);
-      resolve(o3b, r3b, 65536);
-      TBZ_HIP(hipEventRecord(ctx->ev[11], ctx->stream));
+      if ((r = hgroups_launch(ctx, hgs, k2, order_small.size(), order_big.size(), order_h.size(), d_out, mark_lo, mark_hi))) return r;
       have_resolve = true;
     }
     TBZ_HIP(hipGetLastError());

@@ -1272,6 +1272,9 @@ def small_fused(eng_factory):
             empty = {"zlib": zlib.compress(b"", 6), "gzip": pygzip.compress(b"", 6, mtime=0), "deflate": zlib.compress(b"", 6)[2:-4]}[fmt]
             check(empty, fmt, 0, "empty " + fmt)
             check(empty, fmt, 10, "empty, roomy " + fmt)
+            e0s = {"zlib": zlib.compress(b"", 0), "gzip": pygzip.compress(b"", 0, mtime=0), "deflate": zlib.compress(b"", 0)[2:-4]}[fmt]
+            check(e0s, fmt, 0, "empty, one final stored block " + fmt)
+            check(e0s + b"trailing", fmt, 4, "empty stored block, octets after the stream " + fmt)
         c = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
         check(c.compress(p1[:3000]) + c.flush(), "zlib", 3000, "fixed-Huffman block")
         check(zlib.compress(bytes(200_000), 6), "zlib", 200_000, "zeros (dense tokens)")

@@ -3003,6 +3003,7 @@ int tbz_inflate_device(tbz_ctx* ctx, int format, const void* d_in, size_t in_len
 // stream sharded across GPUs.  Whatever is not a clean chain (no markers, history across a cut, any error, a buffer that
 // is too small) is NOT decided here: *handled = false, the whole input is on the device by then (*uploaded), and the
 // caller decodes it by the ordinary path, whose statuses are the answer.
+static int sharded_plan(const uint8_t* in, size_t in_len, size_t n_parts, uint64_t* cuts, uint64_t max_scan);
 static int inflate_host_pipelined(tbz_ctx* ctx, int format, const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap,
                                   tbz_result* res, bool* handled, bool* uploaded) {
   using namespace tbz;
@@ -3010,7 +3011,7 @@ static int inflate_host_pipelined(tbz_ctx* ctx, int format, const uint8_t* in, s
   const size_t S = std::min<size_t>(64, std::max<size_t>(2, (in_len + ctx->pipe_part - 1) / ctx->pipe_part));
   std::vector<uint64_t> cuts(S + 1);
   int r;
-  if ((r = tbz_inflate_sharded_plan(in, in_len, S, cuts.data()))) return r;
+  if ((r = sharded_plan(in, in_len, S, cuts.data(), 2 * ctx->pipe_part))) return r;  // (a marker within two parts' worth, or none)
   size_t live = 0;
   for (size_t k = 0; k < S; k++) live += cuts[k + 1] > cuts[k];
   if (live < 2) return 0;  // (no flush markers: nothing to cut at)
@@ -3606,15 +3607,19 @@ int tbz_inflate_batch_multi_device(tbz_ctx* const* ctxs, size_t n_ctx, int forma
 // plan: cuts[0] = 0 (start), cuts[r] = end of the first flush marker at or after the r-th equal share of the octets
 // (in_len when there is none), cuts[n_parts] = in_len.  Part r is in[cuts[r], cuts[r+1]): part 0 in the stream's own
 // format, the others as raw deflate.
-int tbz_inflate_sharded_plan(const uint8_t* in, size_t in_len, size_t n_parts, uint64_t* cuts) {
+// max_scan: how far behind a part's nominal start a marker is looked for (the C entry: to the end of the input; the
+// pipelined host path: two parts' worth — a stream WITHOUT markers cost a scan of all its octets, 36 ms per GiB of
+// no-flush text, before the ordinary path even started)
+static int sharded_plan(const uint8_t* in, size_t in_len, size_t n_parts, uint64_t* cuts, uint64_t max_scan) {
   if (!cuts || !n_parts || (in_len && !in)) return TBZ_E_ARG;
   cuts[0] = 0;
   for (size_t r = 1; r < n_parts; r++) {
     const uint64_t share = (uint64_t)((unsigned __int128)in_len * r / n_parts);
     uint64_t p = std::max<uint64_t>(cuts[r - 1], share);
+    const uint64_t stop = max_scan < in_len - std::min<uint64_t>(in_len, p) ? p + max_scan : in_len;
     uint64_t cut = in_len;
-    while (p + 4 <= in_len) {
-      const uint8_t* q = (const uint8_t*)memchr(in + p, 0, in_len - p - 3);
+    while (p + 4 <= stop) {
+      const uint8_t* q = (const uint8_t*)memchr(in + p, 0, stop - p - 3);
       if (!q) break;
       p = (uint64_t)(q - in);
       if (in[p + 1] == 0 && in[p + 2] == 0xff && in[p + 3] == 0xff) {
@@ -3627,6 +3632,9 @@ int tbz_inflate_sharded_plan(const uint8_t* in, size_t in_len, size_t n_parts, u
   }
   cuts[n_parts] = in_len;
   return 0;
+}
+int tbz_inflate_sharded_plan(const uint8_t* in, size_t in_len, size_t n_parts, uint64_t* cuts) {
+  return sharded_plan(in, in_len, n_parts, cuts, ~0ull);
 }
 }  // extern "C"
 
